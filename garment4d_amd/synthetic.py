@@ -1,0 +1,88 @@
+"""Seeded synthetic inputs shaped like the reference's data.
+
+There is no CLOTH3D data, SMPL model file or checkpoint in this environment, so tests, the
+golden-fixture generator and bench.py all draw from these generators (numpy Generator/PCG64,
+explicit seeds).  numpy only -- no torch, no HIP.
+"""
+import numpy as np
+
+F32 = np.float32
+
+# SMPL kinematic tree (24 joints), as in the SMPL model files the reference loads
+# (smplx/smplx/body_models.py:49-251 reads `kintree_table`); parents[0] = -1.
+SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],
+                        dtype=np.int64)
+
+
+def unit_cloud(B, N, seed=0):
+    """xyz ~ U[0,1)^3, fp32, (B,N,3)."""
+    return np.random.default_rng(seed).random((B, N, 3), dtype=F32)
+
+
+def body_like_cloud(B, N, seed=0, dup_frac=0.2, zero_frac=0.1):
+    """Tie-heavy cloud: points on a 1.7 x 0.5 x 0.3 ellipsoid shell (shifted into [0,1]^3-ish),
+    a fraction of exact duplicates (the reference up-samples with duplicates,
+    utils/dataloader.py:36-44) and a zero-padded tail (modules/mesh_encoder.py:119-124)."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((B, N, 3)).astype(F32)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True).astype(F32) + F32(1e-12)
+    v = v * np.array([0.25, 0.85, 0.15], dtype=F32) + np.array([0.5, 0.9, 0.5], dtype=F32)
+    v = v.astype(F32)
+    nd = int(N * dup_frac)
+    nz = int(N * zero_frac)
+    if nd > 0:
+        src = rng.integers(0, max(N - nd - nz, 1), size=(B, nd))
+        for b in range(B):
+            v[b, N - nd - nz:N - nz] = v[b, src[b]]
+    if nz > 0:
+        v[:, N - nz:] = 0
+    return np.ascontiguousarray(v)
+
+
+def smpl_like_params(V=6890, J=24, num_betas=10, seed=0):
+    """SMPL-shaped random model parameters:
+    v_template (V,3), shapedirs (V,3,nb), posedirs ((J-1)*9, V*3), J_regressor (J,V) row-normalised
+    sparse-ish positives, parents (J,), lbs_weights (V,J) row-normalised sparse-ish positives."""
+    rng = np.random.default_rng(seed)
+    v_template = (rng.standard_normal((V, 3)) * np.array([0.25, 0.6, 0.15])).astype(F32)
+    shapedirs = (rng.standard_normal((V, 3, num_betas)) * 0.01).astype(F32)
+    posedirs = (rng.standard_normal(((J - 1) * 9, V * 3)) * 0.001).astype(F32)
+    jr = rng.random((J, V)).astype(F32)
+    jr *= (rng.random((J, V)) < min(1.0, 40.0 / V)).astype(F32)
+    jr[:, 0] += F32(1e-3)
+    J_regressor = (jr / jr.sum(1, keepdims=True)).astype(F32)
+    w = rng.random((V, J)).astype(F32) ** 4
+    keep = rng.random((V, J)) < (4.0 / J)
+    w = w * keep
+    w[np.arange(V), rng.integers(0, J, size=V)] += F32(0.5)
+    lbs_weights = (w / w.sum(1, keepdims=True)).astype(F32)
+    if J == 24:
+        parents = SMPL_PARENTS.copy()
+    else:
+        parents = np.array([-1] + [int(rng.integers(0, i)) for i in range(1, J)], dtype=np.int64)
+    return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
+                parents=parents, lbs_weights=lbs_weights)
+
+
+def smpl_like_pose(B, J=24, num_betas=10, seed=1):
+    """betas ~ N(0,1) (B,nb); axis-angle pose ~ N(0,0.2^2) (B,J*3)."""
+    rng = np.random.default_rng(seed)
+    betas = rng.standard_normal((B, num_betas)).astype(F32)
+    pose = (rng.standard_normal((B, J * 3)) * 0.2).astype(F32)
+    return betas, pose
+
+
+def quad_cylinder(rows, cols):
+    """A closed-around quad cylinder: vertices (rows*cols,3), faces (.,4) int32 -- stands in for
+    the garment template mesh (`remesh_cylinder_f`, modules/mesh_encoder.py:286)."""
+    th = np.linspace(0, 2 * np.pi, cols, endpoint=False)
+    h = np.linspace(0, 1, rows)
+    verts = np.stack([np.repeat(np.cos(th)[None], rows, 0) * 0.2, np.repeat(h[:, None], cols, 1),
+                      np.repeat(np.sin(th)[None], rows, 0) * 0.2], axis=-1).reshape(-1, 3).astype(F32)
+    faces = []
+    for r in range(rows - 1):
+        for c in range(cols):
+            a = r * cols + c
+            b = r * cols + (c + 1) % cols
+            faces.append([a, b, b + cols, a + cols])
+    return verts, np.asarray(faces, dtype=np.int32)
