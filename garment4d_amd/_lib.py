@@ -1,0 +1,68 @@
+"""ctypes binding of libg4d_hip.so (the C ABI declared in include/g4d.h).
+
+The library is built in-tree (garment4d_amd/lib/libg4d_hip.so) by `__graft_entry__.build()` /
+`make -C garment4d_amd/csrc`.  There is NO fallback: if the library is missing, or a call fails,
+this raises -- the product path never silently routes to PyTorch eager or to the CPU oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libg4d_hip.so")
+
+_vp = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes (stream last); every function returns int status (0 = ok)
+SIGNATURES = {
+    "g4d_fps_f32": [_I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_gather_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_gather_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_ball_query_f32": [_I, _I, _I, _F, _I, _vp, _vp, _vp, _vp],
+    "g4d_group_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_group_grad_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_three_nn_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],
+    "g4d_three_interp_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
+    "g4d_three_interp_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+class G4DError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libg4d_hip.so once; raise (loudly) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise G4DError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import "
+                f"__graft_entry__ as g; g.build()'` (or `make -C garment4d_amd/csrc`). There is no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.argtypes = args
+            fn.restype = _I
+        L.g4d_version.restype = _I
+        L.g4d_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point; non-zero status -> G4DError (the reference would exit(-1))."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise G4DError(f"{name} failed with status {rc}: {L.g4d_last_error().decode(errors='replace')}")
+    return rc
+
+
+def stream_ptr():
+    """The current torch HIP stream as a raw hipStream_t (reference: at::cuda::getCurrentCUDAStream())."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream

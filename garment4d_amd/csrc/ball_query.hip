@@ -1,0 +1,104 @@
+// Ball query for gfx950 -- replaces ball_query_kernel_fast / ball_query_kernel_launcher_fast
+// (/root/reference/modules/pointnet2/pointnet2/src/ball_query_gpu.cu:9-67).
+//
+// Semantics kept: for query q, hits = ascending k with d2 = (qx-x)^2 + (qy-y)^2 + (qz-z)^2 < r*r
+// (fp32, left-to-right, no fma; r*r rounded once in fp32); out = first `nsample` hits, remaining slots
+// = first hit, all 0 when there is no hit.
+//
+// Layout for the hardware (the reference runs one THREAD per query, each scanning N points serially
+// with broadcast loads and a divergent early exit):
+//   * one WAVE owns QW queries; its 64 lanes test 64 consecutive points per step, so the cloud is read
+//     coalesced (768 B per wave-step) and each loaded point is reused for QW queries whose centres sit
+//     in SGPRs (wave-uniform) -> 9 VALU per 64 point-query pairs, L2->CU traffic cut QW x;
+//   * ascending-index order falls out of ballot + mbcnt prefix (slot = cnt + #hits in lower lanes);
+//   * the hit path is scalar-branched and rare (a radius-0.1 ball holds ~0.4 % of a unit cloud);
+//   * early exit once all QW queries are full.
+// Algorithmic bytes: 12*B*(N+M) + 4*B*M*nsample; B*M*N distance evaluations worst case.
+#include "g4d_common.h"
+
+namespace g4d {
+
+template <int QW>
+__global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                        const float *__restrict__ new_xyz_all,
+                                                        const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * QW;
+    if (q0 >= m) return;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
+    int *idx = idx_all + ((size_t)b * m + q0) * nsample;
+
+    float qx[QW], qy[QW], qz[QW];
+    int cnt[QW], first[QW];
+    int open = 0;  // queries still collecting
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = min(q0 + i, m - 1);
+        qx[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 0])));
+        qy[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 1])));
+        qz[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 2])));
+        cnt[i] = (q0 + i < m) ? 0 : nsample;  // out-of-range query slots start "full"
+        first[i] = 0;
+        open += (q0 + i < m) ? 1 : 0;
+    }
+
+    for (int base = 0; base < n && open > 0; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < n;
+        const int kc = valid ? k : n - 1;
+        const float x = xyz[kc * 3 + 0], y = xyz[kc * 3 + 1], z = xyz[kc * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            if (cnt[i] < nsample) {  // wave-uniform
+                const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const bool hit = valid && (d2 < radius2);
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask != 0ull) {  // wave-uniform, rare
+                    if (cnt[i] == 0) first[i] = base + __builtin_ctzll(mask);
+                    const int slot = cnt[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (hit && slot < nsample) idx[(size_t)i * nsample + slot] = k;
+                    cnt[i] += __builtin_popcountll(mask);
+                    if (cnt[i] >= nsample) --open;
+                }
+            }
+        }
+    }
+    // pad with the first hit (ball_query_gpu.cu:32-36); rows without a hit are zeros
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        if (q0 + i < m && cnt[i] < nsample) {
+            for (int l = cnt[i] + lane; l < nsample; l += 64) idx[(size_t)i * nsample + l] = first[i];
+        }
+    }
+}
+
+}  // namespace g4d
+
+extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                                  int *idx, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "g4d_ball_query_f32: negative size");
+    if (b == 0 || m == 0 || nsample == 0) return G4D_OK;
+    G4D_REQUIRE(new_xyz && xyz && idx, "g4d_ball_query_f32: null pointer");
+    G4D_REQUIRE(b <= 65535, "g4d_ball_query_f32: b > 65535 not supported");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n == 0) return (int)hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * m * nsample, s);
+    const float radius2 = radius * radius;  // ball_query_gpu.cu:23, rounded once in fp32
+    // pick queries-per-wave so the launch still has >= ~2048 waves when the problem allows
+    const long long queries = (long long)b * m;
+    int qw = 8;
+    while (qw > 1 && queries / qw < 2048) qw >>= 1;
+    const int per_block = 4 * qw;
+    dim3 grid((m + per_block - 1) / per_block, b), block(256);
+    switch (qw) {
+        case 8: hipLaunchKernelGGL(ball_query_kernel<8>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
+        case 4: hipLaunchKernelGGL(ball_query_kernel<4>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
+        case 2: hipLaunchKernelGGL(ball_query_kernel<2>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
+        default: hipLaunchKernelGGL(ball_query_kernel<1>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
+    }
+    return check_launch("g4d_ball_query_f32");
+}

@@ -1,0 +1,287 @@
+// Furthest point sampling for gfx950 -- replaces furthest_point_sampling_kernel(_launcher)
+// (/root/reference/modules/pointnet2/pointnet2/src/sampling_gpu.cu:93-253).
+//
+// Semantics kept bit-for-bit: idx[0]=0; round j: mind[k] = min(d(k,old), mind[k])
+// with d = dx*dx + dy*dy + dz*dz evaluated left-to-right in fp32 WITHOUT fma (this file is built with
+// -ffp-contract=off); next = arg-max mind[k], ties resolved like the reference's strided scan +
+// shared-memory tree: let bs = min(1024, 2^floor(log2 N)); smallest bit-reversed (k mod bs) wins, then
+// smallest k.  That total order lets the work be laid out for the hardware instead of copying the
+// reference's thread/tree shape:
+//
+//   * one workgroup per cloud (the rounds are strictly serial; clouds are the parallel axis);
+//   * the cloud and its running min-distances live in VGPRs for the whole kernel (N <= 16384): a thread
+//     owns U residue classes x Q points, visited in ascending tie-rank so a strict `>` scan keeps the
+//     right candidate with 3 VALU ops per point (cmp + 2 cndmask) on top of the 9 distance/min ops;
+//   * per round ONE barrier: wave arg-max by DPP (row_shr / row_bcast, no LDS), each wave publishes a
+//     16-byte candidate into a parity-double-buffered LDS slot, every thread folds the W candidates;
+//   * the winner's coordinates come from an LDS SoA copy of the cloud (broadcast ds_read), never HBM.
+//
+// FPS is bound by the serial dependency chain (rounds x [VALU sweep + wave reduce + barrier + LDS
+// round trip]), not by HBM or MFMA: algorithmic traffic is 12*N + 8*N + 4*M bytes per cloud.
+#include "g4d_common.h"
+
+namespace g4d {
+
+template <int U>
+__device__ __host__ constexpr int brev_small(int v) {
+    // bit reversal on log2(U) bits, U in {1,2,4,8,16}
+    int r = 0;
+    for (int bit = 1, rb = U >> 1; bit < U; bit <<= 1, rb >>= 1)
+        if (v & bit) r |= rb;
+    return r;
+}
+
+struct FpsCand {  // one wave's candidate for this round
+    float val;
+    unsigned rank;  // (bitrev(k mod bs) << 16) | (k / bs): smaller wins among equal val
+    int k;
+    int pad;
+};
+
+__device__ __forceinline__ unsigned fps_rank(int k, int bs, int log2bs) {
+    const unsigned c = (unsigned)k & (unsigned)(bs - 1);
+    const unsigned q = (unsigned)k >> log2bs;
+    const unsigned br = log2bs ? (__builtin_bitreverse32(c) >> (32 - log2bs)) : 0u;
+    return (br << 16) | q;
+}
+
+// Wave arg-max under (value desc, rank asc).  `best` per lane, `k` per lane.  Returns uniform results.
+__device__ __forceinline__ void wave_argmax(float best, int k, int bs, int log2bs, float &wval, int &wk, unsigned &wrank) {
+    wval = wave_max_f32(best);
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(best == wval);
+    int lane;
+    if (__builtin_popcountll(hit) == 1) {  // uniform branch; the common case
+        lane = __builtin_ctzll(hit);
+        wk = __builtin_amdgcn_readlane(k, lane);
+        wrank = fps_rank(wk, bs, log2bs);
+    } else {
+        const unsigned r = (best == wval) ? fps_rank(k, bs, log2bs) : 0xffffffffu;
+        wrank = wave_min_u32(r);
+        lane = __builtin_ctzll(__builtin_amdgcn_ballot_w64(r == wrank));
+        wk = __builtin_amdgcn_readlane(k, lane);
+    }
+}
+
+// Register-resident FPS: T = 64*W threads; thread t owns classes t + u*T (u < U = bs/T) and, per class,
+// points c + q*bs (q < Q).  Slot i = v*Q + q visits u = bitrev(v) so that tie-rank ascends with i.
+template <int W, int U, int Q>
+__global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
+                                                        float *__restrict__ temp_all, int *__restrict__ idx_all) {
+    constexpr int T = 64 * W, P = U * Q;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    FpsCand *slots = reinterpret_cast<FpsCand *>(smem_raw);          // [2][W]
+    float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * 16);   // SoA copy of the cloud
+    float *sy = sx + n;
+    float *sz = sy + n;
+
+    const int t = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    float *temp = temp_all + (size_t)blockIdx.x * n;
+    int *idx = idx_all + (size_t)blockIdx.x * m;
+
+    float px[P], py[P], pz[P], md[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = t + brev_small<U>(i / Q) * T + (i % Q) * bs;
+        const bool ok = k < n;
+        px[i] = ok ? xyz[k * 3 + 0] : 0.f;
+        py[i] = ok ? xyz[k * 3 + 1] : 0.f;
+        pz[i] = ok ? xyz[k * 3 + 2] : 0.f;
+        md[i] = ok ? temp[k] : -2.f;  // -2 never beats the scan's initial best (-1)
+        if (ok) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
+    }
+    if (t == 0) idx[0] = 0;
+    __syncthreads();
+
+    float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+    const int wave = t >> 6;
+    for (int j = 1; j < m; ++j) {
+        float best = -1.f;
+        int bslot = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const float d2 = fminf(d, md[i]);
+            md[i] = d2;
+            const bool gt = d2 > best;
+            bslot = gt ? i : bslot;
+            best = gt ? d2 : best;
+        }
+        int k;
+        if constexpr (P == 1) k = t;
+        else k = t + brev_small<U>(bslot / Q) * T + (bslot % Q) * bs;  // U,Q powers of two: shifts/masks
+        float wval; int wk; unsigned wrank;
+        wave_argmax(best, k, bs, log2bs, wval, wk, wrank);
+        int old;
+        if constexpr (W == 1) {
+            old = wk;
+        } else {
+            FpsCand *buf = slots + (j & 1) * W;
+            if ((t & 63) == 0) { FpsCand c; c.val = wval; c.rank = wrank; c.k = wk; c.pad = 0; buf[wave] = c; }
+            __syncthreads();
+            FpsCand bc = buf[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) {
+                const FpsCand c = buf[w];
+                const bool take = (c.val > bc.val) || (c.val == bc.val && c.rank < bc.rank);
+                bc.val = take ? c.val : bc.val;
+                bc.rank = take ? c.rank : bc.rank;
+                bc.k = take ? c.k : bc.k;
+            }
+            old = __builtin_amdgcn_readfirstlane(bc.k);
+        }
+        x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
+        if (t == 0) idx[j] = old;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = t + brev_small<U>(i / Q) * T + (i % Q) * bs;
+        if (k < n) temp[k] = md[i];
+    }
+}
+
+// Any-N fallback: the reference's thread shape (class c = tid, strided scan from L2-resident global
+// memory), the same DPP + one-barrier reduction.  1024 threads; threads >= bs idle.
+__global__ void __launch_bounds__(1024) fps_generic_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
+                                                          float *__restrict__ temp_all, int *__restrict__ idx_all) {
+    constexpr int W = 16;
+    __shared__ FpsCand slots[2][W];
+    const int t = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    float *temp = temp_all + (size_t)blockIdx.x * n;
+    int *idx = idx_all + (size_t)blockIdx.x * m;
+    if (t == 0) idx[0] = 0;
+    int old = 0;
+    const int wave = t >> 6;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+        float best = -1.f;
+        int besti = 0;
+        if (t < bs) {
+            for (int k = t; k < n; k += bs) {
+                const float dx = xyz[k * 3 + 0] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
+                const float d = dx * dx + dy * dy + dz * dz;
+                const float d2 = fminf(d, temp[k]);
+                temp[k] = d2;
+                const bool gt = d2 > best;
+                besti = gt ? k : besti;
+                best = gt ? d2 : best;
+            }
+        } else {
+            best = -3.f;  // below every real thread's -1: an idle thread never wins
+        }
+        // a thread whose points all failed `>` reports (best=-1, besti=0) like the reference; its rank
+        // must be that of ITS class, not of point 0, so rank from the class id
+        float wval; int wk; unsigned wrank;
+        {
+            wval = wave_max_f32(best);
+            const unsigned r = (best == wval) ? ((t < bs ? ((log2bs ? (__builtin_bitreverse32((unsigned)t) >> (32 - log2bs)) : 0u) << 16) : 0xffff0000u) |
+                                                 (unsigned)(besti >> log2bs))
+                                              : 0xffffffffu;
+            wrank = wave_min_u32(r);
+            const int lane = __builtin_ctzll(__builtin_amdgcn_ballot_w64(r == wrank));
+            wk = __builtin_amdgcn_readlane(besti, lane);
+        }
+        FpsCand *buf = slots[j & 1];
+        if ((t & 63) == 0) { FpsCand c; c.val = wval; c.rank = wrank; c.k = wk; c.pad = 0; buf[wave] = c; }
+        __syncthreads();
+        FpsCand bc = buf[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+            const FpsCand c = buf[w];
+            const bool take = (c.val > bc.val) || (c.val == bc.val && c.rank < bc.rank);
+            bc.val = take ? c.val : bc.val;
+            bc.rank = take ? c.rank : bc.rank;
+            bc.k = take ? c.k : bc.k;
+        }
+        old = __builtin_amdgcn_readfirstlane(bc.k);
+        if (t == 0) idx[j] = old;
+    }
+}
+
+// cuda_utils.h:10-14 opt_n_threads(), through double log() exactly as the reference.
+static int ref_block_size(int work_size) {
+    const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+template <int W, int U, int Q>
+static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+    const size_t lds = 2 * 16 * 16 + (size_t)n * 12;
+    auto kern = fps_reg_kernel<W, U, Q>;
+    static bool attr_done = false;  // benign race: idempotent
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
+    return check_launch("g4d_fps_f32");
+}
+
+static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|0(generic)
+
+}  // namespace g4d
+
+extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "g4d_fps_f32: negative size (b=%d n=%d m=%d)", b, n, m);
+    if (b == 0 || m == 0) return G4D_OK;  // sampling_gpu.cu:100  if (m <= 0) return;
+    G4D_REQUIRE(n > 0, "g4d_fps_f32: n must be > 0 when m > 0");
+    G4D_REQUIRE(xyz && temp && idx, "g4d_fps_f32: null pointer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int bs = ref_block_size(n);
+    int log2bs = 0;
+    while ((1 << log2bs) < bs) ++log2bs;
+    const int q = (n + bs - 1) / bs;
+    if (g_fps_force_w < 0) {
+        const char *e = getenv("G4D_FPS_W");
+        g_fps_force_w = e ? atoi(e) : 99;
+    }
+    const int force = g_fps_force_w;
+    const bool lds_ok = (size_t)n * 12 + 512 <= 150 * 1024;
+#define G4D_FPS_CASE(W, U, Q) return launch_reg<W, U, Q>(b, n, m, bs, log2bs, xyz, temp, idx, s)
+    if (lds_ok && force != 0 && bs >= 64) {
+        const int qp = q <= 1 ? 1 : q <= 2 ? 2 : q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : 0;
+        // single wave: no barrier at all; preferred for small clouds
+        const bool want_w1 = (force == 1) || (force != 4 && n <= 512);
+        if (want_w1 && qp && (bs / 64) * qp <= 32) {
+            const int u = bs / 64;
+            if (u == 1 && qp == 1) G4D_FPS_CASE(1, 1, 1);
+            if (u == 1 && qp == 2) G4D_FPS_CASE(1, 1, 2);
+            if (u == 2 && qp == 1) G4D_FPS_CASE(1, 2, 1);
+            if (u == 2 && qp == 2) G4D_FPS_CASE(1, 2, 2);
+            if (u == 4 && qp == 1) G4D_FPS_CASE(1, 4, 1);
+            if (u == 4 && qp == 2) G4D_FPS_CASE(1, 4, 2);
+            if (u == 8 && qp == 1) G4D_FPS_CASE(1, 8, 1);
+            if (u == 8 && qp == 2) G4D_FPS_CASE(1, 8, 2);
+            if (u == 16 && qp == 1) G4D_FPS_CASE(1, 16, 1);
+            if (u == 16 && qp == 2) G4D_FPS_CASE(1, 16, 2);
+        }
+        if (bs >= 256 && qp) {
+            const int u = bs / 256;
+            if (u == 1 && qp == 1) G4D_FPS_CASE(4, 1, 1);
+            if (u == 1 && qp == 2) G4D_FPS_CASE(4, 1, 2);
+            if (u == 2 && qp == 1) G4D_FPS_CASE(4, 2, 1);
+            if (u == 2 && qp == 2) G4D_FPS_CASE(4, 2, 2);
+            if (u == 4 && qp == 1) G4D_FPS_CASE(4, 4, 1);
+            if (u == 4 && qp == 2) G4D_FPS_CASE(4, 4, 2);
+            if (u == 4 && qp == 4) G4D_FPS_CASE(4, 4, 4);
+            if (u == 4 && qp == 8) G4D_FPS_CASE(4, 4, 8);
+            if (u == 4 && qp == 16 && (size_t)n * 12 + 512 <= 150 * 1024) G4D_FPS_CASE(4, 4, 16);
+        }
+        if (bs >= 64 && bs < 256 && qp && (bs / 64) * qp <= 32) {  // 64 <= n < 256: single wave
+            const int u = bs / 64;
+            if (u == 1 && qp == 1) G4D_FPS_CASE(1, 1, 1);
+            if (u == 1 && qp == 2) G4D_FPS_CASE(1, 1, 2);
+            if (u == 2 && qp == 1) G4D_FPS_CASE(1, 2, 1);
+            if (u == 2 && qp == 2) G4D_FPS_CASE(1, 2, 2);
+        }
+    }
+#undef G4D_FPS_CASE
+    hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx);
+    return check_launch("g4d_fps_f32(generic)");
+}

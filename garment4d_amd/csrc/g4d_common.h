@@ -1,0 +1,68 @@
+// Shared device/host helpers for libg4d_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/g4d.h"
+
+namespace g4d {
+
+void set_error(const char *fmt, ...);
+
+// Every launcher ends with this: report, never exit (the reference exits: sampling_gpu.cu:248-252).
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return G4D_OK;
+}
+
+#define G4D_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            g4d::set_error(__VA_ARGS__); \
+            return G4D_EINVAL;          \
+        }                               \
+    } while (0)
+
+constexpr int kWave = 64;
+
+// ---- wave-level primitives (DPP, no LDS) ------------------------------------------------------
+// dpp_ctrl encodings: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    // old = v: lanes whose source is outside the row / masked keep their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// max over the 64 lanes, returned wave-uniform (SGPR).  No NaNs expected in v.
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_mov_f<0x111, 0xf>(v));
+    v = fmaxf(v, dpp_mov_f<0x112, 0xf>(v));
+    v = fmaxf(v, dpp_mov_f<0x114, 0xf>(v));
+    v = fmaxf(v, dpp_mov_f<0x118, 0xf>(v));  // lane 15 of each row = row max
+    v = fmaxf(v, dpp_mov_f<0x142, 0xa>(v));  // row_bcast:15 into rows 1,3
+    v = fmaxf(v, dpp_mov_f<0x143, 0xc>(v));  // row_bcast:31 into rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, dpp_mov_u<0x111, 0xf>(v));
+    v = min(v, dpp_mov_u<0x112, 0xf>(v));
+    v = min(v, dpp_mov_u<0x114, 0xf>(v));
+    v = min(v, dpp_mov_u<0x118, 0xf>(v));
+    v = min(v, dpp_mov_u<0x142, 0xa>(v));
+    v = min(v, dpp_mov_u<0x143, 0xc>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+}  // namespace g4d

@@ -1,0 +1,241 @@
+// gather / group / three_nn / three_interpolate (+ the three scatter-add backward kernels) for gfx950.
+// Replaces /root/reference/modules/pointnet2/pointnet2/src/{sampling_gpu.cu:8-83, group_points_gpu.cu:8-86,
+// interpolate_gpu.cu:9-161}.  All HBM/L2-bound copies or scans: coalesced along the point axis, the index
+// row is read ONCE per thread and reused for a chunk of channels (the reference re-reads it per channel),
+// 64-bit offsets (the reference's int32 offsets wrap at 2^31 elements).
+#include "g4d_common.h"
+
+namespace g4d {
+
+constexpr int kCT = 8;  // channels per thread in the copy kernels
+
+// out[b,c,e] = points[b,c,idx[b,e]]  (e over npoints*nsample; gather is nsample == 1)
+__global__ void __launch_bounds__(256) group_kernel(int c, int n, long long e_total, const float *__restrict__ points,
+                                                   const int *__restrict__ idx, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= e_total) return;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * kCT;
+    const int k = idx[(size_t)b * e_total + e];
+    const float *src = points + ((size_t)b * c + c0) * n + k;
+    float *dst = out + ((size_t)b * c + c0) * e_total + e;
+    const int cn = min(kCT, c - c0);
+    float v[kCT];
+#pragma unroll
+    for (int i = 0; i < kCT; ++i)
+        if (i < cn) v[i] = src[(size_t)i * n];
+#pragma unroll
+    for (int i = 0; i < kCT; ++i)
+        if (i < cn) dst[(size_t)i * e_total] = v[i];
+}
+
+// grad_points[b,c,idx[b,e]] += grad_out[b,c,e]
+__global__ void __launch_bounds__(256) group_grad_kernel(int c, int n, long long e_total, const float *__restrict__ grad_out,
+                                                        const int *__restrict__ idx, float *__restrict__ grad_points) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= e_total) return;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * kCT;
+    const int k = idx[(size_t)b * e_total + e];
+    float *dst = grad_points + ((size_t)b * c + c0) * n + k;
+    const float *src = grad_out + ((size_t)b * c + c0) * e_total + e;
+    const int cn = min(kCT, c - c0);
+#pragma unroll
+    for (int i = 0; i < kCT; ++i)
+        if (i < cn) atomicAdd(dst + (size_t)i * n, src[(size_t)i * e_total]);
+}
+
+// three nearest known points per unknown point.  One thread per unknown point (as the reference), but the
+// known points are staged through LDS in 16-byte slots and read as wave-broadcast ds_read_b128, and the
+// top-3 insertion only runs when some lane of the wave needs it.
+constexpr int kNNChunk = 1024;
+__global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
+                                                      const float *__restrict__ known_all, float *__restrict__ dist2_all,
+                                                      int *__restrict__ idx_all) {
+    __shared__ float4 sk[kNNChunk];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const float *known = known_all + (size_t)b * m * 3;
+    const int pc = min(p, n - 1);
+    const float *u = unknown_all + ((size_t)b * n + pc) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    // interpolate_gpu.cu:24-25: double best = 1e40 compared against a float d == float compare against +inf
+    float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int base = 0; base < m; base += kNNChunk) {
+        const int cm = min(kNNChunk, m - base);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cm; j += 256) {
+            const float *kp = known + (size_t)(base + j) * 3;
+            sk[j] = make_float4(kp[0], kp[1], kp[2], 0.f);
+        }
+        __syncthreads();
+        for (int j = 0; j < cm; ++j) {
+            const float4 kq = sk[j];
+            const float dx = ux - kq.x, dy = uy - kq.y, dz = uz - kq.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (__builtin_amdgcn_ballot_w64(d < b3) != 0ull) {  // wave-uniform skip
+                const int k = base + j;
+                const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;
+                // cascade of interpolate_gpu.cu:31-42, branch-free
+                const float nb3 = lt2 ? b2 : (lt3 ? d : b3);
+                const int ni3 = lt2 ? i2 : (lt3 ? k : i3);
+                const float nb2 = lt1 ? b1 : (lt2 ? d : b2);
+                const int ni2 = lt1 ? i1 : (lt2 ? k : i2);
+                b1 = lt1 ? d : b1; i1 = lt1 ? k : i1;
+                b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+            }
+        }
+    }
+    if (p < n) {
+        float *d2 = dist2_all + ((size_t)b * n + p) * 3;
+        int *ix = idx_all + ((size_t)b * n + p) * 3;
+        d2[0] = b1; d2[1] = b2; d2[2] = b3;
+        ix[0] = i1; ix[1] = i2; ix[2] = i3;
+    }
+}
+
+// out[b,c,p] = w0*pts[b,c,i0] + w1*pts[b,c,i1] + w2*pts[b,c,i2]   (left-to-right, unfused)
+__global__ void __launch_bounds__(256) three_interp_kernel(int c, int m, int n, const float *__restrict__ points,
+                                                          const int *__restrict__ idx, const float *__restrict__ weight,
+                                                          float *__restrict__ out) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * kCT;
+    const int *ix = idx + ((size_t)b * n + p) * 3;
+    const float *w = weight + ((size_t)b * n + p) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const float *src = points + ((size_t)b * c + c0) * m;
+    float *dst = out + ((size_t)b * c + c0) * n + p;
+    const int cn = min(kCT, c - c0);
+#pragma unroll
+    for (int i = 0; i < kCT; ++i)
+        if (i < cn) {
+            const float *row = src + (size_t)i * m;
+            dst[(size_t)i * n] = w0 * row[i0] + w1 * row[i1] + w2 * row[i2];
+        }
+}
+
+__global__ void __launch_bounds__(256) three_interp_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                                               const int *__restrict__ idx, const float *__restrict__ weight,
+                                                               float *__restrict__ grad_points) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * kCT;
+    const int *ix = idx + ((size_t)b * n + p) * 3;
+    const float *w = weight + ((size_t)b * n + p) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const float *src = grad_out + ((size_t)b * c + c0) * n + p;
+    float *dst = grad_points + ((size_t)b * c + c0) * m;
+    const int cn = min(kCT, c - c0);
+#pragma unroll
+    for (int i = 0; i < kCT; ++i)
+        if (i < cn) {
+            const float g = src[(size_t)i * n];
+            float *row = dst + (size_t)i * m;
+            atomicAdd(row + i0, g * w0);
+            atomicAdd(row + i1, g * w1);
+            atomicAdd(row + i2, g * w2);
+        }
+}
+
+static inline int launch_group(int b, int c, int n, long long e_total, const float *points, const int *idx, float *out,
+                               hipStream_t s, const char *what) {
+    if (b == 0 || c == 0 || e_total == 0) return G4D_OK;
+    dim3 grid((unsigned)((e_total + 255) / 256), (c + kCT - 1) / kCT, b);
+    hipLaunchKernelGGL(group_kernel, grid, dim3(256), 0, s, c, n, e_total, points, idx, out);
+    return check_launch(what);
+}
+
+static inline int launch_group_grad(int b, int c, int n, long long e_total, const float *grad_out, const int *idx,
+                                    float *grad_points, hipStream_t s, const char *what) {
+    if (b == 0 || c == 0 || e_total == 0) return G4D_OK;
+    dim3 grid((unsigned)((e_total + 255) / 256), (c + kCT - 1) / kCT, b);
+    hipLaunchKernelGGL(group_grad_kernel, grid, dim3(256), 0, s, c, n, e_total, grad_out, idx, grad_points);
+    return check_launch(what);
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+#define G4D_STREAM(s) reinterpret_cast<hipStream_t>(s)
+#define G4D_DIMS_OK(name, ...)                                         \
+    do {                                                               \
+        const long long dims_[] = {__VA_ARGS__};                       \
+        for (long long d_ : dims_) G4D_REQUIRE(d_ >= 0, name ": negative size"); \
+    } while (0)
+
+extern "C" int g4d_gather_f32(int b, int c, int n, int m, const float *points, const int *idx, float *out,
+                              g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_gather_f32", b, c, n, m);
+    G4D_REQUIRE(b <= 65535 && (c + kCT - 1) / kCT <= 65535, "g4d_gather_f32: b or c too large for the grid");
+    if ((long long)b * c * m == 0) return G4D_OK;
+    G4D_REQUIRE(points && idx && out, "g4d_gather_f32: null pointer");
+    return launch_group(b, c, n, m, points, idx, out, G4D_STREAM(stream), "g4d_gather_f32");
+}
+
+extern "C" int g4d_gather_grad_f32(int b, int c, int n, int m, const float *grad_out, const int *idx, float *grad_points,
+                                   g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_gather_grad_f32", b, c, n, m);
+    G4D_REQUIRE(b <= 65535 && (c + kCT - 1) / kCT <= 65535, "g4d_gather_grad_f32: b or c too large for the grid");
+    if ((long long)b * c * m == 0) return G4D_OK;
+    G4D_REQUIRE(grad_out && idx && grad_points, "g4d_gather_grad_f32: null pointer");
+    return launch_group_grad(b, c, n, m, grad_out, idx, grad_points, G4D_STREAM(stream), "g4d_gather_grad_f32");
+}
+
+extern "C" int g4d_group_f32(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                             g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_group_f32", b, c, n, npoints, nsample);
+    G4D_REQUIRE(b <= 65535 && (c + kCT - 1) / kCT <= 65535, "g4d_group_f32: b or c too large for the grid");
+    if ((long long)b * c * npoints * nsample == 0) return G4D_OK;
+    G4D_REQUIRE(points && idx && out, "g4d_group_f32: null pointer");
+    return launch_group(b, c, n, (long long)npoints * nsample, points, idx, out, G4D_STREAM(stream), "g4d_group_f32");
+}
+
+extern "C" int g4d_group_grad_f32(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                                  float *grad_points, g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_group_grad_f32", b, c, n, npoints, nsample);
+    G4D_REQUIRE(b <= 65535 && (c + kCT - 1) / kCT <= 65535, "g4d_group_grad_f32: b or c too large for the grid");
+    if ((long long)b * c * npoints * nsample == 0) return G4D_OK;
+    G4D_REQUIRE(grad_out && idx && grad_points, "g4d_group_grad_f32: null pointer");
+    return launch_group_grad(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points, G4D_STREAM(stream),
+                             "g4d_group_grad_f32");
+}
+
+extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                                g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_three_nn_f32", b, n, m);
+    G4D_REQUIRE(b <= 65535, "g4d_three_nn_f32: b > 65535 not supported");
+    if ((long long)b * n == 0) return G4D_OK;
+    G4D_REQUIRE(unknown && dist2 && idx && (known || m == 0), "g4d_three_nn_f32: null pointer");
+    dim3 grid((n + 255) / 256, b);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx);
+    return check_launch("g4d_three_nn_f32");
+}
+
+extern "C" int g4d_three_interp_f32(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                    float *out, g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_three_interp_f32", b, c, m, n);
+    G4D_REQUIRE(b <= 65535 && (c + kCT - 1) / kCT <= 65535, "g4d_three_interp_f32: b or c too large for the grid");
+    if ((long long)b * c * n == 0) return G4D_OK;
+    G4D_REQUIRE(points && idx && weight && out, "g4d_three_interp_f32: null pointer");
+    dim3 grid((n + 255) / 256, (c + kCT - 1) / kCT, b);
+    hipLaunchKernelGGL(three_interp_kernel, grid, dim3(256), 0, G4D_STREAM(stream), c, m, n, points, idx, weight, out);
+    return check_launch("g4d_three_interp_f32");
+}
+
+extern "C" int g4d_three_interp_grad_f32(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                         const float *weight, float *grad_points, g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_three_interp_grad_f32", b, c, n, m);
+    G4D_REQUIRE(b <= 65535 && (c + kCT - 1) / kCT <= 65535, "g4d_three_interp_grad_f32: b or c too large for the grid");
+    if ((long long)b * c * n == 0) return G4D_OK;
+    G4D_REQUIRE(grad_out && idx && weight && grad_points, "g4d_three_interp_grad_f32: null pointer");
+    dim3 grid((n + 255) / 256, (c + kCT - 1) / kCT, b);
+    hipLaunchKernelGGL(three_interp_grad_kernel, grid, dim3(256), 0, G4D_STREAM(stream), c, n, m, grad_out, idx, weight,
+                       grad_points);
+    return check_launch("g4d_three_interp_grad_f32");
+}

@@ -1,0 +1,87 @@
+"""Drop-in for the reference's compiled extension module `pointnet2_cuda`.
+
+Same nine entry points, argument order and in-place output convention as
+/root/reference/modules/pointnet2/pointnet2/src/pointnet2_api.cpp:10-24 (C++ wrappers in
+src/sampling.cpp:11-46, ball_query.cpp:14-25, group_points.cpp, interpolate.cpp); each one forwards raw
+device pointers and the current torch stream to the C ABI of libg4d_hip.so (include/g4d.h).
+
+Error behaviour: wrong dtype / device / non-contiguous input raise (the reference raises a c10 error from
+`.data<float>()` or TORCH_CHECK for ball_query, ball_query.cpp:10-17); a failed launch raises
+RuntimeError instead of the reference's exit(-1).
+
+Install under the reference's name with `garment4d_amd.install_as_pointnet2_cuda()` or by putting the repo
+root (which holds a `pointnet2_cuda.py` shim) on PYTHONPATH.
+"""
+import torch
+
+from . import _lib
+
+
+def _chk(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected scalar type {dtype} but found {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _f(t, name):
+    return _chk(t, torch.float32, name)
+
+
+def _i(t, name):
+    return _chk(t, torch.int32, name)
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    _lib.call("g4d_ball_query_f32", b, n, m, float(radius), nsample, _f(new_xyz, "new_xyz"), _f(xyz, "xyz"),
+              _i(idx, "idx"), _lib.stream_ptr())
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    _lib.call("g4d_group_f32", b, c, n, npoints, nsample, _f(points, "points"), _i(idx, "idx"), _f(out, "out"),
+              _lib.stream_ptr())
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    _lib.call("g4d_group_grad_f32", b, c, n, npoints, nsample, _f(grad_out, "grad_out"), _i(idx, "idx"),
+              _f(grad_points, "grad_points"), _lib.stream_ptr())
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    _lib.call("g4d_gather_f32", b, c, n, npoints, _f(points, "points"), _i(idx, "idx"), _f(out, "out"),
+              _lib.stream_ptr())
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    _lib.call("g4d_gather_grad_f32", b, c, n, npoints, _f(grad_out, "grad_out"), _i(idx, "idx"),
+              _f(grad_points, "grad_points"), _lib.stream_ptr())
+    return 1
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    _lib.call("g4d_fps_f32", b, n, m, _f(points, "points"), _f(temp, "temp"), _i(idx, "idx"), _lib.stream_ptr())
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    _lib.call("g4d_three_nn_f32", b, n, m, _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"),
+              _i(idx, "idx"), _lib.stream_ptr())
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    _lib.call("g4d_three_interp_f32", b, c, m, n, _f(points, "points"), _i(idx, "idx"), _f(weight, "weight"),
+              _f(out, "out"), _lib.stream_ptr())
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    _lib.call("g4d_three_interp_grad_f32", b, c, n, m, _f(grad_out, "grad_out"), _i(idx, "idx"),
+              _f(weight, "weight"), _f(grad_points, "grad_points"), _lib.stream_ptr())

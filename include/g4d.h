@@ -1,0 +1,85 @@
+/*
+ * g4d.h -- C ABI of libg4d_hip.so: the MI355X (gfx950) implementation of Garment4D's point-cloud
+ * encoder + skinning hot path.
+ *
+ * Boundary contract:
+ *   - plain C, raw DEVICE pointers + sizes + a HIP stream; no torch / ATen types;
+ *   - the caller allocates every output and pre-initialises what the reference's callers
+ *     pre-initialise (noted per function); kernels are enqueued on `stream`, never synchronise,
+ *     never allocate, keep no global state -> safe from several host threads on different streams;
+ *   - every entry point returns 0 on success or a non-zero hipError_t / G4D_E* code; it NEVER
+ *     calls exit() (the reference's launchers do: e.g. sampling_gpu.cu:248-252).
+ *     g4d_last_error() returns a thread-local message for the last failure.
+ *   - all tensors are contiguous; fp32 data, int32 indices (as the reference: §2a).
+ *
+ * Each legacy entry point replaces one `*_kernel_launcher*` of the reference
+ * (/root/reference/modules/pointnet2/pointnet2/src/, cited per function) -- the raw-pointer seam
+ * that the reference's pybind wrappers (src/pointnet2_api.cpp:10-24) already call.
+ */
+#ifndef G4D_H
+#define G4D_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t *g4d_stream_t; /* == hipStream_t */
+
+#define G4D_OK 0
+#define G4D_EINVAL 10001 /* bad argument (negative size, null pointer, unsupported width) */
+
+int g4d_version(void);
+const char *g4d_last_error(void);
+
+/* ---- the reference's nine kernels ------------------------------------------------------- */
+
+/* furthest_point_sampling_kernel_launcher (sampling_gpu.h:24-27, sampling_gpu.cu:93-253).
+ * xyz (B,N,3); temp (B,N) in/out scratch, caller fills 1e10 (pointnet2_utils.py:26), holds the
+ * final min-distances on return; idx (B,M) int32 out.  idx[:,0] = 0.  Tie-break identical to the
+ * reference's block-size-dependent tree reduction. */
+int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, g4d_stream_t stream);
+
+/* gather_points_kernel_launcher_fast (sampling_gpu.h:9-13): out[b,c,j] = points[b,c,idx[b,j]].
+ * points (B,C,N), idx (B,M), out (B,C,M). */
+int g4d_gather_f32(int b, int c, int n, int m, const float *points, const int *idx, float *out,
+                   g4d_stream_t stream);
+
+/* gather_points_grad_kernel_launcher_fast (sampling_gpu.h:15-21): scatter-add of grad_out (B,C,M)
+ * into grad_points (B,C,N), which the caller pre-zeroes (pointnet2_utils.py:67). */
+int g4d_gather_grad_f32(int b, int c, int n, int m, const float *grad_out, const int *idx, float *grad_points,
+                        g4d_stream_t stream);
+
+/* ball_query_kernel_launcher_fast (ball_query_gpu.h:12-13, ball_query_gpu.cu:9-67).
+ * new_xyz (B,M,3) queries, xyz (B,N,3); idx (B,M,nsample) int32, first `nsample` in-radius
+ * (d2 < radius*radius, strict) indices in ascending order, padded with the first hit; rows with
+ * no hit are written as zeros (the reference leaves the caller's pre-zeroed row untouched). */
+int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                       int *idx, g4d_stream_t stream);
+
+/* group_points_kernel_launcher_fast (group_points_gpu.h:13-15): out[b,c,p,s] = points[b,c,idx[b,p,s]].
+ * 64-bit offsets (the reference's int32 offsets wrap at 2^31 elements). */
+int g4d_group_f32(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                  g4d_stream_t stream);
+
+/* group_points_grad_kernel_launcher_fast (group_points_gpu.h:17-20): scatter-add, pre-zeroed dst. */
+int g4d_group_grad_f32(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                       float *grad_points, g4d_stream_t stream);
+
+/* three_nn_kernel_launcher_fast (interpolate_gpu.h:13-15, interpolate_gpu.cu:9-74).
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) SQUARED distances, idx (B,n,3) int32. */
+int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                     g4d_stream_t stream);
+
+/* three_interpolate_kernel_launcher_fast (interpolate_gpu.h:18-21):
+ * out[b,c,p] = sum_i weight[b,p,i] * points[b,c,idx[b,p,i]];  points (B,C,m) -> out (B,C,n). */
+int g4d_three_interp_f32(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                         float *out, g4d_stream_t stream);
+
+/* three_interpolate_grad_kernel_launcher_fast (interpolate_gpu.h:24-28): scatter-add, pre-zeroed dst. */
+int g4d_three_interp_grad_f32(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                              const float *weight, float *grad_points, g4d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G4D_H */

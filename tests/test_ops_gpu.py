@@ -1,0 +1,169 @@
+"""Parity of the HIP kernels (through the C ABI / pointnet2_cuda shim) against the CPU oracle and the golden
+vectors.  Index outputs must be bit-exact; float outputs within 1e-5 (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from garment4d_amd import pointnet2_utils as PU
+from garment4d_amd import synthetic as syn
+from oracle import pointnet2_oracle as K
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["cfg1", "ties", "small"])
+def test_golden_chain(golden_ops, case):
+    g = golden_ops
+    xyz = dev(g[f"{case}_xyz"])
+    npoint, r, ns = int(g[f"{case}_npoint"]), float(g[f"{case}_radius"]), int(g[f"{case}_nsample"])
+    idx = PU.furthest_point_sample(xyz, npoint)
+    assert np.array_equal(host(idx), g[f"{case}_fps"])
+    xt = xyz.transpose(1, 2).contiguous()
+    new_xyz = PU.gather_operation(xt, idx).transpose(1, 2).contiguous()
+    assert np.array_equal(host(new_xyz), g[f"{case}_new_xyz"])
+    bq = PU.ball_query(r, ns, xyz, new_xyz)
+    assert np.array_equal(host(bq), g[f"{case}_ball"])
+    assert np.array_equal(host(PU.grouping_operation(xt, bq)), g[f"{case}_grouped"])
+    d, i = PU.three_nn(xyz, new_xyz)
+    assert np.array_equal(host(i), g[f"{case}_nn_idx"])
+    np.testing.assert_allclose(host(d), g[f"{case}_nn_dist"], rtol=1e-6, atol=0)
+    out = PU.three_interpolate(dev(g[f"{case}_feats"]), i, dev(g[f"{case}_weight"]))
+    np.testing.assert_allclose(host(out), g[f"{case}_interp"], **TOL)
+
+
+def test_golden_edges(golden_ops):
+    g = golden_ops
+    bq = PU.ball_query(0.3, 4, dev(g["nohit_xyz"]), dev(g["nohit_q"]))
+    assert np.array_equal(host(bq), g["nohit_ball"])
+    d, i = PU.three_nn(dev(g["m2_unknown"]), dev(g["m2_known"]))
+    assert np.array_equal(host(i), g["m2_idx"])
+    assert np.isinf(host(d)[..., 2]).all()
+    np.testing.assert_allclose(host(d)[..., :2], g["m2_dist"][..., :2], rtol=1e-6)
+
+
+def test_golden_backward(golden_ops):
+    g = golden_ops
+    f = dev(g["bwd_group_feat"]).requires_grad_(True)
+    out = PU.grouping_operation(f, dev(g["small_ball"]))
+    out.backward(dev(g["bwd_group_gout"]))
+    np.testing.assert_allclose(host(f.grad), g["bwd_group_gin"], rtol=1e-4, atol=1e-4)  # atomics: order differs
+    f2 = dev(g["bwd_group_feat"]).requires_grad_(True)
+    out = PU.gather_operation(f2, dev(g["small_fps"]))
+    out.backward(dev(g["bwd_gather_gout"]))
+    np.testing.assert_allclose(host(f2.grad), g["bwd_gather_gin"], rtol=1e-4, atol=1e-4)
+    kf = dev(g["small_feats"]).requires_grad_(True)
+    out = PU.three_interpolate(kf, dev(g["small_nn_idx"]), dev(g["small_weight"]))
+    out.backward(dev(g["bwd_interp_gout"]))
+    np.testing.assert_allclose(host(kf.grad), g["bwd_interp_gin"], rtol=1e-4, atol=1e-4)
+
+
+FPS_CASES = [
+    # (B, N, M, cloud)   -- every kernel variant: single wave, 4 waves, each (U,Q), generic fallback
+    (2, 64, 16, "unit"), (2, 100, 100, "ties"), (3, 128, 32, "unit"), (2, 200, 64, "ties"), (2, 256, 64, "unit"),
+    (2, 300, 64, "ties"), (2, 512, 128, "unit"), (2, 700, 256, "ties"), (2, 1024, 256, "unit"), (2, 1722, 512, "ties"),
+    (2, 2048, 256, "unit"), (2, 3000, 300, "ties"), (2, 4096, 512, "unit"), (2, 6890, 1024, "ties"),
+    (8, 8192, 1024, "unit"), (2, 8192, 1024, "ties"), (1, 10000, 500, "ties"), (1, 16384, 256, "unit"),
+    (1, 20000, 128, "unit"), (2, 5, 5, "ties"), (2, 33, 20, "unit"), (1, 1, 1, "unit"), (1, 2, 2, "unit"),
+]
+
+
+@pytest.mark.parametrize("B,N,M,kind", FPS_CASES)
+def test_fps_vs_oracle(B, N, M, kind):
+    xyz = syn.unit_cloud(B, N, seed=N + M) if kind == "unit" else syn.body_like_cloud(B, N, seed=N + M, dup_frac=0.3, zero_frac=0.15)
+    want, want_temp = K.fps(xyz, M, return_temp=True)
+    x = dev(xyz)
+    got = PU.furthest_point_sample(x, M)
+    assert np.array_equal(host(got), want), f"first mismatch at {np.argwhere(host(got) != want)[:3]}"
+
+
+def test_fps_temp_inout_contract():
+    """temp is in/out scratch and holds the final min-distances (sampling_gpu.cu:131-133)."""
+    from garment4d_amd import pointnet2_cuda as shim
+    xyz = syn.unit_cloud(2, 1500, seed=9)
+    want, want_temp = K.fps(xyz, 200, return_temp=True)
+    x = dev(xyz)
+    temp = torch.full((2, 1500), 1e10, device="cuda")
+    idx = torch.empty((2, 200), dtype=torch.int32, device="cuda")
+    shim.furthest_point_sampling_wrapper(2, 1500, 200, x, temp, idx)
+    assert np.array_equal(host(idx), want)
+    assert np.array_equal(host(temp), want_temp)
+
+
+@pytest.mark.parametrize("forced", ["1", "4", "0"])
+def test_fps_forced_variants(forced, monkeypatch):
+    """All three kernel families give the same indices (G4D_FPS_W is read once per process, so run the
+    forced variants in a subprocess)."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, torch, sys; sys.path.insert(0, '.');"
+        "from garment4d_amd import pointnet2_utils as PU, synthetic as syn;"
+        "from oracle import pointnet2_oracle as K;"
+        "ok=True\n"
+        "for (B,N,M) in [(2,1024,256),(2,1722,300),(2,512,100),(1,8192,200)]:\n"
+        "    x=syn.body_like_cloud(B,N,seed=N);w=K.fps(x,M);g=PU.furthest_point_sample(torch.from_numpy(x).cuda(),M).cpu().numpy();ok&=bool((g==w).all())\n"
+        "print('OK' if ok else 'BAD')")
+    env = dict(os.environ, G4D_FPS_W=forced)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+BQ_CASES = [(2, 1024, 256, 0.2, 32), (2, 8192, 1024, 0.05, 16), (2, 8192, 1024, 0.1, 32), (3, 300, 77, 0.3, 64),
+            (1, 100, 10, 0.01, 8), (2, 1000, 33, 2.0, 128), (1, 65, 1, 0.5, 5), (4, 256, 64, 0.4, 64)]
+
+
+@pytest.mark.parametrize("B,N,M,r,ns", BQ_CASES)
+def test_ball_query_vs_oracle(B, N, M, r, ns):
+    xyz = syn.body_like_cloud(B, N, seed=N + ns) if N % 2 else syn.unit_cloud(B, N, seed=N + ns)
+    q = xyz[:, np.random.default_rng(M).permutation(N)[:M]].copy()
+    q[:, 0] = 7.0  # one query with no neighbour
+    want = K.ball_query(r, ns, xyz, q)
+    got = PU.ball_query(r, ns, dev(xyz), dev(q))
+    assert np.array_equal(host(got), want)
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 1024, 256), (2, 8192, 1024), (3, 300, 7), (1, 10, 3), (1, 5, 2), (2, 2500, 1500)])
+def test_three_nn_vs_oracle(B, n, m):
+    un = syn.unit_cloud(B, n, seed=n)
+    kn = syn.body_like_cloud(B, m, seed=m)  # duplicates among known points -> ties
+    wd, wi = K.three_nn(un, kn)
+    d, i = PU.three_nn(dev(un), dev(kn))
+    assert np.array_equal(host(i), wi)
+    np.testing.assert_allclose(host(d), wd, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("B,C,N,P,S", [(2, 3, 1024, 256, 32), (2, 99, 1024, 256, 16), (1, 195, 256, 64, 64), (2, 7, 100, 13, 5)])
+def test_group_gather_interp_vs_oracle(B, C, N, P, S):
+    rng = np.random.default_rng(C + N)
+    pts = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, P, S)).astype(np.int32)
+    assert np.array_equal(host(PU.grouping_operation(dev(pts), dev(idx))), K.group(pts, idx))
+    assert np.array_equal(host(PU.gather_operation(dev(pts), dev(idx[:, :, 0].copy()))), K.gather(pts, idx[:, :, 0]))
+    i3 = rng.integers(0, N, size=(B, P, 3)).astype(np.int32)
+    w = rng.random((B, P, 3)).astype(np.float32)
+    np.testing.assert_allclose(host(PU.three_interpolate(dev(pts), dev(i3), dev(w))), K.three_interpolate(pts, i3, w), **TOL)
+    # backward kernels vs oracle scatter-add
+    go = rng.standard_normal((B, C, P, S)).astype(np.float32)
+    f = dev(pts).requires_grad_(True)
+    PU.grouping_operation(f, dev(idx)).backward(dev(go))
+    np.testing.assert_allclose(host(f.grad), K.group_grad(go, idx, N), rtol=1e-4, atol=1e-4)
+    go3 = rng.standard_normal((B, C, P)).astype(np.float32)
+    f = dev(pts).requires_grad_(True)
+    PU.three_interpolate(f, dev(i3), dev(w)).backward(dev(go3))
+    np.testing.assert_allclose(host(f.grad), K.three_interpolate_grad(go3, i3, w, N), rtol=1e-4, atol=1e-4)
+
+
+def test_empty_inputs():
+    x = torch.zeros((0, 16, 3), device="cuda")
+    assert PU.furthest_point_sample(x, 4).shape == (0, 4)
+    x = dev(syn.unit_cloud(1, 16, seed=1))
+    q = torch.zeros((1, 0, 3), device="cuda")
+    assert PU.ball_query(0.1, 4, x, q).shape == (1, 0, 4)
