@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libg4d_hip.so")
 _vp = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_LL = ctypes.c_longlong
 
 # name -> argtypes (stream last); every function returns int status (0 = ok)
 SIGNATURES = {
@@ -25,6 +26,13 @@ SIGNATURES = {
     "g4d_three_nn_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_three_interp_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_three_interp_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
+    "g4d_linear_f32": [_LL, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _I, _vp],
+    "g4d_group_linear_f32": [_I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _I, _vp, _I, _I, _vp],
+    "g4d_interp_linear_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
+    "g4d_gcn_linear_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
+    "g4d_pool_rows_f32": [_I, _I, _I, _vp, _I, _vp, _I, _I, _I, _vp],
+    "g4d_transpose_f32": [_I, _I, _I, _vp, _vp, _vp],
+    "g4d_gather_rows_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -31,6 +31,14 @@ __device__ __host__ constexpr int brev_small(int v) {
     return r;
 }
 
+// fminf() makes hipcc canonicalise the loop-carried operand (an extra v_max x,x per point); the bare
+// instruction has the semantics wanted here (IEEE mode: a NaN operand yields the other operand).
+__device__ __forceinline__ float min_f32(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 struct FpsCand {  // one wave's candidate for this round
     float val;
     unsigned rank;  // (bitrev(k mod bs) << 16) | (k / bs): smaller wins among equal val
@@ -43,6 +51,25 @@ __device__ __forceinline__ unsigned fps_rank(int k, int bs, int log2bs) {
     const unsigned q = (unsigned)k >> log2bs;
     const unsigned br = log2bs ? (__builtin_bitreverse32(c) >> (32 - log2bs)) : 0u;
     return (br << 16) | q;
+}
+
+// max of W (4/8/16) 64-bit keys held by lanes 0..W-1 of each 16-lane row (Hillis-Steele with row_shr; lanes
+// without a source read 0, which never wins).  Result valid in lane W-1.
+template <int W>
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long key) {
+#define G4D_STEP(CTRL)                                                                                       \
+    {                                                                                                        \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)key, CTRL, 0xf, 0xf, true);        \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(key >> 32), CTRL, 0xf, 0xf, true); \
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                    \
+        key = o > key ? o : key;                                                                             \
+    }
+    G4D_STEP(0x111)
+    G4D_STEP(0x112)
+    if constexpr (W >= 8) G4D_STEP(0x114)
+    if constexpr (W >= 16) G4D_STEP(0x118)
+#undef G4D_STEP
+    return key;
 }
 
 // Wave arg-max under (value desc, rank asc).  `best` per lane, `k` per lane.  Returns uniform results.
@@ -69,7 +96,6 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
                                                         float *__restrict__ temp_all, int *__restrict__ idx_all) {
     constexpr int T = 64 * W, P = U * Q;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    FpsCand *slots = reinterpret_cast<FpsCand *>(smem_raw);          // [2][W]
     float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * 16);   // SoA copy of the cloud
     float *sy = sx + n;
     float *sz = sy + n;
@@ -102,7 +128,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
         for (int i = 0; i < P; ++i) {
             const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
             const float d = dx * dx + dy * dy + dz * dz;
-            const float d2 = fminf(d, md[i]);
+            const float d2 = min_f32(d, md[i]);
             md[i] = d2;
             const bool gt = d2 > best;
             bslot = gt ? i : bslot;
@@ -117,19 +143,16 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
         if constexpr (W == 1) {
             old = wk;
         } else {
-            FpsCand *buf = slots + (j & 1) * W;
-            if ((t & 63) == 0) { FpsCand c; c.val = wval; c.rank = wrank; c.k = wk; c.pad = 0; buf[wave] = c; }
+            // candidate = 64-bit key (value bits : ~rank); every wave publishes one, after the barrier lane l
+            // picks up candidate l mod W and the W keys are folded by a DPP row scan (no serial compare chain)
+            unsigned long long *buf = reinterpret_cast<unsigned long long *>(smem_raw) + (j & 1) * 16;
+            if ((t & 63) == 0)
+                buf[wave] = ((unsigned long long)__float_as_uint(fmaxf(wval, 0.f)) << 32) | (unsigned)(~wrank);
             __syncthreads();
-            FpsCand bc = buf[0];
-#pragma unroll
-            for (int w = 1; w < W; ++w) {
-                const FpsCand c = buf[w];
-                const bool take = (c.val > bc.val) || (c.val == bc.val && c.rank < bc.rank);
-                bc.val = take ? c.val : bc.val;
-                bc.rank = take ? c.rank : bc.rank;
-                bc.k = take ? c.k : bc.k;
-            }
-            old = __builtin_amdgcn_readfirstlane(bc.k);
+            const unsigned long long key = row_max_u64<W>(buf[t & (W - 1)]);
+            const unsigned rank = ~(unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, W - 1);
+            const unsigned c = log2bs ? (__builtin_bitreverse32(rank >> 16) >> (32 - log2bs)) : 0u;
+            old = (int)(((rank & 0xffffu) << log2bs) | c);
         }
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
         if (t == 0) idx[j] = old;
@@ -222,7 +245,7 @@ static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz,
     return check_launch("g4d_fps_f32");
 }
 
-static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|0(generic)
+static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|8|16|0(generic)
 
 }  // namespace g4d
 
@@ -247,7 +270,7 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
     if (lds_ok && force != 0 && bs >= 64) {
         const int qp = q <= 1 ? 1 : q <= 2 ? 2 : q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : 0;
         // single wave: no barrier at all; preferred for small clouds
-        const bool want_w1 = (force == 1) || (force != 4 && n <= 512);
+        const bool want_w1 = (force == 1) || (force > 16 && n <= 512);
         if (want_w1 && qp && (bs / 64) * qp <= 32) {
             const int u = bs / 64;
             if (u == 1 && qp == 1) G4D_FPS_CASE(1, 1, 1);
@@ -261,6 +284,22 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
             if (u == 16 && qp == 1) G4D_FPS_CASE(1, 16, 1);
             if (u == 16 && qp == 2) G4D_FPS_CASE(1, 16, 2);
         }
+        const int wsel = (force == 4 || force == 8 || force == 16) ? force : (n > 2048 ? 16 : 4);
+        if (wsel == 16 && bs == 1024 && qp && qp <= 8) {
+            if (qp == 1) G4D_FPS_CASE(16, 1, 1);
+            if (qp == 2) G4D_FPS_CASE(16, 1, 2);
+            if (qp == 4) G4D_FPS_CASE(16, 1, 4);
+            if (qp == 8) G4D_FPS_CASE(16, 1, 8);
+        }
+        if (wsel >= 8 && bs >= 512 && qp && qp <= 8) {
+            const int u = bs / 512;
+            if (u == 1 && qp == 1) G4D_FPS_CASE(8, 1, 1);
+            if (u == 1 && qp == 2) G4D_FPS_CASE(8, 1, 2);
+            if (u == 2 && qp == 1) G4D_FPS_CASE(8, 2, 1);
+            if (u == 2 && qp == 2) G4D_FPS_CASE(8, 2, 2);
+            if (u == 2 && qp == 4) G4D_FPS_CASE(8, 2, 4);
+            if (u == 2 && qp == 8) G4D_FPS_CASE(8, 2, 8);
+        }
         if (bs >= 256 && qp) {
             const int u = bs / 256;
             if (u == 1 && qp == 1) G4D_FPS_CASE(4, 1, 1);
@@ -271,7 +310,7 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
             if (u == 4 && qp == 2) G4D_FPS_CASE(4, 4, 2);
             if (u == 4 && qp == 4) G4D_FPS_CASE(4, 4, 4);
             if (u == 4 && qp == 8) G4D_FPS_CASE(4, 4, 8);
-            if (u == 4 && qp == 16 && (size_t)n * 12 + 512 <= 150 * 1024) G4D_FPS_CASE(4, 4, 16);
+            if (u == 4 && qp == 16) G4D_FPS_CASE(4, 4, 16);
         }
         if (bs >= 64 && bs < 256 && qp && (bs / 64) * qp <= 32) {  // 64 <= n < 256: single wave
             const int u = bs / 64;

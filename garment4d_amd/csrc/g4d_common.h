@@ -43,14 +43,30 @@ __device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
 }
 
 // max over the 64 lanes, returned wave-uniform (SGPR).  No NaNs expected in v.
+// Hand-written DPP chain: hipcc does not fold the DPP move into v_max_f32 (it emits mov_dpp + a
+// canonicalising max + max + copy + s_nop per step); here each step is ONE v_max_f32_dpp.  Lanes whose DPP
+// source is outside the row are write-disabled (bound_ctrl off) and keep their value.  `s_nop 1` = the two
+// wait states a DPP read needs after a VALU write of the same VGPR.
 __device__ __forceinline__ float wave_max_f32(float v) {
-    v = fmaxf(v, dpp_mov_f<0x111, 0xf>(v));
-    v = fmaxf(v, dpp_mov_f<0x112, 0xf>(v));
-    v = fmaxf(v, dpp_mov_f<0x114, 0xf>(v));
-    v = fmaxf(v, dpp_mov_f<0x118, 0xf>(v));  // lane 15 of each row = row max
-    v = fmaxf(v, dpp_mov_f<0x142, 0xa>(v));  // row_bcast:15 into rows 1,3
-    v = fmaxf(v, dpp_mov_f<0x143, 0xc>(v));  // row_bcast:31 into rows 2,3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    int out;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %1, %0, 63\n\t"
+        "s_nop 3"
+        : "+v"(v), "=s"(out));
+    return __int_as_float(out);
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {

@@ -143,6 +143,16 @@ __global__ void __launch_bounds__(256) three_interp_grad_kernel(int c, int n, in
         }
 }
 
+// point-major row gather: out[b,j,:] = in[b,idx[b,j],:]  (rows of `c` floats; used for new_xyz = xyz[fps idx])
+__global__ void __launch_bounds__(256) gather_rows_kernel(int n, int m, int c, const float *__restrict__ in,
+                                                         const int *__restrict__ idx, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // over m*c
+    if (e >= (long long)m * c) return;
+    const int b = blockIdx.y;
+    const int j = (int)(e / c), ch = (int)(e - (long long)j * c);
+    out[((size_t)b * m + j) * c + ch] = in[((size_t)b * n + idx[(size_t)b * m + j]) * c + ch];
+}
+
 static inline int launch_group(int b, int c, int n, long long e_total, const float *points, const int *idx, float *out,
                                hipStream_t s, const char *what) {
     if (b == 0 || c == 0 || e_total == 0) return G4D_OK;
@@ -238,4 +248,15 @@ extern "C" int g4d_three_interp_grad_f32(int b, int c, int n, int m, const float
     hipLaunchKernelGGL(three_interp_grad_kernel, grid, dim3(256), 0, G4D_STREAM(stream), c, n, m, grad_out, idx, weight,
                        grad_points);
     return check_launch("g4d_three_interp_grad_f32");
+}
+
+extern "C" int g4d_gather_rows_f32(int b, int n, int m, int c, const float *in, const int *idx, float *out,
+                                   g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_gather_rows_f32", b, n, m, c);
+    G4D_REQUIRE(b <= 65535, "g4d_gather_rows_f32: b > 65535 not supported");
+    if ((long long)b * m * c == 0) return G4D_OK;
+    G4D_REQUIRE(in && idx && out, "g4d_gather_rows_f32: null pointer");
+    dim3 grid((unsigned)(((long long)m * c + 255) / 256), b);
+    hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, G4D_STREAM(stream), n, m, c, in, idx, out);
+    return check_launch("g4d_gather_rows_f32");
 }

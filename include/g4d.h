@@ -79,6 +79,49 @@ int g4d_three_interp_f32(int b, int c, int m, int n, const float *points, const 
 int g4d_three_interp_grad_f32(int b, int c, int n, int m, const float *grad_out, const int *idx,
                               const float *weight, float *grad_points, g4d_stream_t stream);
 
+/* ---- fused shared-MLP layers on the matrix cores (garment4d_amd/csrc/mlp.hip) --------------------------
+ * One call = one layer  Y = act((A . W^T) * scale + shift).  W is (CoutPad64, Kpad) row-major fp32, zero
+ * padded (Kpad % 32 == 0, CoutPad64 % 64 == 0); scale/shift (CoutPad64) carry the folded BatchNorm affine /
+ * conv bias.  Activations are POINT-MAJOR (rows, channels).  Outputs land at column `col0` of rows of width
+ * `ldo` (multi-scale concat for free).  These replace the un-fused chain QueryAndGroup -> SharedMLP ->
+ * max_pool2d (pointnet2_utils.py:242-265, pytorch_utils.py:5-32, pointnet2_modules.py:37-53), three_interpolate
+ * -> cat -> SharedMLP (pointnet2_modules.py:139-156) and GraphConvolution.forward (modules/pygcn/layers.py:35-55). */
+
+/* A = X (rows, ldx) point-major; pool (0 none | 1 max | 2 avg) over s_pool in {16,32,64} consecutive rows. */
+int g4d_linear_f32(long long rows, int K, int Kpad, int Cout, const float *X, int ldx, const float *W,
+                   const float *scale, const float *shift, int relu, int pool, int s_pool, float *out, int ldo,
+                   int col0, g4d_stream_t stream);
+
+/* A row (b,p,s) = [xyz[b,idx[b,p,s]] - new_xyz[b,p] (if use_xyz) | feats[b,idx[b,p,s],:]] ; feats (B,N,C)
+ * point-major; pool: 0 none (out rows = B*P*S), 1 max, 2 avg over the S samples (out rows = B*P; S in {16,32,64}). */
+int g4d_group_linear_f32(int b, int n, int p, int s, int c, int use_xyz, const float *xyz, const float *new_xyz,
+                         const float *feats, const int *idx, int Kpad, int Cout, const float *W, const float *scale,
+                         const float *shift, int relu, int pool, float *out, int ldo, int col0, g4d_stream_t stream);
+
+/* A row (b,p) = [sum_i w_i known_feats[b,nn_idx[b,p,i],:] (C2) | skip[b,p,:] (C1)], w_i = normalised
+ * 1/(sqrt(dist2_i)+1e-8); known_feats (B,m,C2), skip (B,n,C1) point-major; dist2/nn_idx from g4d_three_nn_f32. */
+int g4d_interp_linear_f32(int b, int n, int m, int c2, int c1, const float *known_feats, const float *skip,
+                          const float *dist2, const int *nn_idx, int Kpad, int Cout, const float *W,
+                          const float *scale, const float *shift, int relu, float *out, int ldo, int col0,
+                          g4d_stream_t stream);
+
+/* GCN layer: A row (f,v) = sum_u Ahat[v,u] X[f,u,:] with Ahat in CSR (rowptr (Vg+1), colidx, vals);
+ * out = A . W^T * scale + shift  ==  Ahat (X W) + b  with W^T = reference weight (Fin,Fout), shift = bias. */
+int g4d_gcn_linear_f32(int frames, int vg, int fin, const float *X, int ldx, const int *rowptr, const int *colidx,
+                       const float *vals, int Kpad, int Cout, const float *W, const float *scale, const float *shift,
+                       int relu, float *out, int ldo, int col0, g4d_stream_t stream);
+
+/* max (is_max=1) / mean over S consecutive rows, any S: in (groups*S, ldi) -> out (groups, ldo) at col0. */
+int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0, int is_max,
+                      g4d_stream_t stream);
+
+/* point-major row gather: out[b,j,:] = in[b,idx[b,j],:], rows of c floats (new_xyz = xyz[fps idx] with c=3;
+ * same result as gather_points on the transposed tensor, pointnet2_modules.py:32-35, without the two transposes). */
+int g4d_gather_rows_f32(int b, int n, int m, int c, const float *in, const int *idx, float *out, g4d_stream_t stream);
+
+/* batched matrix transpose (b, r, c) -> (b, c, r): channel-major <-> point-major at the API boundary. */
+int g4d_transpose_f32(int b, int r, int c, const float *in, float *out, g4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

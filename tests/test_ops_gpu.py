@@ -98,7 +98,7 @@ def test_fps_temp_inout_contract():
     assert np.array_equal(host(temp), want_temp)
 
 
-@pytest.mark.parametrize("forced", ["1", "4", "0"])
+@pytest.mark.parametrize("forced", ["1", "4", "8", "16", "0"])
 def test_fps_forced_variants(forced, monkeypatch):
     """All three kernel families give the same indices (G4D_FPS_W is read once per process, so run the
     forced variants in a subprocess)."""
