@@ -1,0 +1,110 @@
+"""PointNet++ MSG segmentation encoder with the layer specification, attribute names and state-dict keys of
+the reference's `Pointnet2MSGSEG` (/root/reference/modules/pointnet2encoder.py:18-145): 3 SA-MSG levels
+(1024/256/64 centroids), optional global SA, 3 FP levels and a Conv1d head.  This is the network BASELINE
+config 2 quotes the metric on (`input_channels=0, global_feat=False`, as instantiated at
+modules/mesh_encoder.py:49).
+
+forward()        -- op-by-op path (HIP ops + torch SharedMLP): trainable, returns exactly what the reference's
+                    forward returns (middle_features, sem_logits, l_features, l_xyz), channel-major features.
+forward_fused()  -- eval-mode inference on the fused HIP kernels; activations stay point-major in HBM.
+
+Unlike the reference module, importing this file has no side effects (the reference parses sys.argv and
+loads cfgs/*.yaml at import time through utils/config.py:129).
+"""
+import torch
+import torch.nn as nn
+
+from . import fused
+from . import pytorch_utils as pt_utils
+from .pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+
+CLASS_NUM = 7  # utils/dataloader.py:24
+
+
+class Pointnet2MSGSEG(nn.Module):
+    def __init__(self, input_channels=3, use_xyz=True, bn=True, global_feat=True, num_classes=CLASS_NUM):
+        super().__init__()
+        self.global_feat = global_feat
+        c0 = input_channels
+        self.SA_modules = nn.ModuleList()
+        self.SA_modules.append(PointnetSAModuleMSG(npoint=1024, radii=[0.05, 0.1], nsamples=[16, 32],
+                                                   mlps=[[c0, 16, 16, 32], [c0, 32, 32, 64]], use_xyz=use_xyz, bn=bn))
+        c1 = 32 + 64
+        self.SA_modules.append(PointnetSAModuleMSG(npoint=256, radii=[0.1, 0.2], nsamples=[16, 32],
+                                                   mlps=[[c1, 32, 32, 64], [c1, 64, 64, 128]], use_xyz=use_xyz, bn=bn))
+        c2 = 64 + 128
+        self.SA_modules.append(PointnetSAModuleMSG(npoint=64, radii=[0.2, 0.4], nsamples=[32, 64],
+                                                   mlps=[[c2, 64, 64, 128], [c2, 128, 128, 256]], use_xyz=use_xyz, bn=bn))
+        c3 = 128 + 256
+        if global_feat:
+            self.Middle_modules = PointnetSAModule(mlp=[c3, 256, 512], use_xyz=use_xyz, bn=bn)
+        self.num_feat = 512
+        self.pointwise_num_feat = 64 + 128 + 256 + 128 + 256
+        self.feat_channels_list = [64, 128, 256, 128 + 256]
+        self.FP_modules = nn.ModuleList()
+        self.FP_modules.append(PointnetFPModule(mlp=[128 + c0, 128, 64], bn=bn))
+        self.FP_modules.append(PointnetFPModule(mlp=[256 + c1, 256, 128], bn=bn))
+        self.FP_modules.append(PointnetFPModule(mlp=[c3 + c2, 512, 256], bn=bn))
+        self.FC_layer = nn.Sequential(pt_utils.Conv1d(64, 32, bn=True), nn.Dropout(),
+                                      pt_utils.Conv1d(32, num_classes, activation=None))
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud: torch.Tensor):
+        """pointcloud (B, N, 3 + input_channels) -> (middle_features, sem_logits (B,N,classes), l_features, l_xyz)."""
+        xyz, features = self._break_up_pc(pointcloud)
+        l_xyz, l_features = [xyz], [features]
+        for sa in self.SA_modules:
+            nx, nf = sa(l_xyz[-1], l_features[-1])
+            l_xyz.append(nx)
+            l_features.append(nf)
+        middle = self.Middle_modules(l_xyz[-1], l_features[-1])[1] if self.global_feat else None
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+        sem_logits = self.FC_layer(l_features[0]).transpose(1, 2).contiguous()
+        return middle, sem_logits, l_features, l_xyz
+
+    def forward_fused(self, pointcloud: torch.Tensor, channel_major: bool = False):
+        """Eval-mode forward on the fused kernels.  Features are point-major (B, N_l, C_l) unless
+        `channel_major` (then converted to the reference's (B, C_l, N_l) at the boundary)."""
+        assert not self.training
+        xyz = pointcloud[..., 0:3].contiguous()
+        feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None  # already point-major
+        l_xyz, l_feats = [xyz], [feats]
+        for sa in self.SA_modules:
+            nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1])
+            l_xyz.append(nx)
+            l_feats.append(nf)
+        middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_feats[i - 1] = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
+        sem_logits = fused.conv_stack_forward(self.FC_layer, l_feats[0])  # (B, N, classes)
+        if channel_major:
+            l_feats = [None if f is None else fused.to_channel_major(f) for f in l_feats]
+            middle = None if middle is None else fused.to_channel_major(middle)
+        return middle, sem_logits, l_feats, l_xyz
+
+
+def seed_encoder(model: nn.Module, seed: int = 0):
+    """Deterministic synthetic weights: kaiming-normal convs, BN affine ~U[0.5,1.5]/N(0,0.1),
+    running stats ~N(0,0.1)/U[0.5,1.5].  There are no checkpoints in this environment."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+            elif name.endswith("bn.weight"):
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    return model

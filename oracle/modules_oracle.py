@@ -17,7 +17,7 @@ F32 = np.float32
 BN_EPS = 1e-5  # torch.nn.BatchNorm default
 
 
-def shared_mlp(x, sd, prefix="", training=False):
+def shared_mlp(x, sd, prefix="", training=False, relu=None):
     """x (B,C,P,S) -> (B,Cout,P,S).  sd: state-dict slice; layers `<prefix>layer{i}.conv.weight`
     (Cout,Cin,1,1), optional `.conv.bias`, optional `.bn.bn.{weight,bias,running_mean,running_var}`."""
     i = 0
@@ -41,7 +41,7 @@ def shared_mlp(x, sd, prefix="", training=False):
             bt = sd[f"{prefix}layer{i}.bn.bn.bias"].astype(np.float64)
             y = ((y - mean[None, :, None, None]) / np.sqrt(var + BN_EPS)[None, :, None, None]
                  * g[None, :, None, None] + bt[None, :, None, None]).astype(F32)
-        x = np.maximum(y, F32(0))
+        x = np.maximum(y, F32(0)) if (relu is None or relu[i]) else y
         i += 1
     return x
 
@@ -100,3 +100,33 @@ def fp_module(unknown, known, unknow_feats, known_feats, sd, training=False):
         interp = np.broadcast_to(known_feats, known_feats.shape[:2] + (unknown.shape[1],))
     x = np.concatenate([interp, unknow_feats], axis=1) if unknow_feats is not None else interp
     return shared_mlp(x[..., None].astype(F32), sd, prefix="mlp.", training=training)[..., 0]
+
+
+# /root/reference/modules/pointnet2encoder.py:41-96 -- (npoint, radii, nsamples) of the three SA-MSG levels
+ENCODER_SA_SPEC = [(1024, [0.05, 0.1], [16, 32]), (256, [0.1, 0.2], [16, 32]), (64, [0.2, 0.4], [32, 64])]
+
+
+def encoder_forward(xyz, sd, sa_spec=ENCODER_SA_SPEC):
+    """Pointnet2MSGSEG.forward (pointnet2encoder.py:112-145) with input_channels=0, global_feat=False, eval
+    mode.  sd = state dict (numpy) with the reference's keys.  Returns (sem_logits (B,N,classes), l_features, l_xyz)."""
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+    l_xyz, l_f = [xyz.astype(F32)], [None]
+    for i, (npoint, radii, ns) in enumerate(sa_spec):
+        nx, nf = sa_module(l_xyz[-1], l_f[-1], npoint, radii, ns, sub(f"SA_modules.{i}."))
+        l_xyz.append(nx)
+        l_f.append(nf)
+    nfp = len(sa_spec)
+    for i in range(-1, -(nfp + 1), -1):
+        l_f[i - 1] = fp_module(l_xyz[i - 1], l_xyz[i], l_f[i - 1], l_f[i], sub(f"FP_modules.{nfp + i}."))
+    # FC_layer = Sequential(Conv1d(64,32,bn) , Dropout, Conv1d(32,classes, activation=None)) (:98-101)
+    fc = sub("FC_layer.")
+    head = {}
+    for k, v in fc.items():
+        if k.startswith("0."):
+            head["layer0." + k[2:]] = v
+        elif k.startswith("2."):
+            head["layer1." + k[2:]] = v
+    logits = shared_mlp(l_f[0][..., None], head, relu=[True, False])[..., 0]
+    return np.ascontiguousarray(logits.transpose(0, 2, 1)), l_f, l_xyz
