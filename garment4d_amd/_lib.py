@@ -33,6 +33,11 @@ SIGNATURES = {
     "g4d_pool_rows_f32": [_I, _I, _I, _vp, _I, _vp, _I, _I, _I, _vp],
     "g4d_transpose_f32": [_I, _I, _I, _vp, _vp, _vp],
     "g4d_gather_rows_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_lbs_shape_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp],
+    "g4d_joint_regress_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp],
+    "g4d_rodrigues_f32": [_I, _vp, _vp, _vp],
+    "g4d_rigid_transform_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_lbs_pose_skin_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp],
 }
 
 _lib = None

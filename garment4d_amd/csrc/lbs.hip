@@ -1,0 +1,313 @@
+// SMPL linear blend skinning for gfx950 -- the reference runs this as ~40 small torch ops per call, on the CPU,
+// batch 1, three times per frame inside its DataLoader workers (/root/reference/smplx/smplx/lbs.py:152-248,
+// called from utils/dataloader.py:199-212).  Here it is four kernels over the whole batch of frames:
+//
+//   lbs_shape_kernel   v_shaped = v_template + shapedirs . betas                       (lbs.py:205, 288-309)
+//   joint_regress      J = J_regressor . v_shaped  (shared or per-sample regressor)    (lbs.py:209, 251-286)
+//   lbs_rigid_kernel   Rodrigues, kinematic chain, rel. transforms A, pose feature     (lbs.py:312-419, 215-222)
+//   lbs_pose_skin      v_posed = v_shaped + pose_feature . posedirs;  T = W . A;  verts = T [v_posed;1]
+//                                                                                     (lbs.py:223-246)
+//
+// All HBM-bound: the model constants (posedirs 17 MB, shapedirs 0.8 MB, J_regressor 0.66 MB, weights 0.66 MB)
+// are read once per batch of up to 8 frames; per-frame algorithmic traffic is 24 B/vertex + 64 B/joint.
+// In lbs_pose_skin a thread owns one vertex: posedirs rows stream coalesced (12 B/lane), the pose features and
+// the 24 joint transforms of the frames sit in LDS (broadcast reads), the 24 skinning weights of the vertex in
+// registers.
+#include "g4d_common.h"
+
+namespace g4d {
+
+constexpr int kFB = 8;  // frames per thread in shape / pose-skin kernels
+
+__global__ void __launch_bounds__(256) lbs_shape_kernel(int B, int V3, int NB, int betas_bstride, const float *__restrict__ betas,
+                                                       const float *__restrict__ v_template,
+                                                       const float *__restrict__ shapedirs, float *__restrict__ v_shaped) {
+    extern __shared__ float sb[];  // [B][NB]
+    for (int i = threadIdx.x; i < B * NB; i += 256) sb[i] = betas[(size_t)(i / NB) * betas_bstride + (i % NB)];
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= V3) return;
+    const float vt = v_template[e];
+    const float *sd = shapedirs + (size_t)e * NB;
+    for (int b = 0; b < B; ++b) {
+        float acc = 0.f;
+        for (int l = 0; l < NB; ++l) acc = fmaf(sb[b * NB + l], sd[l], acc);
+        v_shaped[(size_t)b * V3 + e] = vt + acc;  // lbs.py:205  v_template + blend_shapes
+    }
+}
+
+// joints[b,j,:] = sum_v jreg[(b),j,v] * verts[b,v,:]
+__global__ void __launch_bounds__(256) joint_regress_kernel(int J, int V, long long jreg_bstride, const float *__restrict__ jreg,
+                                                           const float *__restrict__ verts, float *__restrict__ joints) {
+    __shared__ float red[4][3];
+    const int j = blockIdx.x, b = blockIdx.y;
+    const float *w = jreg + (size_t)b * jreg_bstride + (size_t)j * V;
+    const float *vb = verts + (size_t)b * V * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float wv = w[v];
+        sx = fmaf(wv, vb[v * 3 + 0], sx);
+        sy = fmaf(wv, vb[v * 3 + 1], sy);
+        sz = fmaf(wv, vb[v * 3 + 2], sz);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o);
+        sy += __shfl_xor(sy, o);
+        sz += __shfl_xor(sz, o);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        joints[((size_t)b * J + j) * 3 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
+// lbs.py:312-346  batch_rodrigues: angle = ||r + 1e-8||, dir = r / angle, R = I + sin K + (1 - cos) K K
+__device__ __forceinline__ void rodrigues(float rx, float ry, float rz, float *R) {
+    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    const float angle = __fsqrt_rn(ax * ax + ay * ay + az * az);
+    const float x = rx / angle, y = ry / angle, z = rz / angle;
+    const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+    // K = [[0,-z,y],[z,0,-x],[-y,x,0]];  K K = [[-(y2+z2), xy, xz],[xy, -(x2+z2), yz],[xz, yz, -(x2+y2)]]
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+    R[0] = 1.0f + c1 * (-(zz + yy));  // row-major 3x3; K K[0][0] = -z*z - y*y (bmm order: (-z)(z) + (y)(-y))
+    R[1] = s * (-z) + c1 * xy;
+    R[2] = s * y + c1 * xz;
+    R[3] = s * z + c1 * xy;
+    R[4] = 1.0f + c1 * (-(zz + xx));
+    R[5] = s * (-x) + c1 * yz;
+    R[6] = s * (-y) + c1 * xz;
+    R[7] = s * x + c1 * yz;
+    R[8] = 1.0f + c1 * (-(yy + xx));
+}
+
+__global__ void __launch_bounds__(256) rodrigues_kernel(int n, const float *__restrict__ rv, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float R[9];
+    rodrigues(rv[i * 3 + 0], rv[i * 3 + 1], rv[i * 3 + 2], R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[(size_t)i * 9 + k] = R[k];
+}
+
+// One wave per frame.  lanes j < J: per-joint work; the chain runs 23 dependent steps with lanes 0..11 each
+// owning one entry of the 3x4 transform.  lbs.py:362-419.
+__global__ void __launch_bounds__(64) lbs_rigid_kernel(int J, int pose2rot, const float *__restrict__ pose /* (B,J,3) or (B,J,9) */,
+                                                      const float *__restrict__ joints /* (B,J,3) */,
+                                                      const int *__restrict__ parents, float *__restrict__ rot_out /* (B,J,9)|null */,
+                                                      float *__restrict__ posed_joints /* (B,J,3)|null */,
+                                                      float *__restrict__ rel_transforms /* (B,J,16) */,
+                                                      float *__restrict__ pose_feature /* (B,(J-1)*9)|null */) {
+    __shared__ float sR[64][9], sJ[64][3], sL[64][12], sG[64][12];
+    __shared__ int sP[64];
+    const int b = blockIdx.x, l = threadIdx.x;
+    if (l < J) {
+        float R[9];
+        if (pose2rot) {
+            const float *p = pose + ((size_t)b * J + l) * 3;
+            rodrigues(p[0], p[1], p[2], R);
+        } else {
+            const float *p = pose + ((size_t)b * J + l) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sR[l][k] = R[k];
+        const float *jp = joints + ((size_t)b * J + l) * 3;
+        sJ[l][0] = jp[0]; sJ[l][1] = jp[1]; sJ[l][2] = jp[2];
+        sP[l] = parents[l];
+        if (rot_out) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rot_out[((size_t)b * J + l) * 9 + k] = R[k];
+        }
+        if (pose_feature && l > 0) {  // lbs.py:217 / :222  (R[1:] - I).view(B, -1)
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                pose_feature[(size_t)b * (J - 1) * 9 + (l - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
+        }
+    }
+    __syncthreads();
+    if (l < J) {  // local transform [R | J - J_parent]  (lbs.py:390-396)
+        const int p = sP[l];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            sL[l][r * 4 + 0] = sR[l][r * 3 + 0];
+            sL[l][r * 4 + 1] = sR[l][r * 3 + 1];
+            sL[l][r * 4 + 2] = sR[l][r * 3 + 2];
+            sL[l][r * 4 + 3] = (l > 0) ? (sJ[l][r] - sJ[p][r]) : sJ[l][r];
+        }
+    }
+    __syncthreads();
+    if (l < 12) sG[0][l] = sL[0][l];
+    __syncthreads();
+    for (int i = 1; i < J; ++i) {  // G_i = G_parent(i) . L_i   (lbs.py:399-405), 4x4 product with implicit [0 0 0 1]
+        if (l < 12) {
+            const int p = sP[i], r = l >> 2, c = l & 3;
+            float acc = sG[p][r * 4 + 0] * sL[i][0 * 4 + c];
+            acc = fmaf(sG[p][r * 4 + 1], sL[i][1 * 4 + c], acc);
+            acc = fmaf(sG[p][r * 4 + 2], sL[i][2 * 4 + c], acc);
+            if (c == 3) acc += sG[p][r * 4 + 3];
+            sG[i][l] = acc;
+        }
+        __syncthreads();
+    }
+    if (l < J) {
+        float *A = rel_transforms + ((size_t)b * J + l) * 16;
+        const float jx = sJ[l][0], jy = sJ[l][1], jz = sJ[l][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float g0 = sG[l][r * 4 + 0], g1 = sG[l][r * 4 + 1], g2 = sG[l][r * 4 + 2], g3 = sG[l][r * 4 + 3];
+            A[r * 4 + 0] = g0; A[r * 4 + 1] = g1; A[r * 4 + 2] = g2;
+            A[r * 4 + 3] = g3 - fmaf(g2, jz, fmaf(g1, jy, g0 * jx));  // lbs.py:414-417
+            if (posed_joints) posed_joints[((size_t)b * J + l) * 3 + r] = g3;  // lbs.py:410
+        }
+        A[12] = 0.f; A[13] = 0.f; A[14] = 0.f; A[15] = 1.f;
+    }
+}
+
+// verts[b,v,:] = (sum_j W[(b),v,j] A[b,j]) . [v_in[b,v,:] (+ pose_feature[b] . posedirs[:, v]) ; 1]
+template <bool POSE>
+__global__ void __launch_bounds__(256) lbs_pose_skin_kernel(int B, int V, int J, int PF, const float *__restrict__ v_in,
+                                                           const float *__restrict__ pose_feature, const float *__restrict__ posedirs,
+                                                           const float *__restrict__ weights, long long w_bstride,
+                                                           const float *__restrict__ A, float *__restrict__ verts) {
+    extern __shared__ float smem[];
+    float *sA = smem;                 // [kFB][J][12]
+    float *sPF = smem + kFB * J * 12;  // [kFB][PF]
+    const int b0 = blockIdx.y * kFB;
+    const int nf = min(kFB, B - b0);
+    for (int i = threadIdx.x; i < nf * J * 12; i += 256) {
+        const int f = i / (J * 12), r = i % (J * 12);
+        sA[i] = A[((size_t)(b0 + f) * J + r / 12) * 16 + (r % 12)];
+    }
+    if (POSE)
+        for (int i = threadIdx.x; i < nf * PF; i += 256) sPF[i] = pose_feature[(size_t)b0 * PF + i];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    float px[kFB], py[kFB], pz[kFB];
+#pragma unroll
+    for (int f = 0; f < kFB; ++f) {
+        if (f < nf) {
+            const float *p = v_in + ((size_t)(b0 + f) * V + v) * 3;
+            px[f] = p[0]; py[f] = p[1]; pz[f] = p[2];
+        } else {
+            px[f] = py[f] = pz[f] = 0.f;
+        }
+    }
+    if (POSE) {
+        float ox[kFB], oy[kFB], oz[kFB];
+#pragma unroll
+        for (int f = 0; f < kFB; ++f) ox[f] = oy[f] = oz[f] = 0.f;
+        const float *pd = posedirs + (size_t)v * 3;
+        const size_t stride = (size_t)V * 3;
+        for (int k = 0; k < PF; ++k) {
+            const float d0 = pd[k * stride + 0], d1 = pd[k * stride + 1], d2 = pd[k * stride + 2];
+#pragma unroll
+            for (int f = 0; f < kFB; ++f) {
+                const float pf = sPF[f * PF + k];  // LDS broadcast; frames >= nf read stale-but-finite data, discarded
+                ox[f] = fmaf(pf, d0, ox[f]);
+                oy[f] = fmaf(pf, d1, oy[f]);
+                oz[f] = fmaf(pf, d2, oz[f]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < kFB; ++f) { px[f] = ox[f] + px[f]; py[f] = oy[f] + py[f]; pz[f] = oz[f] + pz[f]; }  // lbs.py:229
+    }
+    for (int f = 0; f < nf; ++f) {
+        const float *w = weights + (size_t)(b0 + f) * w_bstride + (size_t)v * J;
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < J; ++j) {
+            const float wj = w[j];
+            const float *a = sA + (f * J + j) * 12;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(wj, a[e], T[e]);  // lbs.py:238  T = W . A
+        }
+        // select this frame's point without dynamic register indexing
+        float x = 0.f, y = 0.f, z = 0.f;
+#pragma unroll
+        for (int g = 0; g < kFB; ++g)
+            if (g == f) { x = px[g]; y = py[g]; z = pz[g]; }
+        float *o = verts + ((size_t)(b0 + f) * V + v) * 3;
+        o[0] = fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3];  // lbs.py:244  T . [v;1]
+        o[1] = fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7];
+        o[2] = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
+    }
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+#define G4D_S(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int g4d_lbs_shape_f32(int b, int v, int nb, const float *betas, int betas_bstride, const float *v_template,
+                                 const float *shapedirs, float *v_shaped, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && v >= 0 && nb >= 0, "g4d_lbs_shape_f32: negative size");
+    if ((long long)b * v == 0) return G4D_OK;
+    G4D_REQUIRE(betas && v_template && shapedirs && v_shaped, "g4d_lbs_shape_f32: null pointer");
+    // frames in slabs so the betas fit LDS comfortably
+    const int slab = 512;
+    for (int b0 = 0; b0 < b; b0 += slab) {
+        const int nbf = (b - b0) < slab ? (b - b0) : slab;
+        hipLaunchKernelGGL(lbs_shape_kernel, dim3((v * 3 + 255) / 256), dim3(256), sizeof(float) * nbf * (nb > 0 ? nb : 1), G4D_S(stream),
+                           nbf, v * 3, nb, betas_bstride, betas + (size_t)b0 * betas_bstride, v_template, shapedirs,
+                           v_shaped + (size_t)b0 * v * 3);
+    }
+    return check_launch("g4d_lbs_shape_f32");
+}
+
+extern "C" int g4d_joint_regress_f32(int b, int j, int v, const float *jreg, int jreg_batched, const float *verts,
+                                     float *joints, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && j >= 0 && v >= 0 && b <= 65535, "g4d_joint_regress_f32: bad size");
+    if ((long long)b * j == 0) return G4D_OK;
+    G4D_REQUIRE(jreg && verts && joints, "g4d_joint_regress_f32: null pointer");
+    hipLaunchKernelGGL(joint_regress_kernel, dim3(j, b), dim3(256), 0, G4D_S(stream), j, v,
+                       jreg_batched ? (long long)j * v : 0ll, jreg, verts, joints);
+    return check_launch("g4d_joint_regress_f32");
+}
+
+extern "C" int g4d_rodrigues_f32(int n, const float *rot_vecs, float *rot_mats, g4d_stream_t stream) {
+    G4D_REQUIRE(n >= 0, "g4d_rodrigues_f32: negative size");
+    if (n == 0) return G4D_OK;
+    G4D_REQUIRE(rot_vecs && rot_mats, "g4d_rodrigues_f32: null pointer");
+    hipLaunchKernelGGL(rodrigues_kernel, dim3((n + 255) / 256), dim3(256), 0, G4D_S(stream), n, rot_vecs, rot_mats);
+    return check_launch("g4d_rodrigues_f32");
+}
+
+extern "C" int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *pose, const float *joints, const int *parents,
+                                       float *rot_out, float *posed_joints, float *rel_transforms, float *pose_feature,
+                                       g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && j > 0 && j <= 64, "g4d_rigid_transform_f32: need 1 <= J <= 64");
+    if (b == 0) return G4D_OK;
+    G4D_REQUIRE(pose && joints && parents && rel_transforms, "g4d_rigid_transform_f32: null pointer");
+    hipLaunchKernelGGL(lbs_rigid_kernel, dim3(b), dim3(64), 0, G4D_S(stream), j, pose2rot, pose, joints, parents, rot_out,
+                       posed_joints, rel_transforms, pose_feature);
+    return check_launch("g4d_rigid_transform_f32");
+}
+
+extern "C" int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const float *pose_feature,
+                                     const float *posedirs, const float *weights, int weights_batched, const float *A,
+                                     float *verts, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && v >= 0 && j > 0 && pf >= 0, "g4d_lbs_pose_skin_f32: bad size");
+    if ((long long)b * v == 0) return G4D_OK;
+    G4D_REQUIRE(v_in && weights && A && verts, "g4d_lbs_pose_skin_f32: null pointer");
+    const bool pose = pf > 0;
+    G4D_REQUIRE(!pose || (pose_feature && posedirs), "g4d_lbs_pose_skin_f32: pose_feature/posedirs missing");
+    const size_t lds = sizeof(float) * ((size_t)kFB * j * 12 + (size_t)kFB * pf);
+    G4D_REQUIRE(lds <= 64 * 1024, "g4d_lbs_pose_skin_f32: J/pose-feature too large for LDS staging");
+    dim3 grid((v + 255) / 256, (b + kFB - 1) / kFB);
+    G4D_REQUIRE(grid.y <= 65535, "g4d_lbs_pose_skin_f32: too many frames in one call");
+    const long long wbs = weights_batched ? (long long)v * j : 0ll;
+    if (pose)
+        hipLaunchKernelGGL(lbs_pose_skin_kernel<true>, grid, dim3(256), lds, G4D_S(stream), b, v, j, pf, v_in, pose_feature,
+                           posedirs, weights, wbs, A, verts);
+    else
+        hipLaunchKernelGGL(lbs_pose_skin_kernel<false>, grid, dim3(256), lds, G4D_S(stream), b, v, j, 0, v_in, nullptr,
+                           nullptr, weights, wbs, A, verts);
+    return check_launch("g4d_lbs_pose_skin_f32");
+}

@@ -1,0 +1,139 @@
+"""Graph convolution layer with the reference's class name, parameters and forward signature
+(/root/reference/modules/pygcn/layers.py:9-61) plus the two adjacency helpers the model uses
+(/root/reference/modules/pygcn/utils.py:56-63 normalize, :73-80 sparse_mx_to_torch_sparse_tensor; adjacency
+construction as in modules/mesh_encoder.py:288-307).
+
+forward(input, adj):  out = adj @ (input @ W) + b  -- here ONE fused HIP kernel per layer: each 64-row tile of
+(adj @ input) is aggregated from the CSR rows straight into LDS and contracted with W on the matrix cores
+((A X) W == A (X W)); the reference materialises X W, transposes it to (N, B*F), runs torch.spmm and transposes
+back.  Inference only: parameters are read, no autograd graph is built.
+"""
+import math
+
+import numpy as np
+import torch
+from torch.nn.parameter import Parameter
+
+from . import _lib
+from .fused import PackedLayer, linear
+
+_csr_cache = {}
+
+
+def normalize(mx):
+    """Row-normalise a scipy sparse matrix: D^-1 mx; empty rows stay zero."""
+    import scipy.sparse as sp
+    rowsum = np.array(mx.sum(1))
+    with np.errstate(divide="ignore"):
+        r_inv = np.power(rowsum, -1.0).flatten()
+    r_inv[np.isinf(r_inv)] = 0.0
+    return sp.diags(r_inv).dot(mx)
+
+
+def sparse_mx_to_torch_sparse_tensor(sparse_mx):
+    """scipy sparse -> torch sparse COO float32 (what the reference hands to GraphConvolution.forward)."""
+    coo = sparse_mx.tocoo().astype(np.float32)
+    indices = torch.from_numpy(np.vstack((coo.row, coo.col)).astype(np.int64))
+    return torch.sparse_coo_tensor(indices, torch.from_numpy(coo.data), torch.Size(coo.shape))
+
+
+def adjacency_from_faces(faces, num_verts):
+    """Row-normalised (A + I) of a quad or triangle mesh, built like the reference model does: four edge slots per
+    face, duplicate entries summed, symmetrised by element-wise max, no binarisation."""
+    import scipy.sparse as sp
+    faces = np.asarray(faces)
+    nf, k = faces.shape
+    edges = np.zeros((2, nf * 4), dtype=np.int64)
+    if k == 4:
+        pairs = {0: (0, 1), 1: (1, 2), 2: (2, 3), 3: (3, 0)}
+    elif k == 3:
+        pairs = {0: (0, 1), 1: (1, 2), 3: (2, 0)}  # slot 2 stays (0, 0), as in the reference
+    else:
+        raise NotImplementedError
+    for slot, (a, b) in pairs.items():
+        edges[0, slot::4] = faces[:, a]
+        edges[1, slot::4] = faces[:, b]
+    adj = sp.coo_matrix((np.ones(edges.shape[1]), (edges[0], edges[1])), shape=(num_verts, num_verts), dtype=np.float32).tocsr()
+    adj = adj.maximum(adj.T)
+    return normalize(adj + sp.eye(num_verts))
+
+
+def _to_csr(adj, device):
+    """torch sparse (COO/CSR) or scipy sparse -> (rowptr, colidx, vals) int32/float32 on `device`, cached per object."""
+    key = (id(adj), str(device))
+    hit = _csr_cache.get(key)
+    if hit is not None and hit[0] is adj:
+        return hit[1]
+    if isinstance(adj, torch.Tensor):
+        a = adj.detach().cpu()
+        a = a.coalesce() if a.layout == torch.sparse_coo else a.to_sparse_coo().coalesce()
+        import scipy.sparse as sp
+        m = sp.coo_matrix((a.values().numpy(), (a.indices()[0].numpy(), a.indices()[1].numpy())), shape=tuple(a.shape)).tocsr()
+    else:
+        m = adj.tocsr()
+    m.sort_indices()
+    csr = (torch.from_numpy(m.indptr.astype(np.int32)).to(device), torch.from_numpy(m.indices.astype(np.int32)).to(device),
+           torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
+    _csr_cache[key] = (adj, csr)
+    return csr
+
+
+class GraphConvolution(torch.nn.Module):
+    """Simple GCN layer (Kipf & Welling): same parameters (`weight` (in,out), `bias` (out)) and init as the reference."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = Parameter(torch.empty(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def _packed(self):
+        key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else self.bias._version)
+        hit = getattr(self, "_g4d_packed", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                dev = self.weight.device
+                shift = self.bias.detach().float() if self.bias is not None else torch.zeros(self.out_features, device=dev)
+                L = PackedLayer(self.weight.detach().float().t().contiguous(), torch.ones(self.out_features, device=dev), shift,
+                                relu=False)
+            hit = (key, L)
+            self._g4d_packed = hit
+        return hit[1]
+
+    def forward(self, input, adj, ismlp=False):
+        """input (B,N,Fin) or (N,Fin); adj sparse (N,N).  ismlp=True skips the aggregation (layers.py:43,51)."""
+        if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError("garment4d_amd.gcn.GraphConvolution is forward-only: call it under torch.no_grad()")
+        if not (input.is_cuda and input.dtype == torch.float32):
+            raise RuntimeError("GraphConvolution: input must be a float32 HIP tensor")
+        x = input.contiguous()
+        L = self._packed()
+        squeeze = x.dim() == 2
+        if squeeze:
+            x = x.unsqueeze(0)
+        B, N, Fin = x.shape
+        out = torch.empty((B, N, self.out_features), dtype=torch.float32, device=x.device)
+        if ismlp:
+            # layers.py:43: `support` only gets the bias when one exists -- same thing here (shift = bias or 0)
+            linear(x.view(B * N, Fin), L, out=out.view(B * N, -1))
+        else:
+            rowptr, colidx, vals, n = _to_csr(adj, x.device)
+            assert n == N, "adjacency size does not match the number of vertices"
+            _lib.call("g4d_gcn_linear_f32", B, N, Fin, x.data_ptr(), Fin, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(),
+                      L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), 0, out.data_ptr(),
+                      self.out_features, 0, _lib.stream_ptr())
+        return out[0] if squeeze else out
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} ({self.in_features} -> {self.out_features})"

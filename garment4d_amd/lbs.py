@@ -1,0 +1,135 @@
+"""SMPL linear blend skinning with the reference's function names and signatures
+(/root/reference/smplx/smplx/lbs.py: lbs :152, vertices2joints :251, vertices2jointsB :270, blend_shapes :288,
+batch_rodrigues :312, batch_rigid_transform :362), computed by the HIP kernels of csrc/lbs.hip through the C ABI.
+
+The reference evaluates these on the CPU, batch 1, three times per frame inside DataLoader workers
+(utils/dataloader.py:199-212) and again on the GPU for the garment skinning (modules/mesh_encoder.py:333-408).
+Here one call handles the whole batch of frames.  Forward only (the reference never differentiates through
+the body model: it runs under no_grad in the dataloader; the garment path's gradient flows through torch ops
+that remain available in the reference's own lbs.py).
+"""
+import torch
+
+from . import _lib
+
+_parents_cache = {}
+
+
+def _f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f"{name} must be a float32 HIP tensor (got {type(t).__name__}"
+                           f"{'' if not isinstance(t, torch.Tensor) else ' ' + str(t.dtype) + ' on ' + str(t.device)})")
+    return t.contiguous()
+
+
+def _parents_i32(parents, device):
+    key = (id(parents), str(device))
+    hit = _parents_cache.get(key)
+    if hit is not None and hit[0] is parents:
+        return hit[1]
+    p = torch.as_tensor(parents).to(device=device, dtype=torch.int32).contiguous()
+    _parents_cache[key] = (parents, p)
+    return p
+
+
+def blend_shapes(betas, shape_disps):
+    """betas (B,NB), shape_disps (V,3,NB) -> per-vertex displacement (B,V,3)."""
+    betas, shape_disps = _f32(betas, "betas"), _f32(shape_disps, "shape_disps")
+    B, NB = betas.shape
+    V = shape_disps.shape[0]
+    zero = torch.zeros((V, 3), dtype=torch.float32, device=betas.device)
+    out = torch.empty((B, V, 3), dtype=torch.float32, device=betas.device)
+    _lib.call("g4d_lbs_shape_f32", B, V, NB, betas.data_ptr(), NB, zero.data_ptr(), shape_disps.data_ptr(), out.data_ptr(),
+              _lib.stream_ptr())
+    return out
+
+
+def vertices2joints(J_regressor, vertices):
+    """J_regressor (J,V), vertices (B,V,3) -> joints (B,J,3)."""
+    J_regressor, vertices = _f32(J_regressor, "J_regressor"), _f32(vertices, "vertices")
+    B, V, _ = vertices.shape
+    J = J_regressor.shape[0]
+    out = torch.empty((B, J, 3), dtype=torch.float32, device=vertices.device)
+    _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor.data_ptr(), 0, vertices.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def vertices2jointsB(J_regressor_B, vertices):
+    """Per-sample regressor: J_regressor_B (B,J,V), vertices (B,V,3) -> (B,J,3)."""
+    J_regressor_B, vertices = _f32(J_regressor_B, "J_regressor_B"), _f32(vertices, "vertices")
+    B, V, _ = vertices.shape
+    J = J_regressor_B.shape[1]
+    out = torch.empty((B, J, 3), dtype=torch.float32, device=vertices.device)
+    _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor_B.data_ptr(), 1, vertices.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def batch_rodrigues(rot_vecs, epsilon: float = 1e-8):
+    """rot_vecs (N,3) axis-angle -> (N,3,3).  `epsilon` is accepted and ignored like in the reference (:330 uses
+    the literal 1e-8)."""
+    rot_vecs = _f32(rot_vecs, "rot_vecs")
+    n = rot_vecs.shape[0]
+    out = torch.empty((n, 3, 3), dtype=torch.float32, device=rot_vecs.device)
+    _lib.call("g4d_rodrigues_f32", n, rot_vecs.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def batch_rigid_transform(rot_mats, joints, parents, dtype=torch.float32):
+    """rot_mats (B,J,3,3), joints (B,J,3), parents (J) -> (posed_joints (B,J,3), rel_transforms (B,J,4,4))."""
+    assert dtype == torch.float32
+    rot_mats, joints = _f32(rot_mats, "rot_mats"), _f32(joints, "joints")
+    B, J = joints.shape[:2]
+    posed = torch.empty((B, J, 3), dtype=torch.float32, device=joints.device)
+    A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=joints.device)
+    _lib.call("g4d_rigid_transform_f32", B, J, 0, rot_mats.data_ptr(), joints.data_ptr(),
+              _parents_i32(parents, joints.device).data_ptr(), 0, posed.data_ptr(), A.data_ptr(), 0, _lib.stream_ptr())
+    return posed, A
+
+
+def skin(weights, A, verts):
+    """Skinning step alone (lbs.py:233-246 / mesh_encoder.py:393,406-408): weights (V,J) or (B,V,J), A (B,J,4,4),
+    verts (B,V,3) -> (B,V,3)."""
+    weights, A, verts = _f32(weights, "weights"), _f32(A, "A"), _f32(verts, "verts")
+    B, V, _ = verts.shape
+    J = A.shape[1]
+    out = torch.empty_like(verts)
+    _lib.call("g4d_lbs_pose_skin_f32", B, V, J, 0, verts.data_ptr(), 0, 0, weights.data_ptr(), int(weights.dim() == 3),
+              A.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, pose2rot: bool = True):
+    """Linear blend skinning.  betas (B,NB); pose (B,(J)*3) axis-angle if pose2rot else rotation matrices
+    (B,J,3,3) / (B,J*9); v_template (V,3); shapedirs (V,3,NB); posedirs ((J-1)*9, V*3); J_regressor (J,V);
+    parents (J); lbs_weights (V,J).  Returns (verts (B,V,3), posed joints (B,J,3))."""
+    betas, pose = _f32(betas, "betas"), _f32(pose, "pose")
+    v_template, shapedirs, posedirs = _f32(v_template, "v_template"), _f32(shapedirs, "shapedirs"), _f32(posedirs, "posedirs")
+    J_regressor, lbs_weights = _f32(J_regressor, "J_regressor"), _f32(lbs_weights, "lbs_weights")
+    if v_template.dim() == 3:
+        if v_template.shape[0] != 1:
+            raise NotImplementedError("per-sample v_template is not supported by the HIP path")
+        v_template = v_template[0].contiguous()
+    B = max(betas.shape[0], pose.shape[0])
+    if betas.shape[0] not in (1, B) or pose.shape[0] != B:
+        raise RuntimeError("lbs: betas batch must be 1 or equal to the pose batch")
+    V = v_template.shape[0]
+    NB = betas.shape[1]
+    J = J_regressor.shape[0]
+    dev = betas.device
+    stream = _lib.stream_ptr()
+    v_shaped = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+    _lib.call("g4d_lbs_shape_f32", B, V, NB, betas.data_ptr(), NB if betas.shape[0] == B else 0, v_template.data_ptr(),
+              shapedirs.data_ptr(), v_shaped.data_ptr(), stream)
+    joints = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
+    _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor.data_ptr(), 0, v_shaped.data_ptr(), joints.data_ptr(), stream)
+    PF = (J - 1) * 9
+    assert posedirs.shape[0] == PF and posedirs.shape[1] == V * 3, "posedirs must be ((J-1)*9, V*3)"
+    posed = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
+    A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=dev)
+    pf = torch.empty((B, PF), dtype=torch.float32, device=dev)
+    _lib.call("g4d_rigid_transform_f32", B, J, int(bool(pose2rot)), pose.data_ptr(), joints.data_ptr(),
+              _parents_i32(parents, dev).data_ptr(), 0, posed.data_ptr(), A.data_ptr(), pf.data_ptr(), stream)
+    verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+    _lib.call("g4d_lbs_pose_skin_f32", B, V, J, PF, v_shaped.data_ptr(), pf.data_ptr(), posedirs.data_ptr(),
+              lbs_weights.data_ptr(), 0, A.data_ptr(), verts.data_ptr(), stream)
+    return verts, posed

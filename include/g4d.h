@@ -122,6 +122,37 @@ int g4d_gather_rows_f32(int b, int n, int m, int c, const float *in, const int *
 /* batched matrix transpose (b, r, c) -> (b, c, r): channel-major <-> point-major at the API boundary. */
 int g4d_transpose_f32(int b, int r, int c, const float *in, float *out, g4d_stream_t stream);
 
+/* ---- SMPL linear blend skinning (garment4d_amd/csrc/lbs.hip; reference: smplx/smplx/lbs.py) ------------- */
+
+/* v_shaped (B,V,3) = v_template (V,3) + shapedirs (V,3,NB) . betas (B,NB)       lbs.py:205, blend_shapes :288-309.
+ * betas_bstride = NB, or 0 to broadcast one betas row over the batch. */
+int g4d_lbs_shape_f32(int b, int v, int nb, const float *betas, int betas_bstride, const float *v_template,
+                      const float *shapedirs, float *v_shaped, g4d_stream_t stream);
+
+/* joints (B,J,3) = jreg . verts (B,V,3); jreg (J,V) shared (vertices2joints, lbs.py:251-268) or, with
+ * jreg_batched != 0, (B,J,V) per sample (vertices2jointsB, lbs.py:270-286). */
+int g4d_joint_regress_f32(int b, int j, int v, const float *jreg, int jreg_batched, const float *verts, float *joints,
+                          g4d_stream_t stream);
+
+/* batch_rodrigues (lbs.py:312-346): rot_vecs (N,3) -> rot_mats (N,3,3). */
+int g4d_rodrigues_f32(int n, const float *rot_vecs, float *rot_mats, g4d_stream_t stream);
+
+/* batch_rigid_transform (lbs.py:362-419), optionally preceded by Rodrigues: pose is (B,J,3) axis-angle when
+ * pose2rot != 0, else (B,J,3,3).  joints (B,J,3) rest joints, parents (J) int32 (parents[0] ignored).
+ * Outputs: rel_transforms (B,J,4,4) [required]; rot_out (B,J,3,3), posed_joints (B,J,3), pose_feature
+ * (B,(J-1)*9) = (R[1:]-I) flattened (lbs.py:217,222) are optional (null to skip).  J <= 64. */
+int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *pose, const float *joints, const int *parents,
+                            float *rot_out, float *posed_joints, float *rel_transforms, float *pose_feature,
+                            g4d_stream_t stream);
+
+/* verts (B,V,3) = (W . A) [v_in + pose_feature . posedirs ; 1]     (lbs.py:223-246).  v_in (B,V,3);
+ * pose_feature (B,PF), posedirs (PF, V*3) -- pass pf = 0 to skip the pose blend shapes (plain skinning, e.g. the
+ * garment skinning of modules/mesh_encoder.py:393,406-408); weights (V,J), or (B,V,J) when weights_batched != 0;
+ * A (B,J,4,4). */
+int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const float *pose_feature,
+                          const float *posedirs, const float *weights, int weights_batched, const float *A, float *verts,
+                          g4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""LBS and GCN HIP kernels against the golden vectors of the reference's lbs.py / layers.py and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from garment4d_amd import gcn as G, lbs as L, synthetic as syn
+from oracle import gcn_oracle, lbs_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)  # north_star: 1e-5 fp32 for skinned vertices
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_lbs_golden_small(golden_lbs):
+    g = golden_lbs
+    P = {k[len("small_"):]: v for k, v in g.items() if k.startswith("small_")}
+    args = [dev(P[k]) for k in ("v_template", "shapedirs", "posedirs", "J_regressor")] + [torch.from_numpy(P["parents"]), dev(P["lbs_weights"])]
+    v, j = L.lbs(dev(P["betas"]), dev(P["pose"]), *args, pose2rot=True)
+    np.testing.assert_allclose(host(v), P["verts"], **TOL)
+    np.testing.assert_allclose(host(j), P["joints"], **TOL)
+    v, j = L.lbs(dev(P["betas"]), dev(P["rot"]), *args, pose2rot=False)
+    np.testing.assert_allclose(host(v), P["verts_rotin"], **TOL)
+    np.testing.assert_allclose(host(j), P["joints_rotin"], **TOL)
+    np.testing.assert_allclose(host(L.batch_rodrigues(dev(P["pose"].reshape(-1, 3)))).reshape(3, 24, 3, 3), P["rot"], **TOL)
+    np.testing.assert_allclose(host(L.batch_rodrigues(dev(g["rod_in"]))), g["rod_out"], **TOL)
+    jB = L.vertices2jointsB(dev(g["brt_Jreg"]), dev(g["brt_verts"]))
+    np.testing.assert_allclose(host(jB), g["brt_joints"], **TOL)
+    pj, A = L.batch_rigid_transform(dev(P["rot"]), jB, torch.from_numpy(P["parents"]))
+    np.testing.assert_allclose(host(pj), g["brt_posed"], **TOL)
+    np.testing.assert_allclose(host(A), g["brt_A"], **TOL)
+    np.testing.assert_allclose(host(L.blend_shapes(dev(P["betas"]), dev(P["shapedirs"]))),
+                               lbs_oracle.blend_shapes(P["betas"], P["shapedirs"]), **TOL)
+    np.testing.assert_allclose(host(L.vertices2joints(dev(P["J_regressor"]), dev(g["brt_verts"]))),
+                               lbs_oracle.vertices2joints(P["J_regressor"], g["brt_verts"]), **TOL)
+
+
+def test_lbs_golden_full_size(golden_lbs):
+    g = golden_lbs
+    P = syn.smpl_like_params(V=6890, J=24, num_betas=10, seed=40)
+    betas, pose = syn.smpl_like_pose(2, seed=41)
+    v, j = L.lbs(dev(betas), dev(pose), dev(P["v_template"]), dev(P["shapedirs"]), dev(P["posedirs"]), dev(P["J_regressor"]),
+                 torch.from_numpy(P["parents"]), dev(P["lbs_weights"]))
+    np.testing.assert_allclose(host(v), g["full_verts"], **TOL)
+    np.testing.assert_allclose(host(j), g["full_joints"], **TOL)
+
+
+@pytest.mark.parametrize("B", [1, 8, 19])
+def test_lbs_vs_oracle_batches(B):
+    P = syn.smpl_like_params(V=1500, J=24, num_betas=10, seed=B)
+    betas, pose = syn.smpl_like_pose(B, seed=B + 1)
+    wv, wj = lbs_oracle.lbs(betas, pose, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"])
+    v, j = L.lbs(dev(betas), dev(pose), dev(P["v_template"]), dev(P["shapedirs"]), dev(P["posedirs"]), dev(P["J_regressor"]),
+                 torch.from_numpy(P["parents"]), dev(P["lbs_weights"]))
+    np.testing.assert_allclose(host(v), wv, **TOL)
+    np.testing.assert_allclose(host(j), wj, **TOL)
+
+
+def test_skin_batched_weights_vs_oracle():
+    """garment skinning (mesh_encoder.py:393,406-408): per-sample, per-vertex blended weights."""
+    rng = np.random.default_rng(5)
+    B, V, J = 5, 777, 24
+    W = rng.random((B, V, J)).astype(np.float32); W /= W.sum(2, keepdims=True)
+    A = rng.standard_normal((B, J, 4, 4)).astype(np.float32); A[:, :, 3] = [0, 0, 0, 1]
+    verts = rng.standard_normal((B, V, 3)).astype(np.float32)
+    np.testing.assert_allclose(host(L.skin(dev(W), dev(A), dev(verts))), lbs_oracle.skin(W, A, verts), **TOL)
+    np.testing.assert_allclose(host(L.skin(dev(W[0]), dev(A), dev(verts))), lbs_oracle.skin(W[0], A, verts), **TOL)
+
+
+def test_lbs_rejects_cpu_tensors():
+    with pytest.raises(RuntimeError):
+        L.batch_rodrigues(torch.zeros(4, 3))
+
+
+def test_gcn_golden(golden_gcn):
+    g = golden_gcn
+    adj = G.adjacency_from_faces(g["faces"], 64)
+    import scipy.sparse as sp
+    ref = sp.csr_matrix((g["adj_val"], (g["adj_row"], g["adj_col"])), shape=(64, 64))
+    assert abs(sp.csr_matrix(adj) - ref).max() < 1e-7
+    t_adj = G.sparse_mx_to_torch_sparse_tensor(adj)
+    layer = G.GraphConvolution(12, 20).cuda()
+    layer.weight.data = dev(g["W"]); layer.bias.data = dev(g["b"])
+    x = dev(g["x"])
+    with torch.no_grad():
+        np.testing.assert_allclose(host(layer(x, t_adj)), g["y"], **TOL)
+        np.testing.assert_allclose(host(layer(x, t_adj, ismlp=True)), g["y_mlp"], **TOL)
+        np.testing.assert_allclose(host(layer(x[0], t_adj)), g["y2d"], **TOL)
+        nb = G.GraphConvolution(12, 3, bias=False).cuda()
+        nb.weight.data = dev(g["W_nb"])
+        np.testing.assert_allclose(host(nb(x, t_adj)), g["y_nb"], **TOL)
+    with pytest.raises(NotImplementedError):
+        layer(x.requires_grad_(True), t_adj)
+
+
+def test_gcn_vs_oracle_tshirt_dims():
+    """layer dims of the refinement head (mesh_encoder.py:267-284): 323 -> 128 -> 128 -> 128 -> 3 on a quad cylinder."""
+    verts, faces = syn.quad_cylinder(32, 32)
+    Vg = verts.shape[0]
+    adj = gcn_oracle.adjacency_from_faces(faces, Vg)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, Vg, 323)).astype(np.float32)
+    h_ref, h = x, dev(x)
+    with torch.no_grad():
+        for fin, fout in [(323, 128), (128, 128), (128, 128), (128, 3)]:
+            layer = G.GraphConvolution(fin, fout).cuda()
+            h_ref = gcn_oracle.graph_convolution(h_ref, host(layer.weight), host(layer.bias), adj)
+            h = layer(h, adj)
+            scale = max(1.0, float(np.abs(h_ref).max()))
+            assert float(np.abs(host(h) - h_ref).max()) <= 1e-5 * scale
+            h_ref = np.maximum(h_ref, 0); h = torch.relu(h)
