@@ -1,0 +1,78 @@
+"""Frame sharding across the GPUs of one node.
+
+Every op of the hot path is independent per frame (the reference folds clips x frames into the batch dimension,
+modules/mesh_encoder.py:133), so frames shard with NO data-path collective: rank r owns a contiguous block of the
+flattened (clip, frame) ids.  Only the temporal model around the hot path exchanges data, at two points:
+
+  * max over the T frames of a clip (mesh_encoder.py:161)          -> all_reduce(MAX) of a (clips, C) tensor
+  * temporal attention over the frames of a clip (:467-476)        -> all_gather of (frames_local, Vg, C) features
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI on an MI355X node), "gloo" on CPU
+for the tests.  On the 8-GPU xGMI mesh the all-gather payload is ~2 MB per frame at Vg=4096, C=128: one collective
+per refinement round, large enough (>= 1 MB per peer) to run at link rate.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) block of `n_items` for `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_frames(x: torch.Tensor, rank: int = None, world: int = None) -> torch.Tensor:
+    """x (F, ...) with F = clips*T flattened frame ids -> this rank's block."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    b, e = shard_range(x.shape[0], rank, world)
+    return x[b:e]
+
+
+def allgather_frames(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Inverse of shard_frames: every rank gets the (n_total, ...) tensor.  Ragged blocks (n_total % world != 0) are
+    padded to the largest block for the collective and trimmed afterwards."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    mx = max(e - b for b, e in sizes)
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if all(e - b == mx for b, e in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], dim=0)
+
+
+def clip_max_over_frames(frame_feats_local: torch.Tensor, frame_ids_local: torch.Tensor, n_clips: int, T: int,
+                         group=None) -> torch.Tensor:
+    """max over the T frames of each clip when a clip's frames live on several ranks.
+    frame_feats_local (f_local, C); frame_ids_local (f_local,) global frame ids (clip = id // T) -> (n_clips, C)."""
+    C = frame_feats_local.shape[1]
+    out = frame_feats_local.new_full((n_clips, C), float("-inf"))
+    clip = (frame_ids_local // T).long()
+    out.scatter_reduce_(0, clip[:, None].expand(-1, C), frame_feats_local, reduce="amax", include_self=True)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.MAX, group=group)
+    return out
+
+
+def temporal_attention(last_feat_local: torch.Tensor, frame_ids_local: torch.Tensor, n_frames: int, T: int, qkv,
+                       group=None) -> torch.Tensor:
+    """The reference's temporal attention (mesh_encoder.py:467-476) for frame-sharded features: k, v of ALL T frames
+    of a clip are needed, so the per-frame features are all-gathered once, q/k/v are computed locally, and each rank
+    evaluates the softmax(q k^T / sqrt(T)) v rows of its own frames.
+    last_feat_local (f_local, Vg, C); qkv: a Linear(Vg*C -> 3*Vg*C)-like callable applied to flattened frames."""
+    feats = allgather_frames(last_feat_local, n_frames, group)          # (F, Vg, C)
+    F_, Vg, C = feats.shape
+    n_clips = F_ // T
+    q, k, v = qkv(feats.reshape(n_clips, T, Vg * C)).chunk(3, dim=-1)   # each (clips, T, Vg*C)
+    att = torch.softmax(torch.matmul(q, k.transpose(1, 2)) / (T ** 0.5), dim=-1)
+    out = torch.matmul(att, v).reshape(F_, Vg, C)
+    return out[frame_ids_local.long()]
