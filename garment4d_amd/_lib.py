@@ -21,6 +21,7 @@ SIGNATURES = {
     "g4d_gather_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_gather_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_ball_query_f32": [_I, _I, _I, _F, _I, _vp, _vp, _vp, _vp],
+    "g4d_ball_query_msg_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_group_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_group_grad_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_three_nn_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],
@@ -30,6 +31,8 @@ SIGNATURES = {
     "g4d_group_linear_f32": [_I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _I, _vp, _I, _I, _vp],
     "g4d_interp_linear_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_gcn_linear_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
+    "g4d_mlp_stack_f32": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp,
+                          _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_pool_rows_f32": [_I, _I, _I, _vp, _I, _vp, _I, _I, _I, _vp],
     "g4d_transpose_f32": [_I, _I, _I, _vp, _vp, _vp],
     "g4d_gather_rows_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
@@ -37,7 +40,7 @@ SIGNATURES = {
     "g4d_joint_regress_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp],
     "g4d_rodrigues_f32": [_I, _vp, _vp, _vp],
     "g4d_rigid_transform_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "g4d_lbs_pose_skin_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp],
+    "g4d_lbs_pose_skin_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -76,7 +76,106 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, float rad
     }
 }
 
+// Multi-scale variant: NS radii per query, one distance evaluation per (query, point) pair.
+struct MsgArgs {
+    float radius2[4];
+    int nsample[4];
+    int *idx[4];
+};
+
+template <int QW, int NS>
+__global__ void __launch_bounds__(256) ball_query_msg_kernel(int n, int m, const MsgArgs a, const float *__restrict__ new_xyz_all,
+                                                            const float *__restrict__ xyz_all) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * QW;
+    if (q0 >= m) return;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
+    float qx[QW], qy[QW], qz[QW];
+    int cnt[QW][NS], first[QW][NS];
+    int open = 0;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = min(q0 + i, m - 1);
+        qx[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 0])));
+        qy[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 1])));
+        qz[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 2])));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cnt[i][s] = (q0 + i < m) ? 0 : a.nsample[s];
+            first[i][s] = 0;
+            open += (q0 + i < m) ? 1 : 0;
+        }
+    }
+    for (int base = 0; base < n && open > 0; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < n;
+        const int kc = valid ? k : n - 1;
+        const float x = xyz[kc * 3 + 0], y = xyz[kc * 3 + 1], z = xyz[kc * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
+                    const bool hit = valid && (d2 < a.radius2[s]);
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (mask != 0ull) {
+                        if (cnt[i][s] == 0) first[i][s] = base + __builtin_ctzll(mask);
+                        const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
+                        cnt[i][s] += __builtin_popcountll(mask);
+                        if (cnt[i][s] >= a.nsample[s]) --open;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (q0 + i < m && cnt[i][s] < a.nsample[s])
+                for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
+}
+
 }  // namespace g4d
+
+extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                      const float *new_xyz, const float *xyz, int *const *idx, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nscales >= 1 && nscales <= 4 && b <= 65535, "g4d_ball_query_msg_f32: bad sizes");
+    G4D_REQUIRE(radii && nsamples && idx, "g4d_ball_query_msg_f32: null pointer");
+    if (nscales == 1) return g4d_ball_query_f32(b, n, m, radii[0], nsamples[0], new_xyz, xyz, idx[0], stream);
+    if (b == 0 || m == 0) return G4D_OK;
+    G4D_REQUIRE(new_xyz && xyz, "g4d_ball_query_msg_f32: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MsgArgs a = {};
+    for (int s = 0; s < nscales; ++s) {
+        G4D_REQUIRE(nsamples[s] > 0 && idx[s], "g4d_ball_query_msg_f32: bad scale %d", s);
+        a.radius2[s] = radii[s] * radii[s];
+        a.nsample[s] = nsamples[s];
+        a.idx[s] = idx[s];
+        if (n == 0) {
+            hipError_t e = hipMemsetAsync(idx[s], 0, sizeof(int) * (size_t)b * m * nsamples[s], st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    if (n == 0) return G4D_OK;
+    const long long queries = (long long)b * m;
+    int qw = 4;
+    while (qw > 1 && queries / qw < 2048) qw >>= 1;
+    dim3 grid((m + 4 * qw - 1) / (4 * qw), b), block(256);
+#define G4D_BQ(QW, NS) hipLaunchKernelGGL((ball_query_msg_kernel<QW, NS>), grid, block, 0, st, n, m, a, new_xyz, xyz)
+    if (nscales == 2) { if (qw == 4) G4D_BQ(4, 2); else if (qw == 2) G4D_BQ(2, 2); else G4D_BQ(1, 2); }
+    else if (nscales == 3) { if (qw == 4) G4D_BQ(4, 3); else if (qw == 2) G4D_BQ(2, 3); else G4D_BQ(1, 3); }
+    else { if (qw == 4) G4D_BQ(4, 4); else if (qw == 2) G4D_BQ(2, 4); else G4D_BQ(1, 4); }
+#undef G4D_BQ
+    return check_launch("g4d_ball_query_msg_f32");
+}
 
 extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                                   int *idx, g4d_stream_t stream) {

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
         px[i] = ok ? xyz[k * 3 + 0] : 0.f;
         py[i] = ok ? xyz[k * 3 + 1] : 0.f;
         pz[i] = ok ? xyz[k * 3 + 2] : 0.f;
-        md[i] = ok ? temp[k] : -2.f;  // -2 never beats the scan's initial best (-1)
+        md[i] = ok ? (temp_all ? temp[k] : 1e10f) : -2.f;  // -2 never beats the scan's initial best (-1)
         if (ok) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
     }
     if (t == 0) idx[0] = 0;
@@ -157,10 +157,12 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
         if (t == 0) idx[j] = old;
     }
+    if (temp_all) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int k = t + brev_small<U>(i / Q) * T + (i % Q) * bs;
-        if (k < n) temp[k] = md[i];
+        for (int i = 0; i < P; ++i) {
+            const int k = t + brev_small<U>(i / Q) * T + (i % Q) * bs;
+            if (k < n) temp[k] = md[i];
+        }
     }
 }
 
@@ -254,7 +256,7 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
     G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "g4d_fps_f32: negative size (b=%d n=%d m=%d)", b, n, m);
     if (b == 0 || m == 0) return G4D_OK;  // sampling_gpu.cu:100  if (m <= 0) return;
     G4D_REQUIRE(n > 0, "g4d_fps_f32: n must be > 0 when m > 0");
-    G4D_REQUIRE(xyz && temp && idx, "g4d_fps_f32: null pointer");
+    G4D_REQUIRE(xyz && idx, "g4d_fps_f32: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int bs = ref_block_size(n);
     int log2bs = 0;
@@ -321,6 +323,7 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
         }
     }
 #undef G4D_FPS_CASE
+    G4D_REQUIRE(temp, "g4d_fps_f32: temp scratch (B,N) is required for this N (register-resident path covers 64 <= N <= 12800)");
     hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx);
     return check_launch("g4d_fps_f32(generic)");
 }

@@ -5,14 +5,13 @@
 //   lbs_shape_kernel   v_shaped = v_template + shapedirs . betas                       (lbs.py:205, 288-309)
 //   joint_regress      J = J_regressor . v_shaped  (shared or per-sample regressor)    (lbs.py:209, 251-286)
 //   lbs_rigid_kernel   Rodrigues, kinematic chain, rel. transforms A, pose feature     (lbs.py:312-419, 215-222)
-//   lbs_pose_skin      v_posed = v_shaped + pose_feature . posedirs;  T = W . A;  verts = T [v_posed;1]
-//                                                                                     (lbs.py:223-246)
+//   lbs_pose_blend     v_posed = v_shaped + pose_feature . posedirs                     (lbs.py:223-229)
+//   lbs_skin           T = W . A;  verts = T [v_posed;1]                                (lbs.py:233-246)
 //
 // All HBM-bound: the model constants (posedirs 17 MB, shapedirs 0.8 MB, J_regressor 0.66 MB, weights 0.66 MB)
 // are read once per batch of up to 8 frames; per-frame algorithmic traffic is 24 B/vertex + 64 B/joint.
-// In lbs_pose_skin a thread owns one vertex: posedirs rows stream coalesced (12 B/lane), the pose features and
-// the 24 joint transforms of the frames sit in LDS (broadcast reads), the 24 skinning weights of the vertex in
-// registers.
+// lbs_pose_blend splits the 207 pose features over 4 k-slices x 64 columns per workgroup so that ~1300 waves stream
+// posedirs; lbs_skin runs one thread per (frame, vertex) with the frame's 24 joint transforms in LDS.
 #include "g4d_common.h"
 
 namespace g4d {
@@ -168,76 +167,78 @@ __global__ void __launch_bounds__(64) lbs_rigid_kernel(int J, int pose2rot, cons
     }
 }
 
-// verts[b,v,:] = (sum_j W[(b),v,j] A[b,j]) . [v_in[b,v,:] (+ pose_feature[b] . posedirs[:, v]) ; 1]
-template <bool POSE>
-__global__ void __launch_bounds__(256) lbs_pose_skin_kernel(int B, int V, int J, int PF, const float *__restrict__ v_in,
-                                                           const float *__restrict__ pose_feature, const float *__restrict__ posedirs,
-                                                           const float *__restrict__ weights, long long w_bstride,
-                                                           const float *__restrict__ A, float *__restrict__ verts) {
+// v_posed[b,e] = v_shaped[b,e] + sum_k pose_feature[b,k] * posedirs[k,e]     (lbs.py:223-229), e over V*3.
+// 256 threads = 64 columns x 4 k-slices: posedirs (17 MB) streams once per <= 8 frames with 256-byte coalesced row
+// segments and ~1300 waves in flight (a thread-per-vertex layout leaves the chip at 27 workgroups and is latency
+// bound); the four k-slices meet in LDS.
+__global__ void __launch_bounds__(256) lbs_pose_blend_kernel(int B, int E, int PF, const float *__restrict__ v_shaped,
+                                                            const float *__restrict__ pose_feature,
+                                                            const float *__restrict__ posedirs, float *__restrict__ v_posed) {
     extern __shared__ float smem[];
-    float *sA = smem;                 // [kFB][J][12]
-    float *sPF = smem + kFB * J * 12;  // [kFB][PF]
+    float *sPF = smem;                 // [kFB][PF]
+    float *sRed = smem + kFB * PF;     // [3][64][kFB]
     const int b0 = blockIdx.y * kFB;
     const int nf = min(kFB, B - b0);
-    for (int i = threadIdx.x; i < nf * J * 12; i += 256) {
-        const int f = i / (J * 12), r = i % (J * 12);
-        sA[i] = A[((size_t)(b0 + f) * J + r / 12) * 16 + (r % 12)];
+    for (int i = threadIdx.x; i < kFB * PF; i += 256) sPF[i] = (i < nf * PF) ? pose_feature[(size_t)b0 * PF + i] : 0.f;
+    __syncthreads();
+    const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + col;
+    const int kper = (PF + 3) / 4;
+    const int k0 = ks * kper, k1 = min(PF, k0 + kper);
+    float acc[kFB];
+#pragma unroll
+    for (int f = 0; f < kFB; ++f) acc[f] = 0.f;
+    if (e < E) {
+        const float *pd = posedirs + e;
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const float d = pd[(size_t)k * E];
+#pragma unroll
+            for (int f = 0; f < kFB; ++f) acc[f] = fmaf(sPF[f * PF + k], d, acc[f]);
+        }
     }
-    if (POSE)
-        for (int i = threadIdx.x; i < nf * PF; i += 256) sPF[i] = pose_feature[(size_t)b0 * PF + i];
+    if (ks > 0) {
+#pragma unroll
+        for (int f = 0; f < kFB; ++f) sRed[((ks - 1) * 64 + col) * kFB + f] = acc[f];
+    }
+    __syncthreads();
+    if (ks == 0 && e < E) {
+#pragma unroll
+        for (int f = 0; f < kFB; ++f) {
+            if (f < nf) {
+                const float o = ((acc[f] + sRed[(0 * 64 + col) * kFB + f]) + sRed[(1 * 64 + col) * kFB + f]) + sRed[(2 * 64 + col) * kFB + f];
+                v_posed[(size_t)(b0 + f) * E + e] = o + v_shaped[(size_t)(b0 + f) * E + e];
+            }
+        }
+    }
+}
+
+// verts[b,v,:] = (sum_j W[(b),v,j] A[b,j]) . [v_in[b,v,:]; 1]   -- one thread per (frame, vertex), A[b] in LDS.
+__global__ void __launch_bounds__(256) lbs_skin_kernel(int V, int J, const float *__restrict__ v_in,
+                                                      const float *__restrict__ weights, long long w_bstride,
+                                                      const float *__restrict__ A, float *__restrict__ verts) {
+    extern __shared__ float sA[];  // [J][12]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < J * 12; i += 256) sA[i] = A[((size_t)b * J + i / 12) * 16 + (i % 12)];
     __syncthreads();
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
-    float px[kFB], py[kFB], pz[kFB];
+    const float *w = weights + (size_t)b * w_bstride + (size_t)v * J;
+    float T[12];
 #pragma unroll
-    for (int f = 0; f < kFB; ++f) {
-        if (f < nf) {
-            const float *p = v_in + ((size_t)(b0 + f) * V + v) * 3;
-            px[f] = p[0]; py[f] = p[1]; pz[f] = p[2];
-        } else {
-            px[f] = py[f] = pz[f] = 0.f;
-        }
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const float wj = w[j];
+        const float *a = sA + j * 12;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(wj, a[e], T[e]);  // lbs.py:238  T = W . A
     }
-    if (POSE) {
-        float ox[kFB], oy[kFB], oz[kFB];
-#pragma unroll
-        for (int f = 0; f < kFB; ++f) ox[f] = oy[f] = oz[f] = 0.f;
-        const float *pd = posedirs + (size_t)v * 3;
-        const size_t stride = (size_t)V * 3;
-        for (int k = 0; k < PF; ++k) {
-            const float d0 = pd[k * stride + 0], d1 = pd[k * stride + 1], d2 = pd[k * stride + 2];
-#pragma unroll
-            for (int f = 0; f < kFB; ++f) {
-                const float pf = sPF[f * PF + k];  // LDS broadcast; frames >= nf read stale-but-finite data, discarded
-                ox[f] = fmaf(pf, d0, ox[f]);
-                oy[f] = fmaf(pf, d1, oy[f]);
-                oz[f] = fmaf(pf, d2, oz[f]);
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < kFB; ++f) { px[f] = ox[f] + px[f]; py[f] = oy[f] + py[f]; pz[f] = oz[f] + pz[f]; }  // lbs.py:229
-    }
-    for (int f = 0; f < nf; ++f) {
-        const float *w = weights + (size_t)(b0 + f) * w_bstride + (size_t)v * J;
-        float T[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-        for (int j = 0; j < J; ++j) {
-            const float wj = w[j];
-            const float *a = sA + (f * J + j) * 12;
-#pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = fmaf(wj, a[e], T[e]);  // lbs.py:238  T = W . A
-        }
-        // select this frame's point without dynamic register indexing
-        float x = 0.f, y = 0.f, z = 0.f;
-#pragma unroll
-        for (int g = 0; g < kFB; ++g)
-            if (g == f) { x = px[g]; y = py[g]; z = pz[g]; }
-        float *o = verts + ((size_t)(b0 + f) * V + v) * 3;
-        o[0] = fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3];  // lbs.py:244  T . [v;1]
-        o[1] = fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7];
-        o[2] = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
-    }
+    const float *p = v_in + ((size_t)b * V + v) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    float *o = verts + ((size_t)b * V + v) * 3;
+    o[0] = fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3];  // lbs.py:244  T . [v;1]
+    o[1] = fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7];
+    o[2] = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
 }
 
 }  // namespace g4d
@@ -292,22 +293,22 @@ extern "C" int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *
 
 extern "C" int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const float *pose_feature,
                                      const float *posedirs, const float *weights, int weights_batched, const float *A,
-                                     float *verts, g4d_stream_t stream) {
-    G4D_REQUIRE(b >= 0 && v >= 0 && j > 0 && pf >= 0, "g4d_lbs_pose_skin_f32: bad size");
+                                     float *v_posed_scratch, float *verts, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && v >= 0 && j > 0 && pf >= 0 && b <= 65535, "g4d_lbs_pose_skin_f32: bad size");
     if ((long long)b * v == 0) return G4D_OK;
     G4D_REQUIRE(v_in && weights && A && verts, "g4d_lbs_pose_skin_f32: null pointer");
-    const bool pose = pf > 0;
-    G4D_REQUIRE(!pose || (pose_feature && posedirs), "g4d_lbs_pose_skin_f32: pose_feature/posedirs missing");
-    const size_t lds = sizeof(float) * ((size_t)kFB * j * 12 + (size_t)kFB * pf);
-    G4D_REQUIRE(lds <= 64 * 1024, "g4d_lbs_pose_skin_f32: J/pose-feature too large for LDS staging");
-    dim3 grid((v + 255) / 256, (b + kFB - 1) / kFB);
-    G4D_REQUIRE(grid.y <= 65535, "g4d_lbs_pose_skin_f32: too many frames in one call");
-    const long long wbs = weights_batched ? (long long)v * j : 0ll;
-    if (pose)
-        hipLaunchKernelGGL(lbs_pose_skin_kernel<true>, grid, dim3(256), lds, G4D_S(stream), b, v, j, pf, v_in, pose_feature,
-                           posedirs, weights, wbs, A, verts);
-    else
-        hipLaunchKernelGGL(lbs_pose_skin_kernel<false>, grid, dim3(256), lds, G4D_S(stream), b, v, j, 0, v_in, nullptr,
-                           nullptr, weights, wbs, A, verts);
+    const float *skin_in = v_in;
+    if (pf > 0) {
+        G4D_REQUIRE(pose_feature && posedirs && v_posed_scratch, "g4d_lbs_pose_skin_f32: pose_feature/posedirs/scratch missing");
+        const size_t lds = sizeof(float) * ((size_t)kFB * pf + 3 * 64 * kFB);
+        G4D_REQUIRE(lds <= 64 * 1024, "g4d_lbs_pose_skin_f32: pose feature too long for LDS staging");
+        dim3 grid((v * 3 + 63) / 64, (b + kFB - 1) / kFB);
+        hipLaunchKernelGGL(lbs_pose_blend_kernel, grid, dim3(256), lds, G4D_S(stream), b, v * 3, pf, v_in, pose_feature, posedirs,
+                           v_posed_scratch);
+        skin_in = v_posed_scratch;
+    }
+    G4D_REQUIRE((size_t)j * 12 * sizeof(float) <= 64 * 1024, "g4d_lbs_pose_skin_f32: too many joints");
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3((v + 255) / 256, b), dim3(256), sizeof(float) * j * 12, G4D_S(stream), v, j, skin_in,
+                       weights, weights_batched ? (long long)v * j : 0ll, A, verts);
     return check_launch("g4d_lbs_pose_skin_f32");
 }

@@ -1,0 +1,113 @@
+// Shared pieces of the MFMA shared-MLP kernels (mlp.hip: one layer per launch; mlp_stack.hip: up to four layers
+// per launch with activations resident in LDS): argument block, per-row loader state and the element loader of
+// the four A-operand sources (DIRECT / GROUP / INTERP / CSR).
+#pragma once
+#include "g4d_common.h"
+
+namespace g4d {
+
+enum { LOAD_DIRECT = 0, LOAD_GROUP = 1, LOAD_INTERP = 2, LOAD_CSR = 3 };
+
+struct LinearArgs {
+    // contraction
+    int rows, K, Kpad, Cout;
+    const float *W;      // [CoutPad64][Kpad] row-major, zero padded (packed once on the host side)
+    const float *scale;  // [CoutPad64]
+    const float *shift;  // [CoutPad64]
+    int relu;
+    // output
+    float *out;
+    int ldo, col0;
+    int pool;  // 0 none, 1 max, 2 avg  over S consecutive rows
+    int S;
+    // DIRECT / CSR source
+    const float *X;
+    int ldx;
+    // GROUP
+    const float *xyz, *new_xyz, *feats;
+    const int *idx;
+    int N, P, C, use_xyz;
+    // INTERP
+    const float *known_feats, *skip, *dist2;
+    const int *nn_idx;
+    int C2, C1, m, n;
+    // CSR
+    const int *rowptr, *colidx;
+    const float *vals;
+    int Vg;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+struct RowCtx {  // per-thread, per-row state reused across K chunks
+    bool valid;
+    // GROUP
+    size_t pt_base;   // (b*N + j)
+    float cx, cy, cz;
+    // INTERP
+    size_t k0, k1, k2, sk;
+    float w0, w1, w2;
+    // CSR
+    int f, beg, end;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowCtx<MODE> make_ctx(const LinearArgs &a, int row) {
+    RowCtx<MODE> c;
+    c.valid = row < a.rows;
+    if (!c.valid) return c;
+    if constexpr (MODE == LOAD_GROUP) {
+        const int q = row / a.S;  // (b*P + p)
+        const int b = q / a.P;
+        const int j = a.idx[row];
+        c.pt_base = (size_t)b * a.N + j;
+        const float *ctr = a.new_xyz + (size_t)q * 3;
+        c.cx = ctr[0]; c.cy = ctr[1]; c.cz = ctr[2];
+    } else if constexpr (MODE == LOAD_INTERP) {
+        const int b = row / a.n;
+        const int *ix = a.nn_idx + (size_t)row * 3;
+        const float *d2 = a.dist2 + (size_t)row * 3;
+        // pointnet2_utils.py:98 sqrt; pointnet2_modules.py:140-142 inverse-distance weights
+        const float r0 = 1.0f / (__fsqrt_rn(d2[0]) + 1e-8f), r1 = 1.0f / (__fsqrt_rn(d2[1]) + 1e-8f),
+                    r2 = 1.0f / (__fsqrt_rn(d2[2]) + 1e-8f);
+        const float norm = (r0 + r1) + r2;
+        c.w0 = r0 / norm; c.w1 = r1 / norm; c.w2 = r2 / norm;
+        c.k0 = ((size_t)b * a.m + ix[0]) * a.C2;
+        c.k1 = ((size_t)b * a.m + ix[1]) * a.C2;
+        c.k2 = ((size_t)b * a.m + ix[2]) * a.C2;
+        c.sk = (size_t)row * a.C1;
+    } else if constexpr (MODE == LOAD_CSR) {
+        c.f = row / a.Vg;
+        const int v = row - c.f * a.Vg;
+        c.beg = a.rowptr[v];
+        c.end = a.rowptr[v + 1];
+    }
+    return c;
+}
+
+template <int MODE>
+__device__ __forceinline__ float load_elem(const LinearArgs &a, const RowCtx<MODE> &c, int row, int k) {
+    if (!c.valid || k >= a.K) return 0.f;
+    if constexpr (MODE == LOAD_DIRECT) {
+        return a.X[(size_t)row * a.ldx + k];
+    } else if constexpr (MODE == LOAD_GROUP) {
+        if (a.use_xyz) {
+            if (k < 3) {
+                const float g = a.xyz[c.pt_base * 3 + k];
+                return g - (k == 0 ? c.cx : (k == 1 ? c.cy : c.cz));
+            }
+            return a.feats[c.pt_base * a.C + (k - 3)];
+        }
+        return a.feats[c.pt_base * a.C + k];
+    } else if constexpr (MODE == LOAD_INTERP) {
+        if (k < a.C2) return c.w0 * a.known_feats[c.k0 + k] + c.w1 * a.known_feats[c.k1 + k] + c.w2 * a.known_feats[c.k2 + k];
+        return a.skip[c.sk + (k - a.C2)];
+    } else {
+        float s = 0.f;
+        for (int e = c.beg; e < c.end; ++e) s += a.vals[e] * a.X[((size_t)c.f * a.Vg + a.colidx[e]) * a.ldx + k];
+        return s;
+    }
+}
+
+}  // namespace g4d

@@ -1,0 +1,245 @@
+// Whole shared-MLP stacks (up to 4 layers) in ONE launch, activations resident in LDS.
+//
+// The one-layer kernel (mlp.hip) already keeps the grouped tensor out of HBM; what is left of the reference's
+// traffic is the hidden activations (B,C,P,S) between the 1x1 convs (pointnet2_modules.py:40 runs Conv2d+BN+ReLU
+// as separate cuDNN/elementwise launches, each round-tripping HBM) and one kernel boundary per layer on launches
+// that last 5-30 us.  Here a workgroup takes 64 rows (64 / S whole neighbourhoods) through every layer:
+//
+//   phase 0  the row loader (GROUP / INTERP / DIRECT / CSR, mlp_common.h) gathers the whole [64][K0pad] input
+//            tile into LDS buffer 0 -- all global loads of the tile are in flight at once;
+//   layer l  A fragments come from the input buffer (ds_read_b128), W fragments straight from global memory
+//            (weights are a few hundred KB, L2-resident, each lane reads 16 contiguous bytes of its row),
+//            4 waves x 4 accumulator tiles of v_mfma_f32_16x16x4_f32 per 64-channel slab; the epilogue applies the
+//            folded BN affine + ReLU and scatters into the other LDS buffer (ping-pong), or -- last layer -- pools
+//            over the S samples in-wave and writes point-major output at a column offset;
+//   one barrier per layer (plus one per extra 64-channel slab), none per K chunk.
+//
+// Hidden widths <= 128 (buffers are [64][ld] fp32, ld = width rounded to 64, +4 to spread ds_read_b128 over the
+// banks).  Waves whose 16-channel slice lies beyond Cout skip their MFMAs (narrow layers leave the matrix pipe to
+// the other resident workgroups).  An optional tap writes one hidden layer to HBM as well (FP1 features feed the
+// head AND are returned to the caller).
+#include "mlp_common.h"
+
+namespace g4d {
+
+constexpr int kMaxLayers = 4;
+
+struct StackLayer {
+    const float *W, *scale, *shift;  // packed like mlp.hip: [CoutPad64][Kpad], [CoutPad64]
+    int Kpad, Cout, relu;
+};
+
+struct StackArgs {
+    LinearArgs in;  // loader description + rows/K/S/pool/out/ldo/col0 (W/scale/shift/Kpad/Cout unused)
+    StackLayer layer[kMaxLayers];
+    int nlayers;
+    int ld0, ld1;  // LDS row strides (floats) of buffer 0 / 1
+    int tap_layer; // -1 or index of a hidden layer whose output is also stored to HBM
+    float *tap_out;
+    int tap_ld;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) mlp_stack_kernel(const StackArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *buf0 = smem;
+    float *buf1 = smem + 64 * s.ld0;
+    const LinearArgs &a = s.in;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * 64;
+    const int fi = lane & 15, fq = lane >> 4;
+
+    // ---- phase 0: gather the input tile [64][K0pad] into buf0 (zeros beyond K and beyond the last row)
+    {
+        const int lr = t >> 2;  // 4 threads per row
+        const RowCtx<MODE> ctx = make_ctx<MODE>(a, row0 + lr);
+        const int K0pad = s.layer[0].Kpad;
+        for (int k = (t & 3) * 4; k < K0pad; k += 16) {
+            f32x4 v;
+            if (MODE == LOAD_DIRECT && ctx.valid && k + 3 < a.K && (a.ldx & 3) == 0) {
+                v = *reinterpret_cast<const f32x4 *>(a.X + (size_t)(row0 + lr) * a.ldx + k);
+            } else {
+                v.x = load_elem<MODE>(a, ctx, row0 + lr, k);
+                v.y = load_elem<MODE>(a, ctx, row0 + lr, k + 1);
+                v.z = load_elem<MODE>(a, ctx, row0 + lr, k + 2);
+                v.w = load_elem<MODE>(a, ctx, row0 + lr, k + 3);
+            }
+            *reinterpret_cast<f32x4 *>(&buf0[lr * s.ld0 + k]) = v;
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < s.nlayers; ++l) {
+        const StackLayer &L = s.layer[l];
+        const float *in = (l & 1) ? buf1 : buf0;
+        float *out = (l & 1) ? buf0 : buf1;
+        const int ldin = (l & 1) ? s.ld1 : s.ld0, ldout = (l & 1) ? s.ld0 : s.ld1;
+        const bool last = l == s.nlayers - 1;
+        const int nslab = (L.Cout + 63) >> 6;
+        for (int sl = 0; sl < nslab; ++sl) {
+            const int ch = sl * 64 + wave * 16 + fi;
+            const bool wave_live = sl * 64 + wave * 16 < L.Cout;  // wave-uniform
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (wave_live) {
+                const float *wp = L.W + (size_t)ch * L.Kpad + fq * 4;
+                const float *ap = in + fi * ldin + fq * 4;
+                f32x4 bf = *reinterpret_cast<const f32x4 *>(wp);
+                for (int kk = 0; kk < L.Kpad; kk += 16) {
+                    const f32x4 bcur = bf;
+                    if (kk + 16 < L.Kpad) bf = *reinterpret_cast<const f32x4 *>(wp + kk + 16);  // prefetch next W fragment
+                    f32x4 af[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(ap + mt * 16 * ldin + kk);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bcur[e], acc[mt], 0, 0, 0);
+                }
+            }
+            const float sc = L.scale[ch], sh = L.shift[ch];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float y = acc[mt][r] * sc + sh;
+                    if (L.relu) y = fmaxf(y, 0.f);
+                    acc[mt][r] = y;
+                }
+            if (!last) {
+                // hidden layer: scatter into the other LDS buffer (channels beyond Cout come out as exact zeros:
+                // W rows, scale and shift are zero padded), optionally tap to HBM
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[(mt * 16 + fq * 4 + r) * ldout + ch] = acc[mt][r];
+                if (l == s.tap_layer && ch < L.Cout) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = row0 + mt * 16 + fq * 4 + r;
+                            if (row < a.rows) s.tap_out[(size_t)row * s.tap_ld + ch] = acc[mt][r];
+                        }
+                }
+                continue;
+            }
+            // ---- last layer: (pool and) store to HBM, same epilogue as mlp.hip
+            const bool ch_ok = ch < L.Cout;
+            if (a.pool == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = row0 + mt * 16 + fq * 4 + r;
+                        if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = acc[mt][r];
+                    }
+            } else {
+                const bool is_max = a.pool == 1;
+                float v[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
+                                     : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
+                    const float y = __shfl_xor(x, 16);
+                    x = is_max ? fmaxf(x, y) : x + y;
+                    const float z = __shfl_xor(x, 32);
+                    x = is_max ? fmaxf(x, z) : x + z;
+                    v[mt] = x;
+                }
+                const int groups = 64 / a.S;
+                if (groups == 2) {
+                    v[0] = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];
+                    v[1] = is_max ? fmaxf(v[2], v[3]) : v[2] + v[3];
+                } else if (groups == 1) {
+                    v[0] = is_max ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : ((v[0] + v[1]) + (v[2] + v[3]));
+                }
+                if (lane < 16 && ch_ok) {
+                    const float inv = is_max ? 1.f : 1.f / (float)a.S;
+                    for (int g = 0; g < groups; ++g) {
+                        const int orow = (row0 / a.S) + g;
+                        if (orow * a.S < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = v[g] * inv;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // layer l's output complete before layer l+1 reads it (and before buf reuse)
+    }
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+
+// One C entry point for all loaders: `mode` 0 DIRECT, 1 GROUP, 2 INTERP, 3 CSR; loader pointers that a mode does
+// not use are ignored.  Layer descriptors arrive as parallel arrays (host memory) of length nlayers <= 4.
+extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
+                                 /* DIRECT / CSR */ const float *X, int ldx,
+                                 /* GROUP  */ int N, int P, int S, int C, int use_xyz, const float *xyz, const float *new_xyz,
+                                 const float *feats, const int *idx,
+                                 /* INTERP */ int n, int m, int C2, int C1, const float *known_feats, const float *skip,
+                                 const float *dist2, const int *nn_idx,
+                                 /* CSR    */ int Vg, const int *rowptr, const int *colidx, const float *vals,
+                                 /* layers */ int nlayers, const float *const *W, const float *const *scale,
+                                 const float *const *shift, const int *Kpad, const int *Cout, const int *relu,
+                                 /* output */ int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
+                                 g4d_stream_t stream) {
+    G4D_REQUIRE(mode >= 0 && mode <= 3, "g4d_mlp_stack_f32: bad mode");
+    G4D_REQUIRE(nlayers >= 1 && nlayers <= kMaxLayers, "g4d_mlp_stack_f32: 1..%d layers", kMaxLayers);
+    G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) && K0 > 0, "g4d_mlp_stack_f32: bad sizes");
+    if (rows == 0) return G4D_OK;
+    G4D_REQUIRE(W && scale && shift && Kpad && Cout && relu && out, "g4d_mlp_stack_f32: null pointer");
+    G4D_REQUIRE(pool >= 0 && pool <= 2, "g4d_mlp_stack_f32: pool must be 0|1|2");
+    if (pool) G4D_REQUIRE((S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_stack_f32: pooling needs S in {16,32,64}");
+    StackArgs s = {};
+    s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
+    s.in.X = X; s.in.ldx = ldx;
+    s.in.xyz = xyz; s.in.new_xyz = new_xyz; s.in.feats = feats; s.in.idx = idx; s.in.N = N; s.in.P = P; s.in.C = C; s.in.use_xyz = use_xyz;
+    s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
+    s.in.rowptr = rowptr; s.in.colidx = colidx; s.in.vals = vals; s.in.Vg = Vg;
+    s.nlayers = nlayers;
+    int w0 = 0, w1 = 0;  // widths (floats) buffer 0 / 1 must hold
+    for (int l = 0; l < nlayers; ++l) {
+        G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 32 == 0 && Cout[l] > 0, "g4d_mlp_stack_f32: bad layer %d", l);
+        s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
+        s.layer[l].Kpad = Kpad[l]; s.layer[l].Cout = Cout[l]; s.layer[l].relu = relu[l];
+        int &win = (l & 1) ? w1 : w0;
+        win = win > Kpad[l] ? win : Kpad[l];
+        if (l > 0) {
+            const int prev_pad64 = (Cout[l - 1] + 63) / 64 * 64;
+            G4D_REQUIRE(Kpad[l] <= prev_pad64 && Kpad[l] >= Cout[l - 1], "g4d_mlp_stack_f32: layer %d K does not chain", l);
+            win = win > prev_pad64 ? win : prev_pad64;
+        }
+    }
+    G4D_REQUIRE(Kpad[0] >= K0, "g4d_mlp_stack_f32: Kpad[0] < K0");
+    if (nlayers > 1 && w1 == 0) w1 = 64;
+    s.ld0 = w0 + 4;
+    s.ld1 = (w1 > 0 ? w1 : 0) + 4;
+    const size_t lds = sizeof(float) * 64 * (size_t)(s.ld0 + s.ld1);
+    G4D_REQUIRE(lds <= 150 * 1024, "g4d_mlp_stack_f32: stack too wide for LDS (%zu bytes)", lds);
+    s.tap_layer = tap_out ? tap_layer : -1;
+    s.tap_out = tap_out; s.tap_ld = tap_ld;
+    G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_stack_f32: tap must be a hidden layer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+#define G4D_LAUNCH_STACK(M)                                                                                        \
+    {                                                                                                              \
+        static bool attr = false;                                                                                  \
+        if (!attr) {                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_kernel<M>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL(mlp_stack_kernel<M>, grid, block, lds, st, s);                                          \
+    }
+    switch (mode) {
+        case LOAD_DIRECT: G4D_LAUNCH_STACK(LOAD_DIRECT) break;
+        case LOAD_GROUP: G4D_LAUNCH_STACK(LOAD_GROUP) break;
+        case LOAD_INTERP: G4D_LAUNCH_STACK(LOAD_INTERP) break;
+        default: G4D_LAUNCH_STACK(LOAD_CSR) break;
+    }
+#undef G4D_LAUNCH_STACK
+    return check_launch("g4d_mlp_stack_f32");
+}

@@ -45,16 +45,42 @@ __global__ void __launch_bounds__(256) group_grad_kernel(int c, int n, long long
         if (i < cn) atomicAdd(dst + (size_t)i * n, src[(size_t)i * e_total]);
 }
 
-// three nearest known points per unknown point.  One thread per unknown point (as the reference), but the
-// known points are staged through LDS in 16-byte slots and read as wave-broadcast ds_read_b128, and the
-// top-3 insertion only runs when some lane of the wave needs it.
+// three nearest known points per unknown point.  The reference runs one thread per unknown point scanning all m
+// known points; that leaves one wave per SIMD and a long serial loop.  Here a workgroup = 64 unknown points x 4
+// slices of the known set: the known points are staged through LDS in 16-byte slots (wave-broadcast ds_read_b128),
+// each wave keeps the 3 smallest (d, index) of its slice (ascending index, strict `<` = the reference's cascade),
+// the top-3 insertion only runs when some lane needs it, and wave 0 merges the four partial lists.  The result is
+// the 3 smallest under (d, index) lexicographic order -- exactly what the sequential scan produces.
 constexpr int kNNChunk = 1024;
+__device__ __forceinline__ void nn_insert(float d, int k, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3) {
+    const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;  // cascade of interpolate_gpu.cu:31-42, branch-free
+    const float nb3 = lt2 ? b2 : (lt3 ? d : b3);
+    const int ni3 = lt2 ? i2 : (lt3 ? k : i3);
+    const float nb2 = lt1 ? b1 : (lt2 ? d : b2);
+    const int ni2 = lt1 ? i1 : (lt2 ? k : i2);
+    b1 = lt1 ? d : b1; i1 = lt1 ? k : i1;
+    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+}
+// merge-time insertion: ties between slices resolve to the lower index
+__device__ __forceinline__ void nn_insert_lex(float d, int k, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3) {
+    const bool lt1 = d < b1 || (d == b1 && k < i1), lt2 = d < b2 || (d == b2 && k < i2), lt3 = d < b3 || (d == b3 && k < i3);
+    const float nb3 = lt2 ? b2 : (lt3 ? d : b3);
+    const int ni3 = lt2 ? i2 : (lt3 ? k : i3);
+    const float nb2 = lt1 ? b1 : (lt2 ? d : b2);
+    const int ni2 = lt1 ? i1 : (lt2 ? k : i2);
+    b1 = lt1 ? d : b1; i1 = lt1 ? k : i1;
+    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+}
+
 __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                       const float *__restrict__ known_all, float *__restrict__ dist2_all,
                                                       int *__restrict__ idx_all) {
     __shared__ float4 sk[kNNChunk];
+    __shared__ float sd[3][64][3];
+    __shared__ int si[3][64][3];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
     const float *known = known_all + (size_t)b * m * 3;
     const int pc = min(p, n - 1);
     const float *u = unknown_all + ((size_t)b * n + pc) * 3;
@@ -70,28 +96,35 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
             sk[j] = make_float4(kp[0], kp[1], kp[2], 0.f);
         }
         __syncthreads();
-        for (int j = 0; j < cm; ++j) {
+        const int per = (cm + 3) >> 2;
+        const int j0 = ks * per, j1 = min(cm, j0 + per);
+        for (int j = j0; j < j1; ++j) {
             const float4 kq = sk[j];
             const float dx = ux - kq.x, dy = uy - kq.y, dz = uz - kq.z;
             const float d = dx * dx + dy * dy + dz * dz;
-            if (__builtin_amdgcn_ballot_w64(d < b3) != 0ull) {  // wave-uniform skip
-                const int k = base + j;
-                const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;
-                // cascade of interpolate_gpu.cu:31-42, branch-free
-                const float nb3 = lt2 ? b2 : (lt3 ? d : b3);
-                const int ni3 = lt2 ? i2 : (lt3 ? k : i3);
-                const float nb2 = lt1 ? b1 : (lt2 ? d : b2);
-                const int ni2 = lt1 ? i1 : (lt2 ? k : i2);
-                b1 = lt1 ? d : b1; i1 = lt1 ? k : i1;
-                b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
-            }
+            if (__builtin_amdgcn_ballot_w64(d < b3) != 0ull)  // wave-uniform skip
+                nn_insert(d, base + j, b1, b2, b3, i1, i2, i3);
         }
     }
-    if (p < n) {
-        float *d2 = dist2_all + ((size_t)b * n + p) * 3;
-        int *ix = idx_all + ((size_t)b * n + p) * 3;
-        d2[0] = b1; d2[1] = b2; d2[2] = b3;
-        ix[0] = i1; ix[1] = i2; ix[2] = i3;
+    if (ks > 0) {
+        sd[ks - 1][lane][0] = b1; sd[ks - 1][lane][1] = b2; sd[ks - 1][lane][2] = b3;
+        si[ks - 1][lane][0] = i1; si[ks - 1][lane][1] = i2; si[ks - 1][lane][2] = i3;
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = sd[w][lane][c];
+                if (d < __builtin_inff()) nn_insert_lex(d, si[w][lane][c], b1, b2, b3, i1, i2, i3);
+            }
+        if (p < n) {
+            float *d2 = dist2_all + ((size_t)b * n + p) * 3;
+            int *ix = idx_all + ((size_t)b * n + p) * 3;
+            d2[0] = b1; d2[1] = b2; d2[2] = b3;
+            ix[0] = i1; ix[1] = i2; ix[2] = i3;
+        }
     }
 }
 
@@ -222,7 +255,7 @@ extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const
     G4D_REQUIRE(b <= 65535, "g4d_three_nn_f32: b > 65535 not supported");
     if ((long long)b * n == 0) return G4D_OK;
     G4D_REQUIRE(unknown && dist2 && idx && (known || m == 0), "g4d_three_nn_f32: null pointer");
-    dim3 grid((n + 255) / 256, b);
+    dim3 grid((n + 63) / 64, b);
     hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx);
     return check_launch("g4d_three_nn_f32");
 }

@@ -80,9 +80,12 @@ class Pointnet2MSGSEG(nn.Module):
             l_xyz.append(nx)
             l_feats.append(nf)
         middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None
-        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+        nfp = len(self.FP_modules)
+        for i in range(-1, -nfp, -1):
             l_feats[i - 1] = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
-        sem_logits = fused.conv_stack_forward(self.FC_layer, l_feats[0])  # (B, N, classes)
+        # last FP level + FC head share one launch (the FP features are tapped out for the caller)
+        l_feats[0], sem_logits = fused.fp_forward(self.FP_modules[0], l_xyz[0], l_xyz[1], l_feats[0], l_feats[1],
+                                                  head=self.FC_layer)  # logits (B, N, classes)
         if channel_major:
             l_feats = [None if f is None else fused.to_channel_major(f) for f in l_feats]
             middle = None if middle is None else fused.to_channel_major(middle)

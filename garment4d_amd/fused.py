@@ -21,6 +21,7 @@ from . import pointnet2_utils as PU
 
 _KC = 32
 _BN = 64
+USE_STACK = True  # whole-stack fusion (csrc/mlp_stack.hip); False = one launch per layer (csrc/mlp.hip)
 
 
 def _ptr(t):
@@ -130,6 +131,56 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
     return out
 
 
+_MAX_STACK_LDS = 150 * 1024
+
+
+def stack_fits(layers, pool, S):
+    """Can these packed layers run as ONE g4d_mlp_stack_f32 launch? (<= 4 layers, hidden widths <= 128, LDS budget,
+    pool window 16/32/64)."""
+    if not (1 <= len(layers) <= 4) or (pool and S not in (16, 32, 64)):
+        return False
+    w = [0, 0]
+    for l, L in enumerate(layers):
+        w[l & 1] = max(w[l & 1], L.Kpad)
+        if l > 0:
+            w[l & 1] = max(w[l & 1], (layers[l - 1].Cout + 63) // 64 * 64)
+    if any(L.Cout > 128 for L in layers[:-1]):
+        return False
+    return 4 * 64 * (w[0] + 4 + w[1] + 4) <= _MAX_STACK_LDS
+
+
+def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, group=None, interp=None, csr=None, tap=None):
+    """One launch for the whole stack.  group = (N,P,C,use_xyz,xyz,new_xyz,feats,idx); interp = (n,m,C2,C1,known,skip,
+    dist2,nn_idx); csr = (Vg,rowptr,colidx,vals); tap = (layer_index, tensor2d)."""
+    import ctypes
+    n = len(layers)
+    PA = ctypes.c_void_p * n
+    IA = ctypes.c_int * n
+    Wp, Sc, Sh = PA(*[L.W.data_ptr() for L in layers]), PA(*[L.scale.data_ptr() for L in layers]), PA(*[L.shift.data_ptr() for L in layers])
+    Kp, Co, Re = IA(*[L.Kpad for L in layers]), IA(*[L.Cout for L in layers]), IA(*[L.relu for L in layers])
+    gN = gP = gC = gU = 0
+    gx = gn = gf = gi = 0
+    if group is not None:
+        gN, gP, gC, gU, xyz, new_xyz, feats, idx = group
+        gx, gn, gf, gi = xyz.data_ptr(), new_xyz.data_ptr(), _ptr(feats), idx.data_ptr()
+    inn = im = iC2 = iC1 = 0
+    ik = isk = idd = ii = 0
+    if interp is not None:
+        inn, im, iC2, iC1, known, skip, dist2, nn_idx = interp
+        ik, isk, idd, ii = known.data_ptr(), _ptr(skip), dist2.data_ptr(), nn_idx.data_ptr()
+    cV = 0
+    cr = cc = cv = 0
+    if csr is not None:
+        cV, rowptr, colidx, vals = csr
+        cr, cc, cv = rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr()
+    tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
+    _lib.call("g4d_mlp_stack_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
+              idd, ii, cV, cr, cc, cv, n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
+              ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
+              ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
+    return out
+
+
 def _pool_rows(x2d, groups, S, out, col0, is_max):
     _lib.call("g4d_pool_rows_f32", groups, S, x2d.shape[1], x2d.data_ptr(), x2d.shape[1], out.data_ptr(), out.shape[-1],
               col0, int(is_max), _lib.stream_ptr())
@@ -164,6 +215,24 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
     _pool_rows(h, rows // S, S, out, col0, pool == 1)
 
 
+def ball_query_msg(radii, nsamples, xyz, new_xyz):
+    """All scales of an MSG layer in one pass over the cloud; returns one (B,P,nsample) int32 tensor per scale."""
+    import ctypes
+    B, N, _ = xyz.shape
+    P = new_xyz.shape[1]
+    outs = [torch.empty((B, P, ns), dtype=torch.int32, device=xyz.device) for ns in nsamples]
+    done = 0
+    while done < len(radii):  # the kernel takes up to 4 scales per launch
+        n = min(4, len(radii) - done)
+        R = (ctypes.c_float * n)(*[float(r) for r in radii[done:done + n]])
+        NS = (ctypes.c_int * n)(*[int(v) for v in nsamples[done:done + n]])
+        IP = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs[done:done + n]])
+        _lib.call("g4d_ball_query_msg_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
+                  new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), _lib.stream_ptr())
+        done += n
+    return outs
+
+
 def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
     """Fused PointnetSAModule(MSG).forward (pointnet2_modules.py:19-55), eval mode.
     xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major)."""
@@ -177,25 +246,33 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
     stream = _lib.stream_ptr()
     if sa.npoint is not None:
         if new_xyz is None:
-            sidx = PU.furthest_point_sample(xyz, sa.npoint)
+            if 64 <= N <= 12800:  # register-resident FPS: no scratch tensor, no fill kernel
+                sidx = torch.empty((B, sa.npoint), dtype=torch.int32, device=xyz.device)
+                _lib.call("g4d_fps_f32", B, N, sa.npoint, xyz.data_ptr(), 0, sidx.data_ptr(), stream)
+            else:
+                sidx = PU.furthest_point_sample(xyz, sa.npoint)
             # gather of the 3 coordinates = GROUP loader with S=1 would do; the legacy kernel wants (B,3,N)
             new_xyz = torch.empty((B, sa.npoint, 3), dtype=torch.float32, device=xyz.device)
             _lib.call("g4d_gather_rows_f32", B, N, sa.npoint, 3, xyz.data_ptr(), sidx.data_ptr(), new_xyz.data_ptr(), stream)
         P = new_xyz.shape[1]
         out = torch.empty((B, P, ctot), dtype=torch.float32, device=xyz.device)
         col0 = 0
-        for grouper, layers in zip(sa.groupers, packed):
+        idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz)
+        for grouper, layers, idx in zip(sa.groupers, packed, idxs):
             S = grouper.nsample
             use_xyz = int(grouper.use_xyz)
             assert use_xyz or feats_pm is not None
-            idx = PU.ball_query(grouper.radius, S, xyz, new_xyz)
 
             def first(L, pl, o, c0, idx=idx, S=S, use_xyz=use_xyz):
                 _lib.call("g4d_group_linear_f32", B, N, P, S, C, use_xyz, xyz.data_ptr(), new_xyz.data_ptr(),
                           _ptr(feats_pm), idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                           L.shift.data_ptr(), L.relu, pl, o.data_ptr(), o.shape[-1], c0, stream)
 
-            _run_stack(first, layers, B * P * S, S, pool, out, col0, xyz.device)
+            if USE_STACK and stack_fits(layers, pool, S):
+                mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
+                          group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))
+            else:
+                _run_stack(first, layers, B * P * S, S, pool, out, col0, xyz.device)
             col0 += layers[-1].Cout
         return new_xyz, out
     # GroupAll (pointnet2_utils.py:268-291): one group of all N points, raw coordinates
@@ -211,14 +288,20 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
                       idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), L.relu, pl,
                       o.data_ptr(), o.shape[-1], c0, stream)
 
-        _run_stack(first, layers, B * N, N, pool, out, col0, xyz.device)
+        if USE_STACK and stack_fits(layers, pool, N):
+            mlp_stack(1, B * N, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=N,
+                      group=(N, 1, C, use_xyz, xyz, zero_c, feats_pm, idx))
+        else:
+            _run_stack(first, layers, B * N, N, pool, out, col0, xyz.device)
         col0 += layers[-1].Cout
     return None, out
 
 
-def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm):
+def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
     """Fused PointnetFPModule.forward (pointnet2_modules.py:127-156), eval mode; all features point-major:
-    unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout)."""
+    unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout).
+    With `head` (an FC stack of Conv1d blocks) returns (features, head(features)), fused into the same launch when
+    the widths allow."""
     assert not fp.training, "fused path is eval-mode only"
     _chk(unknown)
     _chk(known_feats_pm)
@@ -234,7 +317,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm):
         h = x.reshape(B * n, -1).contiguous()
         for i, L in enumerate(layers):
             h = linear(h, L, out=out.view(B * n, -1) if i == len(layers) - 1 else None)
-        return out
+        return out if head is None else (out, conv_stack_forward(head, out))
     m = known.shape[1]
     C2 = known_feats_pm.shape[2]
     dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
@@ -246,7 +329,21 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm):
                   dist2.data_ptr(), nn_idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                   L.shift.data_ptr(), L.relu, o.data_ptr(), o.shape[-1], c0, stream)
 
-    _run_stack(first, layers, B * n, 1, 0, out.view(B * n, -1), 0, unknown.device)
+    if head is not None:
+        # FP stack + FC head in one launch; the FP output is tapped to HBM (it is returned to the caller too)
+        hl = pack_conv_stack(head)
+        allL = layers + hl
+        if USE_STACK and stack_fits(allL, 0, 1):
+            logits = torch.empty((B, n, hl[-1].Cout), dtype=torch.float32, device=unknown.device)
+            mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
+                      tap=(len(layers) - 1, out.view(B * n, -1)))
+            return out, logits
+    if USE_STACK and stack_fits(layers, 0, 1):
+        mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
+    else:
+        _run_stack(first, layers, B * n, 1, 0, out.view(B * n, -1), 0, unknown.device)
+    if head is not None:
+        return out, conv_stack_forward(head, out)
     return out
 
 
@@ -254,6 +351,11 @@ def conv_stack_forward(stack, x_pm):
     """FC head (nn.Sequential of pytorch_utils.Conv1d [+Dropout]) on point-major input (B,N,C) -> (B,N,Cout)."""
     B, N, C = x_pm.shape
     h = _chk(x_pm).view(B * N, C)
-    for L in pack_conv_stack(stack):
+    layers = pack_conv_stack(stack)
+    if USE_STACK and stack_fits(layers, 0, 1):
+        out = torch.empty((B * N, layers[-1].Cout), dtype=torch.float32, device=x_pm.device)
+        mlp_stack(0, B * N, C, layers, out, X=h, ldx=C)
+        return out.view(B, N, -1)
+    for L in layers:
         h = linear(h, L)
     return h.view(B, N, -1)

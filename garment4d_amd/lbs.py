@@ -94,7 +94,7 @@ def skin(weights, A, verts):
     J = A.shape[1]
     out = torch.empty_like(verts)
     _lib.call("g4d_lbs_pose_skin_f32", B, V, J, 0, verts.data_ptr(), 0, 0, weights.data_ptr(), int(weights.dim() == 3),
-              A.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+              A.data_ptr(), 0, out.data_ptr(), _lib.stream_ptr())
     return out
 
 
@@ -130,6 +130,7 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     _lib.call("g4d_rigid_transform_f32", B, J, int(bool(pose2rot)), pose.data_ptr(), joints.data_ptr(),
               _parents_i32(parents, dev).data_ptr(), 0, posed.data_ptr(), A.data_ptr(), pf.data_ptr(), stream)
     verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+    v_posed = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
     _lib.call("g4d_lbs_pose_skin_f32", B, V, J, PF, v_shaped.data_ptr(), pf.data_ptr(), posedirs.data_ptr(),
-              lbs_weights.data_ptr(), 0, A.data_ptr(), verts.data_ptr(), stream)
+              lbs_weights.data_ptr(), 0, A.data_ptr(), v_posed.data_ptr(), verts.data_ptr(), stream)
     return verts, posed

@@ -36,7 +36,8 @@ const char *g4d_last_error(void);
 /* furthest_point_sampling_kernel_launcher (sampling_gpu.h:24-27, sampling_gpu.cu:93-253).
  * xyz (B,N,3); temp (B,N) in/out scratch, caller fills 1e10 (pointnet2_utils.py:26), holds the
  * final min-distances on return; idx (B,M) int32 out.  idx[:,0] = 0.  Tie-break identical to the
- * reference's block-size-dependent tree reduction. */
+ * reference's block-size-dependent tree reduction.  Extension: temp may be NULL when 64 <= N <= 12800 (the
+ * register-resident kernels then start from 1e10 themselves and skip the write-back). */
 int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, g4d_stream_t stream);
 
 /* gather_points_kernel_launcher_fast (sampling_gpu.h:9-13): out[b,c,j] = points[b,c,idx[b,j]].
@@ -55,6 +56,14 @@ int g4d_gather_grad_f32(int b, int c, int n, int m, const float *grad_out, const
  * no hit are written as zeros (the reference leaves the caller's pre-zeroed row untouched). */
 int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                        int *idx, g4d_stream_t stream);
+
+/* Multi-scale ball query: the same queries against `nscales` (<= 4) radii in ONE pass over the cloud (each distance
+ * is evaluated once and compared with every radius) -- the MSG layers of the reference call ball_query once per scale
+ * (pointnet2_modules.py:37-38).  radii / nsamples / idx are HOST arrays of length nscales; idx[s] is a device
+ * (B,M,nsamples[s]) int32 buffer, fully written (no pre-zeroing needed).  Per-scale results identical to
+ * g4d_ball_query_f32. */
+int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                           const float *new_xyz, const float *xyz, int *const *idx, g4d_stream_t stream);
 
 /* group_points_kernel_launcher_fast (group_points_gpu.h:13-15): out[b,c,p,s] = points[b,c,idx[b,p,s]].
  * 64-bit offsets (the reference's int32 offsets wrap at 2^31 elements). */
@@ -111,6 +120,20 @@ int g4d_gcn_linear_f32(int frames, int vg, int fin, const float *X, int ldx, con
                        const float *vals, int Kpad, int Cout, const float *W, const float *scale, const float *shift,
                        int relu, float *out, int ldo, int col0, g4d_stream_t stream);
 
+/* A whole shared-MLP stack (1..4 layers, hidden widths <= 128) in one launch with the activations resident in LDS
+ * (garment4d_amd/csrc/mlp_stack.hip).  mode: 0 DIRECT (X, ldx) | 1 GROUP (N,P,S,C,use_xyz,xyz,new_xyz,feats,idx) |
+ * 2 INTERP (n,m,C2,C1,known_feats,skip,dist2,nn_idx) | 3 CSR (X,ldx,Vg,rowptr,colidx,vals); arguments of the other
+ * modes are ignored.  Layers are parallel HOST arrays of length nlayers (device pointers W/scale/shift packed as for
+ * g4d_linear_f32).  pool over S in {16,32,64} rows applies to the last layer.  tap_out (or NULL): hidden layer
+ * `tap_layer`'s output is also stored, rows x tap_ld. */
+int g4d_mlp_stack_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                      const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                      int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int Vg,
+                      const int *rowptr, const int *colidx, const float *vals, int nlayers, const float *const *W,
+                      const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
+                      const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out,
+                      int tap_ld, g4d_stream_t stream);
+
 /* max (is_max=1) / mean over S consecutive rows, any S: in (groups*S, ldi) -> out (groups, ldo) at col0. */
 int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0, int is_max,
                       g4d_stream_t stream);
@@ -148,10 +171,10 @@ int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *pose, const
 /* verts (B,V,3) = (W . A) [v_in + pose_feature . posedirs ; 1]     (lbs.py:223-246).  v_in (B,V,3);
  * pose_feature (B,PF), posedirs (PF, V*3) -- pass pf = 0 to skip the pose blend shapes (plain skinning, e.g. the
  * garment skinning of modules/mesh_encoder.py:393,406-408); weights (V,J), or (B,V,J) when weights_batched != 0;
- * A (B,J,4,4). */
+ * A (B,J,4,4); v_posed_scratch (B,V,3) receives v_posed when pf > 0 (may be NULL when pf == 0). */
 int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const float *pose_feature,
-                          const float *posedirs, const float *weights, int weights_batched, const float *A, float *verts,
-                          g4d_stream_t stream);
+                          const float *posedirs, const float *weights, int weights_batched, const float *A,
+                          float *v_posed_scratch, float *verts, g4d_stream_t stream);
 
 #ifdef __cplusplus
 }

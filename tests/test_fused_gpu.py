@@ -107,3 +107,21 @@ def test_transpose_roundtrip():
     pm = fused.to_point_major(x)
     assert torch.equal(pm, x.transpose(1, 2).contiguous())
     assert torch.equal(fused.to_channel_major(pm), x)
+
+
+@pytest.mark.parametrize("use_stack", [True, False])
+def test_stack_kernel_equals_per_layer_kernels(use_stack, monkeypatch):
+    """mlp_stack.hip (whole stack per launch) and mlp.hip (one launch per layer) against the op-by-op path on every
+    SA / FP / head shape of the cfg2 encoder (smaller clouds)."""
+    from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
+    monkeypatch.setattr(fused, "USE_STACK", use_stack)
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=True), seed=5).cuda().eval()
+    x = dev(syn.body_like_cloud(2, 3000, seed=11))
+    with torch.no_grad():
+        m0, lg0, f0, x0 = model(x)
+        m1, lg1, f1, x1 = model.forward_fused(x, channel_major=True)
+    close(m1, m0.cpu().numpy())
+    close(lg1, lg0.cpu().numpy())
+    for a, b in zip(f1[1:], f0[1:]):
+        close(a, b.cpu().numpy())
+    close(f1[0], f0[0].cpu().numpy())

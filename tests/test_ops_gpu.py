@@ -167,3 +167,30 @@ def test_empty_inputs():
     x = dev(syn.unit_cloud(1, 16, seed=1))
     q = torch.zeros((1, 0, 3), device="cuda")
     assert PU.ball_query(0.1, 4, x, q).shape == (1, 0, 4)
+
+
+@pytest.mark.parametrize("B,N,M,scales", [(2, 8192, 1024, [(0.05, 16), (0.1, 32)]), (3, 1000, 100, [(0.1, 16), (0.2, 32), (0.4, 64)]),
+                                          (1, 300, 37, [(0.05, 8), (0.3, 16), (0.1, 5), (2.0, 70)]), (2, 256, 64, [(0.2, 32)])])
+def test_ball_query_msg_equals_single_scale(B, N, M, scales):
+    from garment4d_amd import fused
+    xyz = syn.body_like_cloud(B, N, seed=N)
+    q = xyz[:, np.random.default_rng(M).permutation(N)[:M]].copy()
+    q[:, -1] = 9.0
+    outs = fused.ball_query_msg([r for r, _ in scales], [ns for _, ns in scales], dev(xyz), dev(q))
+    for (r, ns), o in zip(scales, outs):
+        assert np.array_equal(host(o), K.ball_query(r, ns, xyz, q))
+
+
+def test_fps_without_scratch():
+    """temp = NULL extension of g4d_fps_f32 (register-resident kernels)."""
+    from garment4d_amd import _lib
+    for n, m in [(8192, 1024), (1024, 256), (256, 64), (6890, 512), (100, 50)]:
+        xyz = syn.body_like_cloud(2, n, seed=n)
+        x = dev(xyz)
+        idx = torch.empty((2, m), dtype=torch.int32, device="cuda")
+        _lib.call("g4d_fps_f32", 2, n, m, x.data_ptr(), 0, idx.data_ptr(), _lib.stream_ptr())
+        assert np.array_equal(host(idx), K.fps(xyz, m))
+    x = dev(syn.unit_cloud(1, 20000, seed=1))
+    idx = torch.empty((1, 8), dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.G4DError):
+        _lib.call("g4d_fps_f32", 1, 20000, 8, x.data_ptr(), 0, idx.data_ptr(), _lib.stream_ptr())
