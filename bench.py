@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=8, help="independent batches in flight per GPU")
+    ap.add_argument("--streams", type=int, default=16, help="independent batches in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the workload the CPU oracle is timed on")

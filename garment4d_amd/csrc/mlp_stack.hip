@@ -9,13 +9,15 @@
 //            tile into LDS buffer 0 -- all global loads of the tile are in flight at once;
 //   layer l  A fragments come from the input buffer (ds_read_b128), W fragments straight from global memory
 //            (weights are a few hundred KB, L2-resident, each lane reads 16 contiguous bytes of its row),
-//            4 waves x 4 accumulator tiles of v_mfma_f32_16x16x4_f32 per 64-channel slab; the epilogue applies the
+//            8 waves (4 channel slices x 2 row halves) x 2 accumulator tiles of v_mfma_f32_16x16x4_f32 per 64-channel
+//            slab -- the activation buffers bound occupancy (1-4 workgroups per CU), so latency is hidden by waves
+//            per workgroup rather than workgroups per CU; the epilogue applies the
 //            folded BN affine + ReLU and scatters into the other LDS buffer (ping-pong), or -- last layer -- pools
 //            over the S samples in-wave and writes point-major output at a column offset;
 //   one barrier per layer (plus one per extra 64-channel slab), none per K chunk.
 //
-// Hidden widths <= 128 (buffers are [64][ld] fp32, ld = width rounded to 64, +4 to spread ds_read_b128 over the
-// banks).  Waves whose 16-channel slice lies beyond Cout skip their MFMAs (narrow layers leave the matrix pipe to
+// Buffers are [64][ld] fp32 with ld = widest Kpad read from them + 4 (spreads ds_read_b128 over the banks); a
+// hidden layer only writes the columns its successor reads.  Waves whose 16-channel slice lies beyond Cout skip their MFMAs (narrow layers leave the matrix pipe to
 // the other resident workgroups).  An optional tap writes one hidden layer to HBM as well (FP1 features feed the
 // head AND are returned to the caller).
 #include "mlp_common.h"
@@ -40,21 +42,23 @@ struct StackArgs {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__(256) mlp_stack_kernel(const StackArgs s) {
+__global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *buf0 = smem;
     float *buf1 = smem + 64 * s.ld0;
     const LinearArgs &a = s.in;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cs = wave & 3;   // 16-channel slice of the 64-channel slab
+    const int rh = wave >> 2;  // row half: rows [32 rh, 32 rh + 32) = accumulator tiles 2 rh, 2 rh + 1
     const int row0 = blockIdx.x * 64;
     const int fi = lane & 15, fq = lane >> 4;
 
     // ---- phase 0: gather the input tile [64][K0pad] into buf0 (zeros beyond K and beyond the last row)
     {
-        const int lr = t >> 2;  // 4 threads per row
+        const int lr = t >> 3;  // 8 threads per row
         const RowCtx<MODE> ctx = make_ctx<MODE>(a, row0 + lr);
         const int K0pad = s.layer[0].Kpad;
-        for (int k = (t & 3) * 4; k < K0pad; k += 16) {
+        for (int k = (t & 7) * 4; k < K0pad; k += 32) {
             f32x4 v;
             if (MODE == LOAD_DIRECT && ctx.valid && k + 3 < a.K && (a.ldx & 3) == 0) {
                 v = *reinterpret_cast<const f32x4 *>(a.X + (size_t)(row0 + lr) * a.ldx + k);
@@ -67,6 +71,8 @@ __global__ void __launch_bounds__(256) mlp_stack_kernel(const StackArgs s) {
             *reinterpret_cast<f32x4 *>(&buf0[lr * s.ld0 + k]) = v;
         }
     }
+    // first W fragment of the first job: in flight across the gather barrier
+    f32x4 bnext = *reinterpret_cast<const f32x4 *>(s.layer[0].W + (size_t)(cs * 16 + fi) * s.layer[0].Kpad + fq * 4);
     __syncthreads();
 
     for (int l = 0; l < s.nlayers; ++l) {
@@ -75,33 +81,43 @@ __global__ void __launch_bounds__(256) mlp_stack_kernel(const StackArgs s) {
         float *out = (l & 1) ? buf0 : buf1;
         const int ldin = (l & 1) ? s.ld1 : s.ld0, ldout = (l & 1) ? s.ld0 : s.ld1;
         const bool last = l == s.nlayers - 1;
-        const int nslab = (L.Cout + 63) >> 6;
+        // a hidden layer only has to produce the columns the next layer reads (its Kpad; zeros beyond Cout)
+        const int wcols = last ? L.Cout : s.layer[l + 1].Kpad;
+        const int nslab = (wcols + 63) >> 6;
         for (int sl = 0; sl < nslab; ++sl) {
-            const int ch = sl * 64 + wave * 16 + fi;
-            const bool wave_live = sl * 64 + wave * 16 < L.Cout;  // wave-uniform
-            f32x4 acc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int ch = sl * 64 + cs * 16 + fi;
+            const bool wave_live = sl * 64 + cs * 16 < L.Cout;   // wave-uniform: has real channels
+            const bool wave_writes = sl * 64 + cs * 16 < wcols;  // wave-uniform: columns somebody reads
+            f32x4 acc[2];
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 bf = bnext;
             if (wave_live) {
                 const float *wp = L.W + (size_t)ch * L.Kpad + fq * 4;
-                const float *ap = in + fi * ldin + fq * 4;
-                f32x4 bf = *reinterpret_cast<const f32x4 *>(wp);
+                const float *ap = in + (rh * 32 + fi) * ldin + fq * 4;
                 for (int kk = 0; kk < L.Kpad; kk += 16) {
                     const f32x4 bcur = bf;
-                    if (kk + 16 < L.Kpad) bf = *reinterpret_cast<const f32x4 *>(wp + kk + 16);  // prefetch next W fragment
-                    f32x4 af[4];
+                    if (kk + 16 < L.Kpad) bf = *reinterpret_cast<const f32x4 *>(wp + kk + 16);  // next W fragment, ahead of the MFMAs
+                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + kk);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ap + 16 * ldin + kk);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(ap + mt * 16 * ldin + kk);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bcur[e], acc[mt], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], bcur[e], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], bcur[e], acc[1], 0, 0, 0);
+                    }
+                }
+            }
+            {   // first W fragment of the NEXT job (next slab, or slab 0 of the next layer): issued before the epilogue
+                int nl = l, nsl = sl + 1;
+                if (nsl >= nslab) { nl = l + 1; nsl = 0; }
+                if (nl < s.nlayers) {
+                    const StackLayer &NL = s.layer[nl];
+                    bnext = *reinterpret_cast<const f32x4 *>(NL.W + (size_t)(nsl * 64 + cs * 16 + fi) * NL.Kpad + fq * 4);
                 }
             }
             const float sc = L.scale[ch], sh = L.shift[ch];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float y = acc[mt][r] * sc + sh;
@@ -111,36 +127,38 @@ __global__ void __launch_bounds__(256) mlp_stack_kernel(const StackArgs s) {
             if (!last) {
                 // hidden layer: scatter into the other LDS buffer (channels beyond Cout come out as exact zeros:
                 // W rows, scale and shift are zero padded), optionally tap to HBM
+                if (wave_writes) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) out[(mt * 16 + fq * 4 + r) * ldout + ch] = acc[mt][r];
+                        for (int r = 0; r < 4; ++r) out[(rh * 32 + mt * 16 + fq * 4 + r) * ldout + ch] = acc[mt][r];
+                }
                 if (l == s.tap_layer && ch < L.Cout) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int row = row0 + mt * 16 + fq * 4 + r;
+                            const int row = row0 + rh * 32 + mt * 16 + fq * 4 + r;
                             if (row < a.rows) s.tap_out[(size_t)row * s.tap_ld + ch] = acc[mt][r];
                         }
                 }
                 continue;
             }
-            // ---- last layer: (pool and) store to HBM, same epilogue as mlp.hip
+            // ---- last layer: (pool and) store to HBM
             const bool ch_ok = ch < L.Cout;
             if (a.pool == 0) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = row0 + mt * 16 + fq * 4 + r;
+                        const int row = row0 + rh * 32 + mt * 16 + fq * 4 + r;
                         if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = acc[mt][r];
                     }
             } else {
                 const bool is_max = a.pool == 1;
-                float v[4];
+                float v[2];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < 2; ++mt) {
                     float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
                                      : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
                     const float y = __shfl_xor(x, 16);
@@ -149,18 +167,30 @@ __global__ void __launch_bounds__(256) mlp_stack_kernel(const StackArgs s) {
                     x = is_max ? fmaxf(x, z) : x + z;
                     v[mt] = x;
                 }
-                const int groups = 64 / a.S;
-                if (groups == 2) {
-                    v[0] = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];
-                    v[1] = is_max ? fmaxf(v[2], v[3]) : v[2] + v[3];
-                } else if (groups == 1) {
-                    v[0] = is_max ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : ((v[0] + v[1]) + (v[2] + v[3]));
-                }
-                if (lane < 16 && ch_ok) {
-                    const float inv = is_max ? 1.f : 1.f / (float)a.S;
-                    for (int g = 0; g < groups; ++g) {
-                        const int orow = (row0 / a.S) + g;
-                        if (orow * a.S < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = v[g] * inv;
+                const float inv = is_max ? 1.f : 1.f / (float)a.S;
+                if (a.S == 16) {  // one neighbourhood per accumulator tile
+                    if (lane < 16 && ch_ok) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const int orow = (row0 >> 4) + rh * 2 + mt;
+                            if (orow * 16 < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = v[mt] * inv;
+                        }
+                    }
+                } else {
+                    float x = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];  // this wave's 32 rows
+                    if (a.S == 32) {
+                        const int orow = (row0 >> 5) + rh;
+                        if (lane < 16 && ch_ok && orow * 32 < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = x * inv;
+                    } else {  // S == 64: the two row halves meet in LDS (`out` is free during the last layer)
+                        if (rh == 1 && lane < 16) out[cs * 16 + lane] = x;
+                        __syncthreads();
+                        if (rh == 0 && lane < 16) {
+                            const float y = out[cs * 16 + lane];
+                            x = is_max ? fmaxf(x, y) : x + y;
+                            const int orow = row0 >> 6;
+                            if (ch_ok && orow * 64 < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = x * inv;
+                        }
+                        __syncthreads();
                     }
                 }
             }
@@ -200,7 +230,7 @@ extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
     s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
     s.in.rowptr = rowptr; s.in.colidx = colidx; s.in.vals = vals; s.in.Vg = Vg;
     s.nlayers = nlayers;
-    int w0 = 0, w1 = 0;  // widths (floats) buffer 0 / 1 must hold
+    int w0 = 0, w1 = 0;  // widths (floats) buffer 0 / 1 must hold: layer l reads Kpad[l] columns of buffer l&1
     for (int l = 0; l < nlayers; ++l) {
         G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 32 == 0 && Cout[l] > 0, "g4d_mlp_stack_f32: bad layer %d", l);
         s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
@@ -208,22 +238,20 @@ extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
         int &win = (l & 1) ? w1 : w0;
         win = win > Kpad[l] ? win : Kpad[l];
         if (l > 0) {
-            const int prev_pad64 = (Cout[l - 1] + 63) / 64 * 64;
+            const int prev_pad64 = (Cout[l - 1] + 63) / 64 * 64;  // packed W/scale/shift rows of layer l-1 exist up to here
             G4D_REQUIRE(Kpad[l] <= prev_pad64 && Kpad[l] >= Cout[l - 1], "g4d_mlp_stack_f32: layer %d K does not chain", l);
-            win = win > prev_pad64 ? win : prev_pad64;
         }
     }
     G4D_REQUIRE(Kpad[0] >= K0, "g4d_mlp_stack_f32: Kpad[0] < K0");
-    if (nlayers > 1 && w1 == 0) w1 = 64;
     s.ld0 = w0 + 4;
-    s.ld1 = (w1 > 0 ? w1 : 0) + 4;
+    s.ld1 = w1 + 4;
     const size_t lds = sizeof(float) * 64 * (size_t)(s.ld0 + s.ld1);
     G4D_REQUIRE(lds <= 150 * 1024, "g4d_mlp_stack_f32: stack too wide for LDS (%zu bytes)", lds);
     s.tap_layer = tap_out ? tap_layer : -1;
     s.tap_out = tap_out; s.tap_ld = tap_ld;
     G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_stack_f32: tap must be a hidden layer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    dim3 grid((unsigned)((rows + 63) / 64)), block(512);
 #define G4D_LAUNCH_STACK(M)                                                                                        \
     {                                                                                                              \
         static bool attr = false;                                                                                  \

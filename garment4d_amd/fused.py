@@ -142,10 +142,6 @@ def stack_fits(layers, pool, S):
     w = [0, 0]
     for l, L in enumerate(layers):
         w[l & 1] = max(w[l & 1], L.Kpad)
-        if l > 0:
-            w[l & 1] = max(w[l & 1], (layers[l - 1].Cout + 63) // 64 * 64)
-    if any(L.Cout > 128 for L in layers[:-1]):
-        return False
     return 4 * 64 * (w[0] + 4 + w[1] + 4) <= _MAX_STACK_LDS
 
 
