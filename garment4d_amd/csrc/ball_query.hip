@@ -1,101 +1,48 @@
 // Ball query for gfx950 -- replaces ball_query_kernel_fast / ball_query_kernel_launcher_fast
-// (/root/reference/modules/pointnet2/pointnet2/src/ball_query_gpu.cu:9-67).
+// (/root/reference/modules/pointnet2/pointnet2/src/ball_query_gpu.cu:9-67), single- and multi-scale.
 //
 // Semantics kept: for query q, hits = ascending k with d2 = (qx-x)^2 + (qy-y)^2 + (qz-z)^2 < r*r
 // (fp32, left-to-right, no fma; r*r rounded once in fp32); out = first `nsample` hits, remaining slots
 // = first hit, all 0 when there is no hit.
 //
-// Layout for the hardware (the reference runs one THREAD per query, each scanning N points serially
-// with broadcast loads and a divergent early exit):
-//   * one WAVE owns QW queries; its 64 lanes test 64 consecutive points per step, so the cloud is read
-//     coalesced (768 B per wave-step) and each loaded point is reused for QW queries whose centres sit
-//     in SGPRs (wave-uniform) -> 9 VALU per 64 point-query pairs, L2->CU traffic cut QW x;
-//   * ascending-index order falls out of ballot + mbcnt prefix (slot = cnt + #hits in lower lanes);
-//   * the hit path is scalar-branched and rare (a radius-0.1 ball holds ~0.4 % of a unit cloud);
-//   * early exit once all QW queries are full.
-// Algorithmic bytes: 12*B*(N+M) + 4*B*M*nsample; B*M*N distance evaluations worst case.
+// Layout for the hardware (the reference runs one THREAD per query, each scanning N points serially with
+// broadcast loads and a divergent early exit, one launch per radius):
+//   * one WAVE owns QW queries; its 64 lanes test 64 consecutive points per step, each point reused for the QW
+//     queries (centres in SGPRs) and for all NS radii of a multi-scale layer (one distance, NS compares);
+//   * a workgroup (4 waves = 4*QW queries) streams the cloud through LDS in 1024-point SoA stages: stage s+1 is
+//     loaded into registers while stage s is consumed, so the L2 stream is shared by the 4 waves and its
+//     latency sits behind 16 steps of VALU work (the first version re-loaded every 64-point step per wave from L2
+//     with nothing in flight: 65 us per radius at B=8, N=8192, M=1024);
+//   * ascending-index order falls out of ballot + mbcnt prefix (slot = cnt + #hits in lower lanes); the hit path
+//     is scalar-branched and rare (a radius-0.1 ball holds ~0.4 % of a unit cloud);
+//   * a wave stops testing once its queries are full; the workgroup leaves when all four are.
+// Algorithmic bytes: 12*B*(N+M) + 4*B*M*sum(nsample); B*M*N distance evaluations worst case.
 #include "g4d_common.h"
 
 namespace g4d {
 
-template <int QW>
-__global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, float radius2, int nsample,
-                                                        const float *__restrict__ new_xyz_all,
-                                                        const float *__restrict__ xyz_all, int *__restrict__ idx_all) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * QW;
-    if (q0 >= m) return;
-    const float *xyz = xyz_all + (size_t)b * n * 3;
-    const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
-    int *idx = idx_all + ((size_t)b * m + q0) * nsample;
-
-    float qx[QW], qy[QW], qz[QW];
-    int cnt[QW], first[QW];
-    int open = 0;  // queries still collecting
-#pragma unroll
-    for (int i = 0; i < QW; ++i) {
-        const int q = min(q0 + i, m - 1);
-        qx[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 0])));
-        qy[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 1])));
-        qz[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 2])));
-        cnt[i] = (q0 + i < m) ? 0 : nsample;  // out-of-range query slots start "full"
-        first[i] = 0;
-        open += (q0 + i < m) ? 1 : 0;
-    }
-
-    for (int base = 0; base < n && open > 0; base += 64) {
-        const int k = base + lane;
-        const bool valid = k < n;
-        const int kc = valid ? k : n - 1;
-        const float x = xyz[kc * 3 + 0], y = xyz[kc * 3 + 1], z = xyz[kc * 3 + 2];
-#pragma unroll
-        for (int i = 0; i < QW; ++i) {
-            if (cnt[i] < nsample) {  // wave-uniform
-                const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                const bool hit = valid && (d2 < radius2);
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                if (mask != 0ull) {  // wave-uniform, rare
-                    if (cnt[i] == 0) first[i] = base + __builtin_ctzll(mask);
-                    const int slot = cnt[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit && slot < nsample) idx[(size_t)i * nsample + slot] = k;
-                    cnt[i] += __builtin_popcountll(mask);
-                    if (cnt[i] >= nsample) --open;
-                }
-            }
-        }
-    }
-    // pad with the first hit (ball_query_gpu.cu:32-36); rows without a hit are zeros
-#pragma unroll
-    for (int i = 0; i < QW; ++i) {
-        if (q0 + i < m && cnt[i] < nsample) {
-            for (int l = cnt[i] + lane; l < nsample; l += 64) idx[(size_t)i * nsample + l] = first[i];
-        }
-    }
-}
-
-// Multi-scale variant: NS radii per query, one distance evaluation per (query, point) pair.
-struct MsgArgs {
+struct BqArgs {
     float radius2[4];
     int nsample[4];
     int *idx[4];
 };
 
+constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered
+
 template <int QW, int NS>
-__global__ void __launch_bounds__(256) ball_query_msg_kernel(int n, int m, const MsgArgs a, const float *__restrict__ new_xyz_all,
-                                                            const float *__restrict__ xyz_all) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+__global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
+                                                        const float *__restrict__ xyz_all) {
+    __shared__ float sp[2][3][kStage];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int b = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * QW;
-    if (q0 >= m) return;
     const float *xyz = xyz_all + (size_t)b * n * 3;
     const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
+
     float qx[QW], qy[QW], qz[QW];
     int cnt[QW][NS], first[QW][NS];
-    int open = 0;
+    int open = 0;  // (query, scale) pairs still collecting
 #pragma unroll
     for (int i = 0; i < QW; ++i) {
         const int q = min(q0 + i, m - 1);
@@ -104,42 +51,80 @@ __global__ void __launch_bounds__(256) ball_query_msg_kernel(int n, int m, const
         qz[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 2])));
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            cnt[i][s] = (q0 + i < m) ? 0 : a.nsample[s];
+            cnt[i][s] = (q0 + i < m) ? 0 : a.nsample[s];  // out-of-range query slots start "full"
             first[i][s] = 0;
             open += (q0 + i < m) ? 1 : 0;
         }
     }
-    for (int base = 0; base < n && open > 0; base += 64) {
-        const int k = base + lane;
-        const bool valid = k < n;
-        const int kc = valid ? k : n - 1;
-        const float x = xyz[kc * 3 + 0], y = xyz[kc * 3 + 1], z = xyz[kc * 3 + 2];
+
+    // stage loader: thread t owns points t, t+256, t+512, t+768 of a stage (coalesced 12-byte records)
+    float rx[4], ry[4], rz[4];
+    auto load_stage = [&](int base) {
 #pragma unroll
-        for (int i = 0; i < QW; ++i) {
-            const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
+        for (int j = 0; j < 4; ++j) {
+            const int k = base + t + j * 256;
+            const int kc = k < n ? k : n - 1;
+            rx[j] = xyz[kc * 3 + 0]; ry[j] = xyz[kc * 3 + 1]; rz[j] = xyz[kc * 3 + 2];
+        }
+    };
+    auto store_stage = [&](int buf) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
-                    const bool hit = valid && (d2 < a.radius2[s]);
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    if (mask != 0ull) {
-                        if (cnt[i][s] == 0) first[i][s] = base + __builtin_ctzll(mask);
-                        const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
-                        cnt[i][s] += __builtin_popcountll(mask);
-                        if (cnt[i][s] >= a.nsample[s]) --open;
+        for (int j = 0; j < 4; ++j) {
+            sp[buf][0][t + j * 256] = rx[j]; sp[buf][1][t + j * 256] = ry[j]; sp[buf][2][t + j * 256] = rz[j];
+        }
+    };
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int base = 0; base < n; base += kStage) {
+        const bool more = base + kStage < n;
+        if (more) load_stage(base + kStage);  // in flight while this stage is consumed
+        const int cn = min(kStage, n - base);
+        for (int c = 0; c < cn && open > 0; c += 64) {
+            const int k = base + c + lane;
+            const bool valid = c + lane < cn;
+            const float x = sp[buf][0][c + lane], y = sp[buf][1][c + lane], z = sp[buf][2][c + lane];
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
+                        const bool hit = valid && (d2 < a.radius2[s]);
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                        if (mask != 0ull) {  // wave-uniform, rare
+                            if (cnt[i][s] == 0) first[i][s] = base + c + __builtin_ctzll(mask);
+                            const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
+                            cnt[i][s] += __builtin_popcountll(mask);
+                            if (cnt[i][s] >= a.nsample[s]) --open;
+                        }
                     }
                 }
             }
         }
+        if (!more) break;
+        if (__syncthreads_or(open > 0) == 0) break;  // everybody done: skip the rest of the cloud (also the WAR barrier)
+        store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
+    // pad with the first hit (ball_query_gpu.cu:32-36); rows without a hit are zeros
 #pragma unroll
     for (int i = 0; i < QW; ++i)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
             if (q0 + i < m && cnt[i][s] < a.nsample[s])
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
+}
+
+template <int NS>
+static void launch_bq(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz) {
+    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
+    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
+    else hipLaunchKernelGGL((ball_query_kernel<1, NS>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
 }
 
 }  // namespace g4d
@@ -149,14 +134,13 @@ extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const fl
     using namespace g4d;
     G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nscales >= 1 && nscales <= 4 && b <= 65535, "g4d_ball_query_msg_f32: bad sizes");
     G4D_REQUIRE(radii && nsamples && idx, "g4d_ball_query_msg_f32: null pointer");
-    if (nscales == 1) return g4d_ball_query_f32(b, n, m, radii[0], nsamples[0], new_xyz, xyz, idx[0], stream);
     if (b == 0 || m == 0) return G4D_OK;
     G4D_REQUIRE(new_xyz && xyz, "g4d_ball_query_msg_f32: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MsgArgs a = {};
+    BqArgs a = {};
     for (int s = 0; s < nscales; ++s) {
         G4D_REQUIRE(nsamples[s] > 0 && idx[s], "g4d_ball_query_msg_f32: bad scale %d", s);
-        a.radius2[s] = radii[s] * radii[s];
+        a.radius2[s] = radii[s] * radii[s];  // ball_query_gpu.cu:23, rounded once in fp32
         a.nsample[s] = nsamples[s];
         a.idx[s] = idx[s];
         if (n == 0) {
@@ -165,15 +149,17 @@ extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const fl
         }
     }
     if (n == 0) return G4D_OK;
+    // queries per wave: keep >= ~2048 waves in the launch when the problem allows
     const long long queries = (long long)b * m;
     int qw = 4;
     while (qw > 1 && queries / qw < 2048) qw >>= 1;
-    dim3 grid((m + 4 * qw - 1) / (4 * qw), b), block(256);
-#define G4D_BQ(QW, NS) hipLaunchKernelGGL((ball_query_msg_kernel<QW, NS>), grid, block, 0, st, n, m, a, new_xyz, xyz)
-    if (nscales == 2) { if (qw == 4) G4D_BQ(4, 2); else if (qw == 2) G4D_BQ(2, 2); else G4D_BQ(1, 2); }
-    else if (nscales == 3) { if (qw == 4) G4D_BQ(4, 3); else if (qw == 2) G4D_BQ(2, 3); else G4D_BQ(1, 3); }
-    else { if (qw == 4) G4D_BQ(4, 4); else if (qw == 2) G4D_BQ(2, 4); else G4D_BQ(1, 4); }
-#undef G4D_BQ
+    dim3 grid((m + 4 * qw - 1) / (4 * qw), b);
+    switch (nscales) {
+        case 1: launch_bq<1>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        case 2: launch_bq<2>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        case 3: launch_bq<3>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        default: launch_bq<4>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+    }
     return check_launch("g4d_ball_query_msg_f32");
 }
 
@@ -183,21 +169,6 @@ extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample
     G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 0, "g4d_ball_query_f32: negative size");
     if (b == 0 || m == 0 || nsample == 0) return G4D_OK;
     G4D_REQUIRE(new_xyz && xyz && idx, "g4d_ball_query_f32: null pointer");
-    G4D_REQUIRE(b <= 65535, "g4d_ball_query_f32: b > 65535 not supported");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n == 0) return (int)hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * m * nsample, s);
-    const float radius2 = radius * radius;  // ball_query_gpu.cu:23, rounded once in fp32
-    // pick queries-per-wave so the launch still has >= ~2048 waves when the problem allows
-    const long long queries = (long long)b * m;
-    int qw = 8;
-    while (qw > 1 && queries / qw < 2048) qw >>= 1;
-    const int per_block = 4 * qw;
-    dim3 grid((m + per_block - 1) / per_block, b), block(256);
-    switch (qw) {
-        case 8: hipLaunchKernelGGL(ball_query_kernel<8>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
-        case 4: hipLaunchKernelGGL(ball_query_kernel<4>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
-        case 2: hipLaunchKernelGGL(ball_query_kernel<2>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
-        default: hipLaunchKernelGGL(ball_query_kernel<1>, grid, block, 0, s, n, m, radius2, nsample, new_xyz, xyz, idx); break;
-    }
-    return check_launch("g4d_ball_query_f32");
+    int *ip[1] = {idx};
+    return g4d_ball_query_msg_f32(b, n, m, 1, &radius, &nsample, new_xyz, xyz, ip, stream);
 }

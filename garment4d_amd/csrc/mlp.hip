@@ -25,7 +25,7 @@
 
 namespace g4d {
 
-constexpr int BM = 64, BN = 64, KC = 32, LDT = KC + 4;  // LDS row stride in floats
+constexpr int BN = 64, KC = 32, LDT = KC + 4;  // LDS row stride in floats
 
 template <int MODE>
 __device__ __forceinline__ f32x4 load4(const LinearArgs &a, const RowCtx<MODE> &c, int row, int k) {
@@ -41,8 +41,11 @@ __device__ __forceinline__ f32x4 load4(const LinearArgs &a, const RowCtx<MODE> &
     return v;
 }
 
-template <int MODE>
+// MT = accumulator tiles per wave: block tile = (16*MT) rows x 64 channels.  MT=4 for big row counts, MT=2 when the
+// launch would otherwise leave CUs idle (few rows, wide layers: the FP levels).
+template <int MODE, int MT>
 __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
+    constexpr int BM = 16 * MT;
     __shared__ __attribute__((aligned(16))) float sA[2][BM * LDT];
     __shared__ __attribute__((aligned(16))) float sB[2][BN * LDT];
     const int t = threadIdx.x;
@@ -52,19 +55,21 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
 
     // staging map: thread -> (tile row lr + 32*pass, 4 consecutive k at lk)
     const int lr = t >> 3, lk = (t & 7) * 4;
-    RowCtx<MODE> ctx0 = make_ctx<MODE>(a, row0 + lr), ctx1 = make_ctx<MODE>(a, row0 + lr + 32);
+    constexpr bool TWO = BM == 64;  // a second pass of 32 A rows
+    RowCtx<MODE> ctx0 = make_ctx<MODE>(a, row0 + lr), ctx1 = make_ctx<MODE>(a, TWO ? row0 + lr + 32 : a.rows);
     const float *wrow0 = a.W + (size_t)(n0 + lr) * a.Kpad + lk;
     const float *wrow1 = a.W + (size_t)(n0 + lr + 32) * a.Kpad + lk;
 
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nchunk = a.Kpad / KC;  // Kpad is a multiple of 32
-    f32x4 ra0 = load4<MODE>(a, ctx0, row0 + lr, lk), ra1 = load4<MODE>(a, ctx1, row0 + lr + 32, lk);
+    f32x4 ra0 = load4<MODE>(a, ctx0, row0 + lr, lk), ra1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (TWO) ra1 = load4<MODE>(a, ctx1, row0 + lr + 32, lk);
     f32x4 rb0 = *reinterpret_cast<const f32x4 *>(wrow0), rb1 = *reinterpret_cast<const f32x4 *>(wrow1);
     *reinterpret_cast<f32x4 *>(&sA[0][lr * LDT + lk]) = ra0;
-    *reinterpret_cast<f32x4 *>(&sA[0][(lr + 32) * LDT + lk]) = ra1;
+    if (TWO) *reinterpret_cast<f32x4 *>(&sA[0][(lr + 32) * LDT + lk]) = ra1;
     *reinterpret_cast<f32x4 *>(&sB[0][lr * LDT + lk]) = rb0;
     *reinterpret_cast<f32x4 *>(&sB[0][(lr + 32) * LDT + lk]) = rb1;
     __syncthreads();
@@ -76,28 +81,28 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
         if (more) {
             const int k = (c + 1) * KC + lk;
             ra0 = load4<MODE>(a, ctx0, row0 + lr, k);
-            ra1 = load4<MODE>(a, ctx1, row0 + lr + 32, k);
+            if (TWO) ra1 = load4<MODE>(a, ctx1, row0 + lr + 32, k);
             rb0 = *reinterpret_cast<const f32x4 *>(wrow0 + (c + 1) * KC);
             rb1 = *reinterpret_cast<const f32x4 *>(wrow1 + (c + 1) * KC);
         }
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 16) {
             const f32x4 bf = *reinterpret_cast<const f32x4 *>(&sB[cur][(wave * 16 + fi) * LDT + kk + fq * 4]);
-            f32x4 af[4];
+            f32x4 af[MT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
                 af[mt] = *reinterpret_cast<const f32x4 *>(&sA[cur][(mt * 16 + fi) * LDT + kk + fq * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bf[e], acc[mt], 0, 0, 0);
             }
         }
         if (more) {
             const int nxt = cur ^ 1;
             *reinterpret_cast<f32x4 *>(&sA[nxt][lr * LDT + lk]) = ra0;
-            *reinterpret_cast<f32x4 *>(&sA[nxt][(lr + 32) * LDT + lk]) = ra1;
+            if (TWO) *reinterpret_cast<f32x4 *>(&sA[nxt][(lr + 32) * LDT + lk]) = ra1;
             *reinterpret_cast<f32x4 *>(&sB[nxt][lr * LDT + lk]) = rb0;
             *reinterpret_cast<f32x4 *>(&sB[nxt][(lr + 32) * LDT + lk]) = rb1;
         }
@@ -108,7 +113,7 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
     const int ch = n0 + wave * 16 + fi;
     const float sc = a.scale[ch], sh = a.shift[ch];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float y = acc[mt][r] * sc + sh;
@@ -118,7 +123,7 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
     const bool ch_ok = ch < a.Cout;
     if (a.pool == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + mt * 16 + fq * 4 + r;
@@ -126,7 +131,8 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
             }
         return;
     }
-    // pooled: S in {16,32,64}; rows of one neighbourhood are consecutive and tile-aligned (64 % S == 0)
+    // pooled: S in {16,32,64}; rows of one neighbourhood are consecutive and tile-aligned (64 % S == 0); MT == 4 only
+    if constexpr (MT == 4) {
     const bool is_max = a.pool == 1;
     float v[4];
 #pragma unroll
@@ -153,6 +159,7 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
             const int orow = (row0 / a.S) + g;
             if (orow * a.S < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = v[g] * inv;
         }
+    }
     }
 }
 
@@ -187,12 +194,26 @@ __global__ void __launch_bounds__(256) transpose_kernel(int R, int Cc, const flo
 }
 
 static int launch_linear(int mode, const LinearArgs &a, hipStream_t s) {
-    dim3 grid((a.rows + BM - 1) / BM, (a.Cout + BN - 1) / BN), block(256);
-    switch (mode) {
-        case LOAD_DIRECT: hipLaunchKernelGGL(linear_kernel<LOAD_DIRECT>, grid, block, 0, s, a); break;
-        case LOAD_GROUP: hipLaunchKernelGGL(linear_kernel<LOAD_GROUP>, grid, block, 0, s, a); break;
-        case LOAD_INTERP: hipLaunchKernelGGL(linear_kernel<LOAD_INTERP>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(linear_kernel<LOAD_CSR>, grid, block, 0, s, a); break;
+    const int nb = (a.Cout + BN - 1) / BN;
+    // 32-row tiles when 64-row tiles would not even give two workgroups per CU (and no fused pooling is asked for)
+    const bool small = a.pool == 0 && (long long)((a.rows + 63) / 64) * nb < 2 * 256;
+    dim3 block(256);
+    if (small) {
+        dim3 grid((a.rows + 31) / 32, nb);
+        switch (mode) {
+            case LOAD_DIRECT: hipLaunchKernelGGL((linear_kernel<LOAD_DIRECT, 2>), grid, block, 0, s, a); break;
+            case LOAD_GROUP: hipLaunchKernelGGL((linear_kernel<LOAD_GROUP, 2>), grid, block, 0, s, a); break;
+            case LOAD_INTERP: hipLaunchKernelGGL((linear_kernel<LOAD_INTERP, 2>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((linear_kernel<LOAD_CSR, 2>), grid, block, 0, s, a); break;
+        }
+    } else {
+        dim3 grid((a.rows + 63) / 64, nb);
+        switch (mode) {
+            case LOAD_DIRECT: hipLaunchKernelGGL((linear_kernel<LOAD_DIRECT, 4>), grid, block, 0, s, a); break;
+            case LOAD_GROUP: hipLaunchKernelGGL((linear_kernel<LOAD_GROUP, 4>), grid, block, 0, s, a); break;
+            case LOAD_INTERP: hipLaunchKernelGGL((linear_kernel<LOAD_INTERP, 4>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((linear_kernel<LOAD_CSR, 4>), grid, block, 0, s, a); break;
+        }
     }
     return check_launch("g4d_linear");
 }

@@ -13,6 +13,8 @@ layout -- are produced only at the API boundary (`to_channel_major`).  Torch is 
 parameter packing only; every FLOP of the forward runs in libg4d_hip.so.  Train-mode BatchNorm needs batch
 statistics over the grouped tensor and stays on the op-by-op path (pointnet2_modules.py).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +23,7 @@ from . import pointnet2_utils as PU
 
 _KC = 32
 _BN = 64
+USE_WAVE = os.environ.get("G4D_MLP_WAVE", "1") != "0"  # wave-autonomous kernel for narrow stacks (csrc/mlp_wave.hip)
 USE_STACK = True  # whole-stack fusion (csrc/mlp_stack.hip); False = one launch per layer (csrc/mlp.hip)
 
 
@@ -145,6 +148,15 @@ def stack_fits(layers, pool, S):
     return 4 * 64 * (w[0] + 4 + w[1] + 4) <= _MAX_STACK_LDS
 
 
+def wave_fits(layers, pool, S):
+    """Narrow stack (every hidden width <= 64): eligible for the wave-autonomous kernel (csrc/mlp_wave.hip)."""
+    if not USE_WAVE or not (1 <= len(layers) <= 4) or (pool and S not in (16, 32, 64)):
+        return False
+    # measured: wins for xyz-only first levels (K0 <= 32); with wide gathered inputs the workgroup-cooperative
+    # stack kernel is faster (its whole-tile gather keeps more loads in flight)
+    return layers[0].Kpad == 32 and all(L.Cout <= 64 for L in layers[:-1]) and all(L.Kpad <= 64 for L in layers[1:])
+
+
 def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, group=None, interp=None, csr=None, tap=None):
     """One launch for the whole stack.  group = (N,P,C,use_xyz,xyz,new_xyz,feats,idx); interp = (n,m,C2,C1,known,skip,
     dist2,nn_idx); csr = (Vg,rowptr,colidx,vals); tap = (layer_index, tensor2d)."""
@@ -170,6 +182,12 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
         cV, rowptr, colidx, vals = csr
         cr, cc, cv = rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr()
     tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
+    if tap is None and wave_fits(layers, pool, S):
+        _lib.call("g4d_mlp_wave_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
+                  idd, ii, cV, cr, cc, cv, n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
+                  ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
+                  ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, _lib.stream_ptr())
+        return out
     _lib.call("g4d_mlp_stack_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
               idd, ii, cV, cr, cc, cv, n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
               ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),

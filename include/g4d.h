@@ -134,6 +134,15 @@ int g4d_mlp_stack_f32(int mode, long long rows, int K0, const float *X, int ldx,
                       const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out,
                       int tap_ld, g4d_stream_t stream);
 
+/* Wave-autonomous variant of g4d_mlp_stack_f32 for narrow stacks (every hidden width <= 64): each wave takes 64 rows
+ * through all layers with no workgroup barrier (garment4d_amd/csrc/mlp_wave.hip).  Same arguments, no tap. */
+int g4d_mlp_wave_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                     const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                     int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int Vg,
+                     const int *rowptr, const int *colidx, const float *vals, int nlayers, const float *const *W,
+                     const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
+                     const int *relu, int pool, float *out, int ldo, int col0, g4d_stream_t stream);
+
 /* max (is_max=1) / mean over S consecutive rows, any S: in (groups*S, ldi) -> out (groups, ldo) at col0. */
 int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0, int is_max,
                       g4d_stream_t stream);
