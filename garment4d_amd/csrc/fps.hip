@@ -247,7 +247,9 @@ static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz,
     return check_launch("g4d_fps_f32");
 }
 
-static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|8|16|0(generic)
+int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s);  // fps_bucket.hip
+
+static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|8|16|0(generic); unset = automatic (bucketed kernel for 2048 < n <= 8192)
 
 }  // namespace g4d
 
@@ -267,6 +269,12 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
         g_fps_force_w = e ? atoi(e) : 99;
     }
     const int force = g_fps_force_w;
+    // 2048 < n <= 8192: optional bucketed kernel with exact box pruning (fps_bucket.hip), opt-in: G4D_FPS_BUCKET=1
+    static const bool use_bucket = getenv("G4D_FPS_BUCKET") && atoi(getenv("G4D_FPS_BUCKET")) != 0;  // experimental, see fps_bucket.hip
+    if (use_bucket && force > 16 && n > 2048 && n <= 8192) {
+        const int rc = fps_bucket_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, s);
+        if (rc >= 0) return rc;
+    }
     const bool lds_ok = (size_t)n * 12 + 512 <= 150 * 1024;
 #define G4D_FPS_CASE(W, U, Q) return launch_reg<W, U, Q>(b, n, m, bs, log2bs, xyz, temp, idx, s)
     if (lds_ok && force != 0 && bs >= 64) {

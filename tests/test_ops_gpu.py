@@ -194,3 +194,24 @@ def test_fps_without_scratch():
     idx = torch.empty((1, 8), dtype=torch.int32, device="cuda")
     with pytest.raises(_lib.G4DError):
         _lib.call("g4d_fps_f32", 1, 20000, 8, x.data_ptr(), 0, idx.data_ptr(), _lib.stream_ptr())
+
+
+def test_fps_bucketed_variant_is_index_exact():
+    """fps_bucket.hip (Morton-sorted buckets + exact fp32-monotone box pruning, opt-in) gives the same indices."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, torch, sys; sys.path.insert(0, '.');"
+        "from garment4d_amd import pointnet2_utils as PU, synthetic as syn;"
+        "from oracle import pointnet2_oracle as K;"
+        "ok=True\n"
+        "for (B,N,M,kind) in [(2,8192,1024,'u'),(2,6890,700,'t'),(2,4096,512,'u'),(2,3000,300,'t'),(1,2049,64,'u')]:\n"
+        "    x=syn.unit_cloud(B,N,seed=N) if kind=='u' else syn.body_like_cloud(B,N,seed=N,dup_frac=0.3,zero_frac=0.1)\n"
+        "    w,wt=K.fps(x,M,return_temp=True)\n"
+        "    from garment4d_amd import pointnet2_cuda as shim\n"
+        "    xt=torch.from_numpy(x).cuda(); t=torch.full((B,N),1e10,device='cuda'); i=torch.empty((B,M),dtype=torch.int32,device='cuda')\n"
+        "    shim.furthest_point_sampling_wrapper(B,N,M,xt,t,i)\n"
+        "    ok&=bool((i.cpu().numpy()==w).all()) and bool((t.cpu().numpy()==wt).all())\n"
+        "print('OK' if ok else 'BAD')")
+    env = dict(os.environ, G4D_FPS_BUCKET="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.stdout.strip().endswith("OK"), out.stdout + out.stderr
