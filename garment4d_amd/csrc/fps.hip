@@ -269,9 +269,9 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
         g_fps_force_w = e ? atoi(e) : 99;
     }
     const int force = g_fps_force_w;
-    // 2048 < n <= 8192: optional bucketed kernel with exact box pruning (fps_bucket.hip), opt-in: G4D_FPS_BUCKET=1
-    static const bool use_bucket = getenv("G4D_FPS_BUCKET") && atoi(getenv("G4D_FPS_BUCKET")) != 0;  // experimental, see fps_bucket.hip
-    if (use_bucket && force > 16 && n > 2048 && n <= 8192) {
+    // 4096 < n <= 8192: bucketed kernel with exact box pruning (fps_bucket.hip); G4D_FPS_BUCKET=0 turns it off
+    static const int use_bucket = getenv("G4D_FPS_BUCKET") ? atoi(getenv("G4D_FPS_BUCKET")) : 1;  // 0 = off, 2 = also 2048 < n <= 4096
+    if (use_bucket && force > 16 && n > (use_bucket >= 2 ? 2048 : 4096) && n <= 8192) {
         const int rc = fps_bucket_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, s);
         if (rc >= 0) return rc;
     }

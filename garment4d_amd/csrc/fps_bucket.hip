@@ -1,28 +1,27 @@
-// Bucketed furthest point sampling: identical output to fps.hip / the reference.  EXPERIMENTAL (opt-in with
-// G4D_FPS_BUCKET=1): the pruning works -- 12 of 128 buckets swept per round at N=8192, M=1024 -- but on gfx950 the
-// round is dominated by its fixed dependent chain (DPP step 19 cycles, LDS round trip 64, 16-wave barrier 60,
-// measured by scripts/micro/clock.hip), and the per-bucket arg-max added here costs what the skipped sweeps save:
-// 1.09 us/round either way.  Next step: prune against the global max (free) and keep one arg-max per wave.
+// Bucketed furthest point sampling: identical output to fps.hip / the reference, ~23 % fewer cycles per round at
+// N = 8192 (1.085 -> 0.84 us per round, B = 8) and the first FPS here whose work per round does not grow with N.
 //
-// In round j only points closer to the new sample than their current min-distance change.  The cloud is sorted
-// along a Morton curve (bitonic sort in LDS, once per launch) and cut into buckets of 64 consecutive points --
-// one VGPR "slot" of one wave, buckets dealt round-robin to the 16 waves so that the buckets near a sample sit in
-// different waves.  Each wave keeps, lane-distributed, the bounding box of each of its buckets and the bucket's
-// current (max min-distance, tie rank, index).  A round is then
+// In round j only points closer to the new sample than their current min-distance change, and every min-distance
+// is <= g_j, the value of the sample just selected (the global max).  The cloud is sorted along a Morton curve
+// (bitonic sort in LDS, once per launch) and cut into buckets of 64 consecutive points -- one VGPR "slot" of one
+// wave, buckets dealt round-robin to the 16 waves so that the buckets near a sample sit in different waves.  Each
+// wave keeps the bounding boxes of its buckets lane-distributed.  A round is then
 //
-//   1. lane i tests box i against the new sample: d_box = dx*dx + dy*dy + dz*dz with dx = the gap between the
-//      sample and the box along x, ... evaluated with the SAME fp32 operation order as the point distance.  Every
-//      fp32 operation involved is monotone, so d(p) >= d_box holds for the rounded values of every point p in the box,
-//      exactly, without any epsilon: if d_box >= bucket_max the sweep could not change a single min-distance and the
-//      bucket is skipped -- pruning is bit-exact.
-//   2. only the active buckets (typically 1-2 of 8 per wave, uniform branches over a ballot mask) are swept and their
-//      (max, rank, index) refreshed by a DPP wave arg-max;
-//   3. the wave's candidate = best of its lane-held bucket candidates (DPP row scan over 8 lanes); the workgroup
-//      exchange (one barrier, parity-buffered 8-byte keys) and the LDS lookup of the winner are those of fps.hip.
+//   1. lane i tests box i against the new sample: d_box = gx*gx + gy*gy + gz*gz with gx = the gap between the sample
+//      and the box along x, ... evaluated with the SAME fp32 operation order as the point distance.  Every fp32
+//      operation involved is monotone, so d(p) >= d_box holds for the ROUNDED values of every point p in the box,
+//      exactly, without any epsilon: if d_box >= g_j the sweep could not lower a single min-distance and the bucket
+//      is skipped -- pruning is bit-exact (measured: 14 of 128 buckets swept per round at N=8192, M=1024);
+//   2. a wave with no active bucket (about half of them in a typical round) republishes its cached candidate; the
+//      others sweep their active buckets and redo ONE arg-max: balanced max / rank-select trees over the lane's 8
+//      points, then a DPP wave arg-max;
+//   3. the workgroup exchange is one LDS atomic max per wave on a rotating 64-bit slot, one barrier, one read; the
+//      winner's coordinates come from the LDS SoA copy of the cloud.
 //
 // Tie-break = the reference's (smallest bit-reversed (k mod bs), then smallest k) through the same rank key, computed
-// from ORIGINAL indices, so the permutation is invisible in the output.  Still bound by the serial round chain, but
-// see the note at the top for where the time goes.
+// from ORIGINAL indices, so the permutation is invisible in the output.  What bounds the round now is plain
+// dependent issue: a lone wave retires one dependent instruction per ~6 cycles, a DPP step costs 19, an LDS round
+// trip 64, a 16-wave barrier 60 (scripts/micro/clock.hip); the slowest wave's ~190-instruction path is the round.
 #include "g4d_common.h"
 
 namespace g4d {
@@ -56,6 +55,12 @@ __device__ __forceinline__ unsigned long long fpsb_row_max_u64(unsigned long lon
     if constexpr (W >= 16) G4D_STEP(0x118)
 #undef G4D_STEP
     return key;
+}
+
+__device__ __forceinline__ float fmax_raw(float a, float b) {  // bare v_max_f32: no canonicalising pre-pass (inputs are never NaN)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ float wave_min_f32(float v) {
@@ -175,74 +180,101 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
         md[i] = ok ? (temp ? temp[k] : 1e10f) : -2.f;  // -2: below every real min-distance, never a candidate
         if (ok) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
     }
-    // bucket boxes + initial bucket candidates, lane i holds bucket i
+    // bucket boxes, lane i holds the box of bucket i; per-slot tie ranks of the points
     float blx = INF, bly = INF, blz = INF, bhx = -INF, bhy = -INF, bhz = -INF;
-    float smax = -2.f;
-    unsigned srank = 0xffffffffu;
+    unsigned rk[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const bool ok = pk[i] >= 0;
+        rk[i] = ok ? fpsb_rank(pk[i], bs, log2bs) : 0xffffffffu;
         const float a0 = wave_min_f32(ok ? px[i] : INF), a1 = wave_min_f32(ok ? py[i] : INF), a2 = wave_min_f32(ok ? pz[i] : INF);
         const float a3 = wave_max_f32(ok ? px[i] : -INF), a4 = wave_max_f32(ok ? py[i] : -INF), a5 = wave_max_f32(ok ? pz[i] : -INF);
-        // initial candidate of the bucket (arg-max of md under the rank order)
-        const float v = wave_max_f32(md[i]);
-        const unsigned r = (md[i] == v && ok) ? fpsb_rank(pk[i], bs, log2bs) : 0xffffffffu;
-        const unsigned rmin = wave_min_u32(r);
-        if (lane == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; smax = v; srank = rmin; }
+        if (lane == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }
     }
-    if (t == 0) idx[0] = 0;
+    if (t == 0) { idx[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
     __syncthreads();
 
     float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+    float gval = INF;          // global max of the min-distances (the last winner's value): nothing can exceed it
+    float cval = -2.f;         // this wave's cached candidate (value, rank); refreshed only when one of its buckets was swept
+    unsigned crank = 0xffffffffu;
 #ifdef G4D_FPS_DEBUG
-    unsigned dbg_active = 0, dbg_maxw = 0;
+    unsigned dbg_active = 0;
+    long long dbg_t[5] = {0, 0, 0, 0, 0}, dbg_c0 = 0;
+#define G4D_STAMP(i) { const long long now_ = clock64(); dbg_t[i] += now_ - dbg_c0; dbg_c0 = now_; }
+#else
+#define G4D_STAMP(i)
 #endif
     for (int j = 1; j < m; ++j) {
-        // 1. which buckets can change?  gap between the sample and the box, per axis, same op order as the point distance
+#ifdef G4D_FPS_DEBUG
+        dbg_c0 = clock64();
+#endif
+        // 1. which buckets can change?  gap between the sample and the box, per axis, same op order as the point distance;
+        //    a bucket whose box is at least sqrt(gval) away cannot lower any min-distance (every one is <= gval)
         const float gx = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
         const float gy = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
         const float gz = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
         const float dbox = gx * gx + gy * gy + gz * gz;
-        const unsigned active = (unsigned)__builtin_amdgcn_ballot_w64(lane < P && dbox < smax);
+        const unsigned active = (unsigned)__builtin_amdgcn_ballot_w64(lane < P && dbox < gval);
 #ifdef G4D_FPS_DEBUG
         dbg_active += __builtin_popcount(active);
 #endif
-        // 2. sweep the active buckets
+        G4D_STAMP(0)
+        if (active != 0u) {  // wave-uniform; about half of the waves skip the whole block in a typical round
+            // 2. sweep the active buckets
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            if ((active >> i) & 1u) {  // wave-uniform
-                const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-                const float d = dx * dx + dy * dy + dz * dz;
-                const float d2 = fpsb_min(d, md[i]);
-                md[i] = d2;
-                const float v = wave_max_f32(d2);
-                const unsigned long long hit = __builtin_amdgcn_ballot_w64(d2 == v);
-                unsigned r;
-                if (__builtin_popcountll(hit) == 1) {
-                    const int kk = __builtin_amdgcn_readlane(pk[i], __builtin_ctzll(hit));
-                    r = fpsb_rank(kk, bs, log2bs);
-                } else {
-                    const unsigned rr = (d2 == v && pk[i] >= 0) ? fpsb_rank(pk[i], bs, log2bs) : 0xffffffffu;
-                    r = wave_min_u32(rr);
+            for (int i = 0; i < P; ++i) {
+                if ((active >> i) & 1u) {
+                    const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+                    const float d = dx * dx + dy * dy + dz * dz;
+                    md[i] = fpsb_min(d, md[i]);
                 }
-                smax = (lane == i) ? v : smax;
-                srank = (lane == i) ? r : srank;
+            }
+            // 3. lane candidate: max value over its P points, smallest rank among the points holding it; then the wave's
+            //    (balanced trees: the round is a dependent-issue chain at ~6 cycles per instruction, depth is what counts)
+            float tv[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) tv[i] = md[i];
+#pragma unroll
+            for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                for (int i = 0; i < w / 2; ++i) tv[i] = fmax_raw(tv[i], tv[i + w / 2]);
+            const float b = tv[0];
+            unsigned tr[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) tr[i] = (md[i] == b) ? rk[i] : 0xffffffffu;
+#pragma unroll
+            for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                for (int i = 0; i < w / 2; ++i) tr[i] = min(tr[i], tr[i + w / 2]);
+            const unsigned r = tr[0];
+            cval = wave_max_f32(b);
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(b == cval);
+            if (__builtin_popcountll(hit) == 1) {
+                crank = (unsigned)__builtin_amdgcn_readlane((int)r, __builtin_ctzll(hit));
+            } else {
+                crank = wave_min_u32(b == cval ? r : 0xffffffffu);
             }
         }
-        // 3. wave candidate = best bucket candidate (lanes 0..P-1), then the workgroup exchange
-        unsigned long long key = (lane < P) ? (((unsigned long long)__float_as_uint(fmaxf(smax, 0.f)) << 32) | (unsigned)(~srank)) : 0ull;
-        key = fpsb_row_max_u64<P>(key);
-        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), P - 1);
-        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, P - 1);
-        unsigned long long *buf = slots + (j & 1) * 16;
-        if (lane == 0) buf[wave] = ((unsigned long long)khi << 32) | klo;
+        G4D_STAMP(1)
+        // 4. workgroup arg-max: ONE LDS atomic max per wave on a rotating slot, one barrier, one read
+        if (lane == 0)
+            atomicMax(&slots[j % 3], ((unsigned long long)__float_as_uint(fmaxf(cval, 0.f)) << 32) | (unsigned)(~crank));
         __syncthreads();
-        const unsigned long long best = fpsb_row_max_u64<W>(buf[t & (W - 1)]);
-        const unsigned rank = ~(unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, W - 1);
+        G4D_STAMP(2)
+        const unsigned long long best = slots[j % 3];
+        if (t == 0) slots[(j + 2) % 3] = 0ull;  // next use is after the NEXT barrier; last read was before this one
+        const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(best >> 32));
+        const unsigned rank = ~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)best);
+        gval = __uint_as_float(bhi);
         const unsigned c = log2bs ? (__builtin_bitreverse32(rank >> 16) >> (32 - log2bs)) : 0u;
         const int old = (int)(((rank & 0xffffu) << log2bs) | c);
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
         if (t == 0) idx[j] = old;
+#ifdef G4D_FPS_DEBUG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        G4D_STAMP(3)
     }
     if (temp) {
 #pragma unroll
@@ -252,7 +284,8 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
 #ifdef G4D_FPS_DEBUG
     __syncthreads();
     if (lane == 0 && temp) atomicAdd(&temp[0], (float)dbg_active);  // debug only: total active (wave, bucket) sweeps
-    (void)dbg_maxw;
+    if (lane == 0 && temp && (wave == 0 || wave == 5) && blockIdx.x == 0)
+        for (int q = 0; q < 4; ++q) temp[1 + (wave ? 4 : 0) + q] = (float)dbg_t[q];
 #endif
 }
 
@@ -273,7 +306,12 @@ static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *x
 
 // Called by g4d_fps_f32 (fps.hip) for 2048 < n <= 8192.  Returns -1 when the shape is not covered.
 int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
-    if (n > 4096 && n <= 8192) return launch_bucket<16, 8>(b, n, m, bs, log2bs, xyz, temp, idx, s);
+    static const int cfg = getenv("G4D_FPS_BUCKET_W") ? atoi(getenv("G4D_FPS_BUCKET_W")) : 16;  // tuning hook
+    if (n > 4096 && n <= 8192) {
+        if (cfg == 8) return launch_bucket<8, 16>(b, n, m, bs, log2bs, xyz, temp, idx, s);
+        if (cfg == 4) return launch_bucket<4, 32>(b, n, m, bs, log2bs, xyz, temp, idx, s);
+        return launch_bucket<16, 8>(b, n, m, bs, log2bs, xyz, temp, idx, s);
+    }
     if (n > 2048 && n <= 4096) return launch_bucket<16, 4>(b, n, m, bs, log2bs, xyz, temp, idx, s);
     return -1;
 }
