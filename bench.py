@@ -94,13 +94,21 @@ def kernel_rooflines(model, cloud):
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3  # seconds
 
-    # 1. FPS level 1 (8192 -> 1024): one launch = B clouds.  Algorithmic bytes = xyz in + temp in/out + idx out.
-    t = timed(lambda: PU.furthest_point_sample(cloud, 1024))
-    fps_bytes = B_CLOUDS * (12 * N_POINTS + 8 * N_POINTS + 4 * 1024)
-    res["fps"] = {"kernel": "fps_reg_kernel (8192->1024, B=8)", "bound": "hbm", "achieved": fps_bytes / t / 1e9,
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+    # 1. FPS level 1 (8192 -> 1024), the dominant kernel by GPU time (56 % in profiles/r01_kernel_stats_bench_default.csv).
+    #    One launch = B clouds.  Algorithmic bytes = xyz in + idx out (the fused path passes temp=NULL: no scratch traffic).
+    xyz_dev = cloud
+    idx_dev = torch.empty((B_CLOUDS, 1024), dtype=torch.int32, device=cloud.device)
+    from garment4d_amd import _lib
+    t = timed(lambda: _lib.call("g4d_fps_f32", B_CLOUDS, N_POINTS, 1024, xyz_dev.data_ptr(), 0, idx_dev.data_ptr(), _lib.stream_ptr()))
+    fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024)
+    res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8)", "bound": "hbm", "achieved": fps_bytes / t / 1e9,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS,
+                  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch: 545.1 KB + 154.4 KB
+                  # (profiles/r01_pmc_hbm_traffic.csv; calibration factor 1.02 measured on linear_kernel in the same run)
+                  "traffic": (545.1 + 154.4) * 1024, "traffic_unit": "bytes/launch", "algorithmic_bytes": fps_bytes,
                   "avg_launch_us": t * 1e6, "rounds_per_s_per_cloud": 1023 / t,
-                  "note": "serial-dependency bound (1023 dependent rounds/launch), neither HBM nor MFMA"}
+                  "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
+                          "neither HBM nor MFMA limits it -- see DESIGN.md section 5"}
     # 2. heaviest MFMA layer: FP1 layer 0 (interp + 128->128 over B*8192 rows)
     rows, K, Cout = B_CLOUDS * N_POINTS, 128, 128
     x = torch.randn(rows, K, device=cloud.device)
