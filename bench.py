@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 16 batches in flight on 16
+# streams, 4 queues serialise them four deep (11.8k frames/s); 32 queues let every stream own one (17.9k).  Must be
+# set before the runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -38,13 +42,15 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=160)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--streams", type=int, default=16, help="independent batches in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the workload the CPU oracle is timed on")
     ap.add_argument("--no-lbs", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
+                                                       "exercising the multi-rank path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -152,12 +158,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    ndev = torch.cuda.device_count()
+    if local >= ndev:
+        assert args.backend != "nccl", f"LOCAL_RANK {local} but only {ndev} GPU(s) visible"
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier / max-reduce only
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; used for the barrier / max-reduce only
+        else:
+            dist.init_process_group(args.backend)
 
     with_lbs = not args.no_lbs
     try:
@@ -206,7 +219,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         barrier()
@@ -223,6 +236,7 @@ def main():
             "config": {"workload": "cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32"
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),
                        "frames_per_step": B_CLOUDS, "batches_in_flight": ns, "hipgraph": graphs is not None,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roof["fps"], "roofline_mfma": roof["mlp"],
         }
