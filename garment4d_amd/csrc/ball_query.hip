@@ -13,8 +13,9 @@
 //     loaded into registers while stage s is consumed, so the L2 stream is shared by the 4 waves and its
 //     latency sits behind 16 steps of VALU work (the first version re-loaded every 64-point step per wave from L2
 //     with nothing in flight: 65 us per radius at B=8, N=8192, M=1024);
-//   * ascending-index order falls out of ballot + mbcnt prefix (slot = cnt + #hits in lower lanes); the hit path
-//     is scalar-branched and rare (a radius-0.1 ball holds ~0.4 % of a unit cloud);
+//   * ascending-index order falls out of ballot + mbcnt prefix (slot = cnt + #hits in lower lanes); the common case
+//     -- no lane within the LARGEST radius -- costs one compare and one branch for all scales (a radius-0.1 ball
+//     holds ~0.4 % of a unit cloud), the per-scale bookkeeping runs only behind it;
 //   * a wave stops testing once its queries are full; the workgroup leaves when all four are.
 // Algorithmic bytes: 12*B*(N+M) + 4*B*M*sum(nsample); B*M*N distance evaluations worst case.
 #include "g4d_common.h"
@@ -22,6 +23,7 @@
 namespace g4d {
 
 struct BqArgs {
+    float radius2_max;
     float radius2[4];
     int nsample[4];
     int *idx[4];
@@ -63,8 +65,10 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = base + t + j * 256;
-            const int kc = k < n ? k : n - 1;
-            rx[j] = xyz[kc * 3 + 0]; ry[j] = xyz[kc * 3 + 1]; rz[j] = xyz[kc * 3 + 2];
+            const bool ok = k < n;
+            const int kc = ok ? k : n - 1;
+            const float inf = __builtin_inff();
+            rx[j] = ok ? xyz[kc * 3 + 0] : inf; ry[j] = ok ? xyz[kc * 3 + 1] : inf; rz[j] = ok ? xyz[kc * 3 + 2] : inf;
         }
     };
     auto store_stage = [&](int buf) {
@@ -83,18 +87,20 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
         const int cn = min(kStage, n - base);
         for (int c = 0; c < cn && open > 0; c += 64) {
             const int k = base + c + lane;
-            const bool valid = c + lane < cn;
+            // lanes past the end of the cloud hold +inf coordinates (stage loader) -> never a hit, no `valid` predicate
             const float x = sp[buf][0][c + lane], y = sp[buf][1][c + lane], z = sp[buf][2][c + lane];
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
                 const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
                 const float d2 = dx * dx + dy * dy + dz * dz;
+                // common case: nobody within the LARGEST radius -> one compare, one branch for all NS scales
+                if (__builtin_amdgcn_ballot_w64(d2 < a.radius2_max) == 0ull) continue;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
-                        const bool hit = valid && (d2 < a.radius2[s]);
+                        const bool hit = d2 < a.radius2[s];
                         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                        if (mask != 0ull) {  // wave-uniform, rare
+                        if (mask != 0ull) {
                             if (cnt[i][s] == 0) first[i][s] = base + c + __builtin_ctzll(mask);
                             const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                             if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
@@ -141,6 +147,7 @@ extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const fl
     for (int s = 0; s < nscales; ++s) {
         G4D_REQUIRE(nsamples[s] > 0 && idx[s], "g4d_ball_query_msg_f32: bad scale %d", s);
         a.radius2[s] = radii[s] * radii[s];  // ball_query_gpu.cu:23, rounded once in fp32
+        a.radius2_max = s == 0 ? a.radius2[0] : (a.radius2[s] > a.radius2_max ? a.radius2[s] : a.radius2_max);
         a.nsample[s] = nsamples[s];
         a.idx[s] = idx[s];
         if (n == 0) {
