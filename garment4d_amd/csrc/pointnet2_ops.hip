@@ -186,6 +186,35 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(int n, int m, int c, c
     out[((size_t)b * m + j) * c + ch] = in[((size_t)b * n + idx[(size_t)b * m + j]) * c + ch];
 }
 
+// point-major three_interpolate + skip concat (PointnetFPModule.forward, pointnet2_modules.py:139-149):
+// out[b,p,:] = [ sum_i w_i known[b,idx_i,:] (C2) | skip[b,p,:] (C1) ],  w_i = normalised 1/(sqrt(dist2_i)+1e-8).
+// One thread per (row, 4 channels): the three source rows are contiguous C2-float vectors.
+__global__ void __launch_bounds__(256) interp_concat_kernel(long long rows, int n, int m, int C2, int C1,
+                                                           const float *__restrict__ known, const float *__restrict__ skip,
+                                                           const float *__restrict__ dist2, const int *__restrict__ nn_idx,
+                                                           float *__restrict__ out) {
+    const int K = C2 + C1;
+    const int per_row = (K + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * per_row) return;
+    const long long row = gid / per_row;
+    const int k0 = (int)(gid - row * per_row) * 4;
+    const int b = (int)(row / n);
+    const int *ix = nn_idx + row * 3;
+    const float *d2 = dist2 + row * 3;
+    const float r0 = 1.0f / (__fsqrt_rn(d2[0]) + 1e-8f), r1 = 1.0f / (__fsqrt_rn(d2[1]) + 1e-8f), r2 = 1.0f / (__fsqrt_rn(d2[2]) + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    const float w0 = r0 / norm, w1 = r1 / norm, w2 = r2 / norm;
+    const float *a0 = known + ((size_t)b * m + ix[0]) * C2, *a1 = known + ((size_t)b * m + ix[1]) * C2,
+                *a2 = known + ((size_t)b * m + ix[2]) * C2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        if (k >= K) break;
+        out[row * K + k] = k < C2 ? (w0 * a0[k] + w1 * a1[k] + w2 * a2[k]) : skip[row * C1 + (k - C2)];
+    }
+}
+
 static inline int launch_group(int b, int c, int n, long long e_total, const float *points, const int *idx, float *out,
                                hipStream_t s, const char *what) {
     if (b == 0 || c == 0 || e_total == 0) return G4D_OK;
@@ -292,4 +321,17 @@ extern "C" int g4d_gather_rows_f32(int b, int n, int m, int c, const float *in, 
     dim3 grid((unsigned)(((long long)m * c + 255) / 256), b);
     hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, G4D_STREAM(stream), n, m, c, in, idx, out);
     return check_launch("g4d_gather_rows_f32");
+}
+
+extern "C" int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const float *known_feats, const float *skip,
+                                     const float *dist2, const int *nn_idx, float *out, g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_interp_concat_f32", b, n, m, c2, c1);
+    const long long rows = (long long)b * n;
+    if (rows == 0 || c2 + c1 == 0) return G4D_OK;
+    G4D_REQUIRE(known_feats && dist2 && nn_idx && out && (c1 == 0 || skip), "g4d_interp_concat_f32: null pointer");
+    const long long work = rows * ((c2 + c1 + 3) / 4);
+    G4D_REQUIRE((work + 255) / 256 < (1ll << 31), "g4d_interp_concat_f32: too large");
+    hipLaunchKernelGGL(interp_concat_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, G4D_STREAM(stream), rows, n, m, c2, c1,
+                       known_feats, skip, dist2, nn_idx, out);
+    return check_launch("g4d_interp_concat_f32");
 }

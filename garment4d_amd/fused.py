@@ -354,6 +354,15 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
             return out, logits
     if USE_STACK and stack_fits(layers, 0, 1):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
+    elif layers[0].Cout > 64:
+        # wide FP level: every 64-channel tile of the first layer would redo the interpolation -> materialise the
+        # interpolated + concatenated rows once (a few MB), then plain DIRECT layers
+        x = torch.empty((B * n, C2 + C1), dtype=torch.float32, device=unknown.device)
+        _lib.call("g4d_interp_concat_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm), dist2.data_ptr(),
+                  nn_idx.data_ptr(), x.data_ptr(), stream)
+        h = x
+        for i, L in enumerate(layers):
+            h = linear(h, L, out=out.view(B * n, -1) if i == len(layers) - 1 else None)
     else:
         _run_stack(first, layers, B * n, 1, 0, out.view(B * n, -1), 0, unknown.device)
     if head is not None:

@@ -151,6 +151,12 @@ int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float 
  * same result as gather_points on the transposed tensor, pointnet2_modules.py:32-35, without the two transposes). */
 int g4d_gather_rows_f32(int b, int n, int m, int c, const float *in, const int *idx, float *out, g4d_stream_t stream);
 
+/* point-major three_interpolate + skip concat: out (B,n,C2+C1) = [sum_i w_i known_feats[b,nn_idx_i,:] | skip[b,p,:]],
+ * w_i = normalised 1/(sqrt(dist2_i)+1e-8) (pointnet2_modules.py:139-149).  Used ahead of g4d_linear_f32 when the FP
+ * stack is too wide for the LDS-resident kernels (each 64-channel tile would otherwise redo the interpolation). */
+int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const float *known_feats, const float *skip,
+                          const float *dist2, const int *nn_idx, float *out, g4d_stream_t stream);
+
 /* batched matrix transpose (b, r, c) -> (b, c, r): channel-major <-> point-major at the API boundary. */
 int g4d_transpose_f32(int b, int r, int c, const float *in, float *out, g4d_stream_t stream);
 
