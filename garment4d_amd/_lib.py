@@ -38,6 +38,7 @@ SIGNATURES = {
     "g4d_pool_rows_f32": [_I, _I, _I, _vp, _I, _vp, _I, _I, _I, _vp],
     "g4d_transpose_f32": [_I, _I, _I, _vp, _vp, _vp],
     "g4d_interp_concat_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_spmm_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_gather_rows_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_lbs_shape_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp],
     "g4d_joint_regress_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp],

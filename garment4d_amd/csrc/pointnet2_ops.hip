@@ -215,6 +215,41 @@ __global__ void __launch_bounds__(256) interp_concat_kernel(long long rows, int 
     }
 }
 
+// Batched SpMM of GraphConvolution.forward (modules/pygcn/layers.py:44-47): out[f,v,:] = sum_u Ahat[v,u] * S[f,u,:] (+ bias).
+// The reference folds the batch into columns (transpose, reshape, torch.spmm, reshape, transpose); here one thread owns
+// 4 consecutive channels of one (frame, vertex) row: the ~5 neighbour rows are read as contiguous float4 segments
+// (lanes = consecutive channels -> coalesced) and nothing is transposed.
+__global__ void __launch_bounds__(256) spmm_rows_kernel(long long rows, int vg, int c, const float *__restrict__ S,
+                                                       const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                                       const float *__restrict__ vals, const float *__restrict__ bias,
+                                                       float *__restrict__ out) {
+    const int per_row = (c + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * per_row) return;
+    const long long row = gid / per_row;
+    const int c0 = (int)(gid - row * per_row) * 4;
+    const long long f = row / vg;
+    const int v = (int)(row - f * vg);
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = (c0 + 3 < c) && ((c & 3) == 0);
+    for (int e = beg; e < end; ++e) {
+        const float a = vals[e];
+        const float *src = S + ((size_t)f * vg + colidx[e]) * c + c0;
+        if (full) {
+            const float4 x = *reinterpret_cast<const float4 *>(src);
+            acc[0] = fmaf(a, x.x, acc[0]); acc[1] = fmaf(a, x.y, acc[1]); acc[2] = fmaf(a, x.z, acc[2]); acc[3] = fmaf(a, x.w, acc[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < c) acc[j] = fmaf(a, src[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < c) out[(size_t)row * c + c0 + j] = acc[j] + (bias ? bias[c0 + j] : 0.f);
+}
+
 static inline int launch_group(int b, int c, int n, long long e_total, const float *points, const int *idx, float *out,
                                hipStream_t s, const char *what) {
     if (b == 0 || c == 0 || e_total == 0) return G4D_OK;
@@ -334,4 +369,17 @@ extern "C" int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const 
     hipLaunchKernelGGL(interp_concat_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, G4D_STREAM(stream), rows, n, m, c2, c1,
                        known_feats, skip, dist2, nn_idx, out);
     return check_launch("g4d_interp_concat_f32");
+}
+
+extern "C" int g4d_spmm_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
+                                 const float *vals, const float *bias, float *out, g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_spmm_rows_f32", frames, vg, c);
+    const long long rows = (long long)frames * vg;
+    if (rows == 0 || c == 0) return G4D_OK;
+    G4D_REQUIRE(S && rowptr && colidx && vals && out, "g4d_spmm_rows_f32: null pointer");
+    const long long work = rows * ((c + 3) / 4);
+    G4D_REQUIRE((work + 255) / 256 < (1ll << 31), "g4d_spmm_rows_f32: too large");
+    hipLaunchKernelGGL(spmm_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, G4D_STREAM(stream), rows, vg, c, S, rowptr,
+                       colidx, vals, bias, out);
+    return check_launch("g4d_spmm_rows_f32");
 }

@@ -3,10 +3,11 @@
 (/root/reference/modules/pygcn/utils.py:56-63 normalize, :73-80 sparse_mx_to_torch_sparse_tensor; adjacency
 construction as in modules/mesh_encoder.py:288-307).
 
-forward(input, adj):  out = adj @ (input @ W) + b  -- here ONE fused HIP kernel per layer: each 64-row tile of
-(adj @ input) is aggregated from the CSR rows straight into LDS and contracted with W on the matrix cores
-((A X) W == A (X W)); the reference materialises X W, transposes it to (N, B*F), runs torch.spmm and transposes
-back.  Inference only: parameters are read, no autograd graph is built.
+forward(input, adj):  out = adj @ (input @ W) + b  -- the reference's order, two HIP kernels per layer: the dense
+contraction on the matrix cores (g4d_linear_f32, point-major rows) and a batched CSR SpMM whose threads own 4
+channels of one (frame, vertex) row (g4d_spmm_rows_f32); the reference transposes X W to (N, B*F), runs torch.spmm
+and transposes back.  (A fused CSR-aggregate-then-contract kernel exists too, g4d_gcn_linear_f32; it redoes the
+aggregation per 64-channel tile and only pays for Fin <= 64.)  Inference only: no autograd graph is built.
 """
 import math
 
@@ -104,9 +105,13 @@ class GraphConvolution(torch.nn.Module):
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 dev = self.weight.device
-                shift = self.bias.detach().float() if self.bias is not None else torch.zeros(self.out_features, device=dev)
-                L = PackedLayer(self.weight.detach().float().t().contiguous(), torch.ones(self.out_features, device=dev), shift,
-                                relu=False)
+                zero = torch.zeros(self.out_features, device=dev)
+                bias = self.bias.detach().float().contiguous() if self.bias is not None else None
+                wt = self.weight.detach().float().t().contiguous()
+                one = torch.ones(self.out_features, device=dev)
+                L = (PackedLayer(wt, one, zero, relu=False),                          # support = X W
+                     PackedLayer(wt, one, bias if bias is not None else zero, relu=False),  # ismlp: X W + b
+                     bias)
             hit = (key, L)
             self._g4d_packed = hit
         return hit[1]
@@ -118,7 +123,7 @@ class GraphConvolution(torch.nn.Module):
         if not (input.is_cuda and input.dtype == torch.float32):
             raise RuntimeError("GraphConvolution: input must be a float32 HIP tensor")
         x = input.contiguous()
-        L = self._packed()
+        L_support, L_mlp, bias = self._packed()
         squeeze = x.dim() == 2
         if squeeze:
             x = x.unsqueeze(0)
@@ -126,13 +131,13 @@ class GraphConvolution(torch.nn.Module):
         out = torch.empty((B, N, self.out_features), dtype=torch.float32, device=x.device)
         if ismlp:
             # layers.py:43: `support` only gets the bias when one exists -- same thing here (shift = bias or 0)
-            linear(x.view(B * N, Fin), L, out=out.view(B * N, -1))
+            linear(x.view(B * N, Fin), L_mlp, out=out.view(B * N, -1))
         else:
             rowptr, colidx, vals, n = _to_csr(adj, x.device)
             assert n == N, "adjacency size does not match the number of vertices"
-            _lib.call("g4d_gcn_linear_f32", B, N, Fin, x.data_ptr(), Fin, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(),
-                      L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), 0, out.data_ptr(),
-                      self.out_features, 0, _lib.stream_ptr())
+            support = linear(x.view(B * N, Fin), L_support)                          # layers.py:42  matmul(input, weight)
+            _lib.call("g4d_spmm_rows_f32", B, N, self.out_features, support.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(),
+                      vals.data_ptr(), 0 if bias is None else bias.data_ptr(), out.data_ptr(), _lib.stream_ptr())  # :46-55
         return out[0] if squeeze else out
 
     def __repr__(self):

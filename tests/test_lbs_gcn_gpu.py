@@ -115,3 +115,23 @@ def test_gcn_vs_oracle_tshirt_dims():
             scale = max(1.0, float(np.abs(h_ref).max()))
             assert float(np.abs(host(h) - h_ref).max()) <= 1e-5 * scale
             h_ref = np.maximum(h_ref, 0); h = torch.relu(h)
+
+
+def test_gcn_fused_csr_linear_entry_point():
+    """g4d_gcn_linear_f32 ((A X) W fused in one kernel) stays correct next to the two-kernel path gcn.py uses."""
+    from garment4d_amd import _lib, fused
+    verts, faces = syn.quad_cylinder(16, 16)
+    Vg = verts.shape[0]
+    adj = gcn_oracle.adjacency_from_faces(faces, Vg)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, Vg, 40)).astype(np.float32)
+    W = (rng.standard_normal((40, 24)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(24).astype(np.float32)
+    want = gcn_oracle.graph_convolution(x, W, b, adj)
+    L = fused.PackedLayer(dev(W.T.copy()), torch.ones(24, device="cuda"), dev(b), relu=False)
+    rowptr, colidx, vals, _ = G._to_csr(adj, torch.device("cuda"))
+    out = torch.empty((2, Vg, 24), device="cuda")
+    xd = dev(x)
+    _lib.call("g4d_gcn_linear_f32", 2, Vg, 40, xd.data_ptr(), 40, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), L.Kpad, L.Cout,
+              L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), 0, out.data_ptr(), 24, 0, _lib.stream_ptr())
+    np.testing.assert_allclose(host(out), want, **TOL)
