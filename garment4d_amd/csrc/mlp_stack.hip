@@ -27,7 +27,7 @@ namespace g4d {
 constexpr int kMaxLayers = 4;
 
 struct StackLayer {
-    const float *W, *scale, *shift;  // packed like mlp.hip: [CoutPad64][Kpad], [CoutPad64]
+    const float *W, *scale, *shift;  // W in FRAGMENT order [CoutPad64/16][Kpad/16][64 lanes][4]; scale/shift [CoutPad64]
     int Kpad, Cout, relu;
 };
 
@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
         }
     }
     // first W fragment of the first job: in flight across the gather barrier
-    f32x4 bnext = *reinterpret_cast<const f32x4 *>(s.layer[0].W + (size_t)(cs * 16 + fi) * s.layer[0].Kpad + fq * 4);
+    // W is in fragment order: [16-channel tile][k-step][lane][4]  (one B-fragment load = 1 KB contiguous per wave)
+    f32x4 bnext = *reinterpret_cast<const f32x4 *>(s.layer[0].W + (size_t)cs * (s.layer[0].Kpad >> 4) * 256 + lane * 4);
     __syncthreads();
 
     for (int l = 0; l < s.nlayers; ++l) {
@@ -93,11 +94,11 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 bf = bnext;
             if (wave_live) {
-                const float *wp = L.W + (size_t)ch * L.Kpad + fq * 4;
+                const float *wp = L.W + (size_t)(sl * 4 + cs) * (L.Kpad >> 4) * 256 + lane * 4;
                 const float *ap = in + (rh * 32 + fi) * ldin + fq * 4;
                 for (int kk = 0; kk < L.Kpad; kk += 16) {
                     const f32x4 bcur = bf;
-                    if (kk + 16 < L.Kpad) bf = *reinterpret_cast<const f32x4 *>(wp + kk + 16);  // next W fragment, ahead of the MFMAs
+                    if (kk + 16 < L.Kpad) bf = *reinterpret_cast<const f32x4 *>(wp + (kk + 16) * 16);  // next W fragment, ahead of the MFMAs
                     const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + kk);
                     const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ap + 16 * ldin + kk);
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
                 if (nsl >= nslab) { nl = l + 1; nsl = 0; }
                 if (nl < s.nlayers) {
                     const StackLayer &NL = s.layer[nl];
-                    bnext = *reinterpret_cast<const f32x4 *>(NL.W + (size_t)(nsl * 64 + cs * 16 + fi) * NL.Kpad + fq * 4);
+                    bnext = *reinterpret_cast<const f32x4 *>(NL.W + (size_t)(nsl * 4 + cs) * (NL.Kpad >> 4) * 256 + lane * 4);
                 }
             }
             const float sc = L.scale[ch], sh = L.shift[ch];

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256, 3) mlp_wave_kernel(const WaveArgs s) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float *wbase = L.W + (size_t)(g * 64 + fi) * L.Kpad + fq * 4;
+            const float *wbase = L.W + (size_t)(g * 4) * (L.Kpad >> 4) * 256 + lane * 4;  // fragment-order weights
 #pragma unroll 1
             for (int kc = 0; kc < L.Kpad; kc += 32) {
                 if (l == 0) {
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256, 3) mlp_wave_kernel(const WaveArgs s) {
                         af[mt] = *reinterpret_cast<const f32x4 *>(&slab[(mt * 16 + fi) * ld + koff + kk + fq * 4]);
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        if (ct < nct) bf[ct] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)ct * 16 * L.Kpad + kc + kk);
+                        if (ct < nct) bf[ct] = *reinterpret_cast<const f32x4 *>(wbase + ((size_t)ct * (L.Kpad >> 4) + ((kc + kk) >> 4)) * 256);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll

@@ -38,7 +38,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "scale", "shift", "K", "Kpad", "Cout", "relu")
+    __slots__ = ("W", "Wf", "scale", "shift", "K", "Kpad", "Cout", "relu")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -51,7 +51,10 @@ class PackedLayer:
         sh = torch.zeros(cpad, dtype=torch.float32, device=dev)
         sc[:cout] = scale
         sh[:cout] = shift
-        self.W, self.scale, self.shift = W, sc, sh
+        # fragment order for the LDS-resident kernels: [16-channel tile][k-step of 16][lane = fq*16+fi][4 consecutive k]
+        # -> one MFMA B-fragment load of a wave is ONE contiguous 1 KB read instead of 16 half cache lines
+        Wf = W.view(cpad // 16, 16, kpad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+        self.W, self.Wf, self.scale, self.shift = W, Wf, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
 
 
@@ -164,7 +167,7 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
     n = len(layers)
     PA = ctypes.c_void_p * n
     IA = ctypes.c_int * n
-    Wp, Sc, Sh = PA(*[L.W.data_ptr() for L in layers]), PA(*[L.scale.data_ptr() for L in layers]), PA(*[L.shift.data_ptr() for L in layers])
+    Wp, Sc, Sh = PA(*[L.Wf.data_ptr() for L in layers]), PA(*[L.scale.data_ptr() for L in layers]), PA(*[L.shift.data_ptr() for L in layers])
     Kp, Co, Re = IA(*[L.Kpad for L in layers]), IA(*[L.Cout for L in layers]), IA(*[L.relu for L in layers])
     gN = gP = gC = gU = 0
     gx = gn = gf = gi = 0

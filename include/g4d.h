@@ -123,8 +123,9 @@ int g4d_gcn_linear_f32(int frames, int vg, int fin, const float *X, int ldx, con
 /* A whole shared-MLP stack (1..4 layers, hidden widths <= 128) in one launch with the activations resident in LDS
  * (garment4d_amd/csrc/mlp_stack.hip).  mode: 0 DIRECT (X, ldx) | 1 GROUP (N,P,S,C,use_xyz,xyz,new_xyz,feats,idx) |
  * 2 INTERP (n,m,C2,C1,known_feats,skip,dist2,nn_idx) | 3 CSR (X,ldx,Vg,rowptr,colidx,vals); arguments of the other
- * modes are ignored.  Layers are parallel HOST arrays of length nlayers (device pointers W/scale/shift packed as for
- * g4d_linear_f32).  pool over S in {16,32,64} rows applies to the last layer.  tap_out (or NULL): hidden layer
+ * modes are ignored.  Layers are parallel HOST arrays of length nlayers; scale/shift as for g4d_linear_f32, but W[l]
+ * is in FRAGMENT order [CoutPad64/16][Kpad/16][64][4]: element ((t*(Kpad/16) + s)*64 + q*16 + i)*4 + e holds
+ * W[16t + i][16s + 4q + e], so that one B-fragment load of a wave is a contiguous 1 KB read.  pool over S in {16,32,64} rows applies to the last layer.  tap_out (or NULL): hidden layer
  * `tap_layer`'s output is also stored, rows x tap_ld. */
 int g4d_mlp_stack_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
                       const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
