@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the workload the CPU oracle is timed on")
     ap.add_argument("--no-lbs", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE config 3: shared-MLP operands in bf16 (fp32 accumulate); default fp32 = config 2")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
                                                        "exercising the multi-rank path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -72,8 +74,8 @@ def build_workload(device, streams, with_lbs):
     return model, clouds, lbs_in
 
 
-def one_step(model, cloud, lbs_in, slot):
-    out = model.forward_fused(cloud)
+def one_step(model, cloud, lbs_in, slot, precision="fp32"):
+    out = model.forward_fused(cloud, precision=precision)
     if lbs_in is not None:
         G, smpl, poses = lbs_in
         betas, pose = poses[slot]
@@ -186,7 +188,7 @@ def main():
         for w in range(max(args.warmup, 1)):
             s = w % ns
             with torch.cuda.stream(streams[s]):
-                one_step(model, clouds[s], lbs_in, s)
+                one_step(model, clouds[s], lbs_in, s, args.precision)
         torch.cuda.synchronize()
         graphs = None
         if not args.no_graph:
@@ -194,7 +196,7 @@ def main():
             for s in range(ns):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=streams[s]):
-                    one_step(model, clouds[s], lbs_in, s)
+                    one_step(model, clouds[s], lbs_in, s, args.precision)
                 graphs.append(g)
             for s in range(ns):  # one untimed replay each
                 with torch.cuda.stream(streams[s]):
@@ -215,7 +217,7 @@ def main():
                 if graphs is not None:
                     graphs[s].replay()
                 else:
-                    one_step(model, clouds[s], lbs_in, s)
+                    one_step(model, clouds[s], lbs_in, s, args.precision)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -232,7 +234,7 @@ def main():
             "metric": "point-cloud frames/s (FPS+ball_query+SA-MLP+LBS), B=8 N=8192",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16 MLP operands / f32 accumulate, sampling, LBS", "data": "synthetic",
             "config": {"workload": "cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32"
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),
                        "frames_per_step": B_CLOUDS, "batches_in_flight": ns, "hipgraph": graphs is not None,

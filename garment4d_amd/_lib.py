@@ -33,6 +33,8 @@ SIGNATURES = {
     "g4d_gcn_linear_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_mlp_stack_f32": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp,
                           _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
+    "g4d_mlp_stack_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp,
+                           _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_wave_f32": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp,
                          _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_pool_rows_f32": [_I, _I, _I, _vp, _I, _vp, _I, _I, _I, _vp],

@@ -68,10 +68,20 @@ class Pointnet2MSGSEG(nn.Module):
         sem_logits = self.FC_layer(l_features[0]).transpose(1, 2).contiguous()
         return middle, sem_logits, l_features, l_xyz
 
-    def forward_fused(self, pointcloud: torch.Tensor, channel_major: bool = False):
+    def forward_fused(self, pointcloud: torch.Tensor, channel_major: bool = False, precision: str = "fp32"):
         """Eval-mode forward on the fused kernels.  Features are point-major (B, N_l, C_l) unless
-        `channel_major` (then converted to the reference's (B, C_l, N_l) at the boundary)."""
-        assert not self.training
+        `channel_major` (then converted to the reference's (B, C_l, N_l) at the boundary).
+        precision="bf16" (BASELINE config 3) runs the shared MLPs with bf16 operands / fp32 accumulation; sampling,
+        grouping, interpolation weights and all tensors crossing the API stay fp32."""
+        assert not self.training and precision in ("fp32", "bf16")
+        prev = fused.PRECISION
+        fused.PRECISION = precision
+        try:
+            return self._forward_fused(pointcloud, channel_major)
+        finally:
+            fused.PRECISION = prev
+
+    def _forward_fused(self, pointcloud, channel_major):
         xyz = pointcloud[..., 0:3].contiguous()
         feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None  # already point-major
         l_xyz, l_feats = [xyz], [feats]

@@ -38,7 +38,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "Wf", "scale", "shift", "K", "Kpad", "Cout", "relu")
+    __slots__ = ("W", "Wf", "Wf16", "scale", "shift", "K", "Kpad", "Cout", "relu")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -54,7 +54,9 @@ class PackedLayer:
         # fragment order for the LDS-resident kernels: [16-channel tile][k-step of 16][lane = fq*16+fi][4 consecutive k]
         # -> one MFMA B-fragment load of a wave is ONE contiguous 1 KB read instead of 16 half cache lines
         Wf = W.view(cpad // 16, 16, kpad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
-        self.W, self.Wf, self.scale, self.shift = W, Wf, sc, sh
+        # bf16 copy (RNE) in the fragment order of v_mfma_f32_16x16x32_bf16: [tile][k-step of 32][lane = fq*16+fi][8 k]
+        Wf16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+        self.W, self.Wf, self.Wf16, self.scale, self.shift = W, Wf, Wf16, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
 
 
@@ -140,14 +142,26 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
 _MAX_STACK_LDS = 150 * 1024
 
 
-def stack_fits(layers, pool, S):
-    """Can these packed layers run as ONE g4d_mlp_stack_f32 launch? (<= 4 layers, hidden widths <= 128, LDS budget,
-    pool window 16/32/64)."""
+PRECISION = "fp32"  # "bf16": MLP operands in bf16 (cfg3), set per call through encoder.forward_fused(precision=...)
+
+
+_BF16_MIN_ROWS = 8192  # below 128 workgroups of 64 rows the one-launch bf16 stack leaves the chip idle: stay on the fp32 path
+
+
+def _use_bf16(rows):
+    return PRECISION == "bf16" and (rows is None or rows >= _BF16_MIN_ROWS)
+
+
+def stack_fits(layers, pool, S, rows=None):
+    """Can these packed layers run as ONE stack launch? (<= 4 layers, LDS budget, pool window 16/32/64).  In bf16 mode
+    the activations take 2 bytes in LDS, so wider stacks fit -- but only launches with >= 8192 rows use that kernel."""
     if not (1 <= len(layers) <= 4) or (pool and S not in (16, 32, 64)):
         return False
     w = [0, 0]
     for l, L in enumerate(layers):
         w[l & 1] = max(w[l & 1], L.Kpad)
+    if _use_bf16(rows):
+        return 2 * 64 * (w[0] + 8 + w[1] + 8) <= _MAX_STACK_LDS
     return 4 * 64 * (w[0] + 4 + w[1] + 4) <= _MAX_STACK_LDS
 
 
@@ -185,6 +199,13 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
         cV, rowptr, colidx, vals = csr
         cr, cc, cv = rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr()
     tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
+    if _use_bf16(rows):
+        W16 = PA(*[L.Wf16.data_ptr() for L in layers])
+        _lib.call("g4d_mlp_stack_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
+                  idd, ii, cV, cr, cc, cv, n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
+                  ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
+                  ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
+        return out
     if tap is None and wave_fits(layers, pool, S):
         _lib.call("g4d_mlp_wave_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
                   idd, ii, cV, cr, cc, cv, n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
@@ -285,7 +306,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
                           _ptr(feats_pm), idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                           L.shift.data_ptr(), L.relu, pl, o.data_ptr(), o.shape[-1], c0, stream)
 
-            if USE_STACK and stack_fits(layers, pool, S):
+            if USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
                 mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
                           group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))
             else:
@@ -305,7 +326,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
                       idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), L.relu, pl,
                       o.data_ptr(), o.shape[-1], c0, stream)
 
-        if USE_STACK and stack_fits(layers, pool, N):
+        if USE_STACK and stack_fits(layers, pool, N, rows=B * N):
             mlp_stack(1, B * N, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=N,
                       group=(N, 1, C, use_xyz, xyz, zero_c, feats_pm, idx))
         else:
@@ -350,12 +371,12 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
         # FP stack + FC head in one launch; the FP output is tapped to HBM (it is returned to the caller too)
         hl = pack_conv_stack(head)
         allL = layers + hl
-        if USE_STACK and stack_fits(allL, 0, 1):
+        if USE_STACK and stack_fits(allL, 0, 1, rows=B * n):
             logits = torch.empty((B, n, hl[-1].Cout), dtype=torch.float32, device=unknown.device)
             mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
                       tap=(len(layers) - 1, out.view(B * n, -1)))
             return out, logits
-    if USE_STACK and stack_fits(layers, 0, 1):
+    if USE_STACK and stack_fits(layers, 0, 1, rows=B * n):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
     elif layers[0].Cout > 64:
         # wide FP level: every 64-channel tile of the first layer would redo the interpolation -> materialise the
@@ -378,7 +399,7 @@ def conv_stack_forward(stack, x_pm):
     B, N, C = x_pm.shape
     h = _chk(x_pm).view(B * N, C)
     layers = pack_conv_stack(stack)
-    if USE_STACK and stack_fits(layers, 0, 1):
+    if USE_STACK and stack_fits(layers, 0, 1, rows=B * N):
         out = torch.empty((B * N, layers[-1].Cout), dtype=torch.float32, device=x_pm.device)
         mlp_stack(0, B * N, C, layers, out, X=h, ldx=C)
         return out.view(B, N, -1)

@@ -135,6 +135,18 @@ int g4d_mlp_stack_f32(int mode, long long rows, int K0, const float *X, int ldx,
                       const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out,
                       int tap_ld, g4d_stream_t stream);
 
+/* bf16 variant of g4d_mlp_stack_f32 (BASELINE config 3: bf16 MLP operands, fp32 accumulate / affine / pooling / I/O):
+ * W[l] is bf16 in fragment order [CoutPad64/16][Kpad/32][64][8] -- element ((t*(Kpad/32) + s)*64 + q*16 + i)*8 + e
+ * holds W[16t + i][32s + 8q + e]; activations are rounded to bf16 (RNE) between layers.  Wide stacks fit too
+ * (LDS holds 2 bytes per activation).  garment4d_amd/csrc/mlp_stack_bf16.hip. */
+int g4d_mlp_stack_bf16(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                       const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                       int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int Vg,
+                       const int *rowptr, const int *colidx, const float *vals, int nlayers,
+                       const unsigned short *const *W, const float *const *scale, const float *const *shift,
+                       const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
+                       int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream);
+
 /* Wave-autonomous variant of g4d_mlp_stack_f32 for narrow stacks (every hidden width <= 64): each wave takes 64 rows
  * through all layers with no workgroup barrier (garment4d_amd/csrc/mlp_wave.hip).  Same arguments, no tap. */
 int g4d_mlp_wave_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,

@@ -17,6 +17,16 @@ F32 = np.float32
 BN_EPS = 1e-5  # torch.nn.BatchNorm default
 
 
+def bf16_round(a):
+    """Round fp32 to bf16 (round-to-nearest-even), returned as fp32 -- emulates the operands of the bf16 MFMA path."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return r.view(np.float32)
+
+
+BF16 = False  # set True (tests) to emulate the cfg3 bf16 path: conv operands rounded to bf16, everything else fp32
+
+
 def shared_mlp(x, sd, prefix="", training=False, relu=None):
     """x (B,C,P,S) -> (B,Cout,P,S).  sd: state-dict slice; layers `<prefix>layer{i}.conv.weight`
     (Cout,Cin,1,1), optional `.conv.bias`, optional `.bn.bn.{weight,bias,running_mean,running_var}`."""
@@ -25,6 +35,8 @@ def shared_mlp(x, sd, prefix="", training=False, relu=None):
     while f"{prefix}layer{i}.conv.weight" in sd:
         w = sd[f"{prefix}layer{i}.conv.weight"].astype(F32)
         w = w.reshape(w.shape[0], w.shape[1])
+        if BF16:
+            w, x = bf16_round(w), bf16_round(x)
         y = np.einsum("oc,bcps->bops", w, x, dtype=F32).astype(F32)
         bkey = f"{prefix}layer{i}.conv.bias"
         if bkey in sd:

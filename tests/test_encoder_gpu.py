@@ -45,3 +45,32 @@ def test_encoder_state_dict_keys_match_reference_layout():
         assert k in keys, k
     assert model.state_dict()["SA_modules.1.mlps.0.layer0.conv.weight"].shape == (32, 99, 1, 1)
     assert model.state_dict()["FP_modules.2.mlp.layer0.conv.weight"].shape == (512, 576, 1, 1)
+
+
+def test_encoder_bf16_vs_bf16_emulating_oracle(monkeypatch):
+    """BASELINE config 3 precision: MLP operands bf16 (RNE), fp32 accumulate.  Against the oracle emulating exactly that
+    (weights and layer inputs rounded to bf16) the bound is tight; against the fp32 oracle it is the bf16 bound."""
+    B, N = 2, 2048
+    xyz = syn.unit_cloud(B, N, seed=9)
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=4).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    want32_logits, want32_f, want_xyz = MO.encoder_forward(xyz, sd)
+    monkeypatch.setattr(MO, "BF16", True)
+    want_logits, want_f, _ = MO.encoder_forward(xyz, sd)
+    model = model.cuda()
+    with torch.no_grad():
+        _, logits, l_f, l_xyz = model.forward_fused(torch.from_numpy(xyz).cuda(), channel_major=True, precision="bf16")
+    for lvl in range(1, 4):
+        assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl])  # sampling is fp32: bit-exact
+    # the scale/shift fold differs from the un-fused BN by fp32 rounding, which flips the bf16 rounding of an activation
+    # now and then (1 bf16 ulp = 2^-8 relative) and the flips compound over the ~15 layers below level 0: tolerance
+    # 2e-2 of the tensor scale against the bf16-emulating oracle, 5e-2 against the pure fp32 oracle
+    errs = []
+    for lvl in range(0, 4):
+        e16, e32 = rel_err(l_f[lvl].cpu().numpy(), want_f[lvl]), rel_err(l_f[lvl].cpu().numpy(), want32_f[lvl])
+        errs.append((lvl, e16, e32))
+        assert e16 < 2e-2, f"level {lvl} vs bf16-emulating oracle: {e16}"
+        assert e32 < 5e-2, f"level {lvl} vs fp32 oracle: {e32}"
+    print("bf16 path rel. errors (level, vs bf16-emulating oracle, vs fp32 oracle):", errs)
+    assert rel_err(logits.cpu().numpy(), want_logits) < 2e-2
+    assert rel_err(logits.cpu().numpy(), want32_logits) < 5e-2
