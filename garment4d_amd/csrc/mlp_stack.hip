@@ -41,24 +41,28 @@ struct StackArgs {
     int tap_ld;
 };
 
-template <int MODE>
+// MT = accumulator tiles per wave: the workgroup takes ROWS = 32*MT rows (64, or 32 to halve the LDS footprint and
+// double the resident workgroups when the pool window allows it).
+template <int MODE, int MT>
 __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
+    constexpr int ROWS = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *buf0 = smem;
-    float *buf1 = smem + 64 * s.ld0;
+    float *buf1 = smem + ROWS * s.ld0;
     const LinearArgs &a = s.in;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cs = wave & 3;   // 16-channel slice of the 64-channel slab
-    const int rh = wave >> 2;  // row half: rows [32 rh, 32 rh + 32) = accumulator tiles 2 rh, 2 rh + 1
-    const int row0 = blockIdx.x * 64;
+    const int rh = wave >> 2;  // row half: rows [16 MT rh, 16 MT (rh + 1))
+    const int row0 = blockIdx.x * ROWS;
     const int fi = lane & 15, fq = lane >> 4;
 
     // ---- phase 0: gather the input tile [64][K0pad] into buf0 (zeros beyond K and beyond the last row)
     {
-        const int lr = t >> 3;  // 8 threads per row
+        constexpr int TPR = 512 / ROWS;  // threads per row: 8 (64 rows) or 16 (32 rows)
+        const int lr = t / TPR;
         const RowCtx<MODE> ctx = make_ctx<MODE>(a, row0 + lr);
         const int K0pad = s.layer[0].Kpad;
-        for (int k = (t & 7) * 4; k < K0pad; k += 32) {
+        for (int k = (t % TPR) * 4; k < K0pad; k += TPR * 4) {
             f32x4 v;
             if (MODE == LOAD_DIRECT && ctx.valid && k + 3 < a.K && (a.ldx & 3) == 0) {
                 v = *reinterpret_cast<const f32x4 *>(a.X + (size_t)(row0 + lr) * a.ldx + k);
@@ -89,23 +93,24 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
             const int ch = sl * 64 + cs * 16 + fi;
             const bool wave_live = sl * 64 + cs * 16 < L.Cout;   // wave-uniform: has real channels
             const bool wave_writes = sl * 64 + cs * 16 < wcols;  // wave-uniform: columns somebody reads
-            f32x4 acc[2];
-            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 bf = bnext;
             if (wave_live) {
                 const float *wp = L.W + (size_t)(sl * 4 + cs) * (L.Kpad >> 4) * 256 + lane * 4;
-                const float *ap = in + (rh * 32 + fi) * ldin + fq * 4;
+                const float *ap = in + (rh * 16 * MT + fi) * ldin + fq * 4;
                 for (int kk = 0; kk < L.Kpad; kk += 16) {
                     const f32x4 bcur = bf;
                     if (kk + 16 < L.Kpad) bf = *reinterpret_cast<const f32x4 *>(wp + (kk + 16) * 16);  // next W fragment, ahead of the MFMAs
-                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap + kk);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ap + 16 * ldin + kk);
+                    f32x4 av[MT];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], bcur[e], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], bcur[e], acc[1], 0, 0, 0);
-                    }
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4 *>(ap + mt * 16 * ldin + kk);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bcur[e], acc[mt], 0, 0, 0);
                 }
             }
             {   // first W fragment of the NEXT job (next slab, or slab 0 of the next layer): issued before the epilogue
@@ -118,7 +123,7 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
             }
             const float sc = L.scale[ch], sh = L.shift[ch];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float y = acc[mt][r] * sc + sh;
@@ -130,16 +135,16 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
                 // W rows, scale and shift are zero padded), optionally tap to HBM
                 if (wave_writes) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) out[(rh * 32 + mt * 16 + fq * 4 + r) * ldout + ch] = acc[mt][r];
+                        for (int r = 0; r < 4; ++r) out[(rh * 16 * MT + mt * 16 + fq * 4 + r) * ldout + ch] = acc[mt][r];
                 }
                 if (l == s.tap_layer && ch < L.Cout) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int row = row0 + rh * 32 + mt * 16 + fq * 4 + r;
+                            const int row = row0 + rh * 16 * MT + mt * 16 + fq * 4 + r;
                             if (row < a.rows) s.tap_out[(size_t)row * s.tap_ld + ch] = acc[mt][r];
                         }
                 }
@@ -149,17 +154,17 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
             const bool ch_ok = ch < L.Cout;
             if (a.pool == 0) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = row0 + rh * 32 + mt * 16 + fq * 4 + r;
+                        const int row = row0 + rh * 16 * MT + mt * 16 + fq * 4 + r;
                         if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = acc[mt][r];
                     }
             } else {
                 const bool is_max = a.pool == 1;
-                float v[2];
+                float v[MT];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
                                      : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
                     const float y = __shfl_xor(x, 16);
@@ -172,24 +177,25 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
                 if (a.S == 16) {  // one neighbourhood per accumulator tile
                     if (lane < 16 && ch_ok) {
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            const int orow = (row0 >> 4) + rh * 2 + mt;
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const int orow = (row0 >> 4) + rh * MT + mt;
                             if (orow * 16 < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = v[mt] * inv;
                         }
                     }
                 } else {
-                    float x = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];  // this wave's 32 rows
-                    if (a.S == 32) {
-                        const int orow = (row0 >> 5) + rh;
-                        if (lane < 16 && ch_ok && orow * 32 < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = x * inv;
-                    } else {  // S == 64: the two row halves meet in LDS (`out` is free during the last layer)
+                    float x = v[0];  // this wave's 16*MT rows
+                    if constexpr (MT == 2) x = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];
+                    if (a.S == 16 * MT) {
+                        const int orow = row0 / a.S + rh;
+                        if (lane < 16 && ch_ok && orow * a.S < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = x * inv;
+                    } else {  // S == 32*MT == ROWS: the two row halves meet in LDS (`out` is free during the last layer)
                         if (rh == 1 && lane < 16) out[cs * 16 + lane] = x;
                         __syncthreads();
                         if (rh == 0 && lane < 16) {
                             const float y = out[cs * 16 + lane];
                             x = is_max ? fmaxf(x, y) : x + y;
-                            const int orow = row0 >> 6;
-                            if (ch_ok && orow * 64 < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = x * inv;
+                            const int orow = row0 / a.S;
+                            if (ch_ok && orow * a.S < a.rows) a.out[(size_t)orow * a.ldo + a.col0 + ch] = x * inv;
                         }
                         __syncthreads();
                     }
@@ -246,22 +252,32 @@ extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
     G4D_REQUIRE(Kpad[0] >= K0, "g4d_mlp_stack_f32: Kpad[0] < K0");
     s.ld0 = w0 + 4;
     s.ld1 = w1 + 4;
-    const size_t lds = sizeof(float) * 64 * (size_t)(s.ld0 + s.ld1);
-    G4D_REQUIRE(lds <= 150 * 1024, "g4d_mlp_stack_f32: stack too wide for LDS (%zu bytes)", lds);
+    // 32-row workgroups (half the LDS, twice the workgroups) are available behind G4D_STACK_MT=1
+    static const int mt_env = getenv("G4D_STACK_MT") ? atoi(getenv("G4D_STACK_MT")) : 0;  // tuning hook: 1 | 2 | 0 (auto)
+    const size_t lds64 = sizeof(float) * 64 * (size_t)(s.ld0 + s.ld1);
+    G4D_REQUIRE(lds64 <= 150 * 1024, "g4d_mlp_stack_f32: stack too wide for LDS (%zu bytes)", lds64);
+    const bool can32 = !pool || S <= 32;
+    const bool want32 = mt_env == 1;  // measured: no gain from 32-row workgroups on any cfg2 stack, 64 rows stays the default
+    const int mt = (can32 && want32) ? 1 : 2;
+    const size_t lds = lds64 / 2 * mt;
     s.tap_layer = tap_out ? tap_layer : -1;
     s.tap_out = tap_out; s.tap_ld = tap_ld;
     G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_stack_f32: tap must be a hidden layer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((unsigned)((rows + 63) / 64)), block(512);
+    const int rows_per_wg = 32 * mt;
+    dim3 grid((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), block(512);
 #define G4D_LAUNCH_STACK(M)                                                                                        \
     {                                                                                                              \
         static bool attr = false;                                                                                  \
         if (!attr) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_kernel<M>),                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_kernel<M, 2>),                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_kernel<M, 1>),                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
             attr = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL(mlp_stack_kernel<M>, grid, block, lds, st, s);                                          \
+        if (mt == 2) hipLaunchKernelGGL((mlp_stack_kernel<M, 2>), grid, block, lds, st, s);                        \
+        else hipLaunchKernelGGL((mlp_stack_kernel<M, 1>), grid, block, lds, st, s);                                \
     }
     switch (mode) {
         case LOAD_DIRECT: G4D_LAUNCH_STACK(LOAD_DIRECT) break;
