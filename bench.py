@@ -242,7 +242,7 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roof["fps"], "roofline_mfma": roof["mlp"],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (same host cores at every N)
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames, with_lbs)
         print(json.dumps(line))
     if dist is not None:
