@@ -1,0 +1,99 @@
+// Kernels of the garment skinning around the hot path (/root/reference/modules/mesh_encoder.py:337-390):
+//   knn_blend_weights : inverse-distance blend of the K nearest body vertices' skinning weights (:339-347, :374-382)
+//   spmm_axpy_rows    : one Jacobi smoothing step  W <- W + coeff * (adj . W)  over the garment mesh (:385-390, x100)
+// Both HBM/L2-bound gathers with point-major rows; nothing is repeated/expanded the way the reference does it
+// (`.repeat(1, 1, K, 1)` of the (V, J) weight table followed by torch.gather materialises B*T x Vg x K x J floats).
+#include "g4d_common.h"
+
+namespace g4d {
+
+// out[f,v,:] = sum_k w_k * W[f, idx[c,v,k], :],  c = f / frames_per_clip,
+// w_k = (1/d_k with inf -> 0) / sum, again inf -> 0   (the reference's two isinf fix-ups, :342-345)
+// one wave per output row: lanes 0..J-1 own a joint, the K neighbours are walked with wave-uniform (idx, w).
+__global__ void __launch_bounds__(256) knn_blend_weights_kernel(long long rows, int vg, int v, int K, int J, int frames_per_clip,
+                                                               const float *__restrict__ W, const int *__restrict__ idx,
+                                                               const float *__restrict__ dists, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long f = row / vg;
+    const int gv = (int)(row - f * vg);
+    const long long c = f / frames_per_clip;
+    const int *ix = idx + ((size_t)c * vg + gv) * K;
+    const float *dd = dists + ((size_t)c * vg + gv) * K;
+    // pass 1: normaliser  sum_k (1/d_k, inf -> 0), lanes stride over k
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float w = 1.0f / dd[k];
+        if (__builtin_isinf(w)) w = 0.f;
+        s += w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    // pass 2: blend
+    const float *Wf = W + (size_t)f * v * J;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float w = 1.0f / dd[k];
+        if (__builtin_isinf(w)) w = 0.f;
+        w = w / s;
+        if (__builtin_isinf(w)) w = 0.f;
+        if (lane < J) acc += Wf[(size_t)ix[k] * J + lane] * w;  // (nn_W * interp).sum(-2), k ascending
+    }
+    if (lane < J) out[(size_t)row * J + lane] = acc;
+}
+
+// out[f,v,:] = S[f,v,:] + coeff * sum_u adj[v,u] * S[f,u,:]
+__global__ void __launch_bounds__(256) spmm_axpy_rows_kernel(long long rows, int vg, int c, const float *__restrict__ S,
+                                                            const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                                            const float *__restrict__ vals, float coeff, float *__restrict__ out) {
+    const int per_row = (c + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * per_row) return;
+    const long long row = gid / per_row;
+    const int c0 = (int)(gid - row * per_row) * 4;
+    const long long f = row / vg;
+    const int v = (int)(row - f * vg);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) {
+        const float a = vals[e];
+        const float *src = S + ((size_t)f * vg + colidx[e]) * c + c0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < c) acc[j] += a * src[j];
+    }
+    const float *self = S + (size_t)row * c + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < c) out[(size_t)row * c + c0 + j] = self[j] + coeff * acc[j];
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+
+extern "C" int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, int k, int j, const float *W, const int *idx,
+                                         const float *dists, float *out, g4d_stream_t stream) {
+    G4D_REQUIRE(frames >= 0 && frames_per_clip >= 1 && vg >= 0 && v > 0 && k >= 1 && j >= 1 && j <= 64,
+                "g4d_knn_blend_weights_f32: bad sizes (J <= 64)");
+    const long long rows = (long long)frames * vg;
+    if (rows == 0) return G4D_OK;
+    G4D_REQUIRE(W && idx && dists && out, "g4d_knn_blend_weights_f32: null pointer");
+    G4D_REQUIRE((rows + 3) / 4 < (1ll << 31), "g4d_knn_blend_weights_f32: too large");
+    hipLaunchKernelGGL(knn_blend_weights_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows,
+                       vg, v, k, j, frames_per_clip, W, idx, dists, out);
+    return check_launch("g4d_knn_blend_weights_f32");
+}
+
+extern "C" int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
+                                      const float *vals, float coeff, float *out, g4d_stream_t stream) {
+    G4D_REQUIRE(frames >= 0 && vg >= 0 && c >= 0, "g4d_spmm_axpy_rows_f32: negative size");
+    const long long rows = (long long)frames * vg;
+    if (rows == 0 || c == 0) return G4D_OK;
+    G4D_REQUIRE(S && rowptr && colidx && vals && out && S != out, "g4d_spmm_axpy_rows_f32: null or aliased pointer");
+    const long long work = rows * ((c + 3) / 4);
+    G4D_REQUIRE((work + 255) / 256 < (1ll << 31), "g4d_spmm_axpy_rows_f32: too large");
+    hipLaunchKernelGGL(spmm_axpy_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows,
+                       vg, c, S, rowptr, colidx, vals, coeff, out);
+    return check_launch("g4d_spmm_axpy_rows_f32");
+}

@@ -1,0 +1,84 @@
+"""Garment skinning by KNN-interpolated body weights -- the immediate caller of the LBS hot path
+(`PCALBSGarmentUseSegEncoderSeg.lbs_garment_interpolation`, /root/reference/modules/mesh_encoder.py:312-410).
+
+Same inputs / outputs as the reference method; `body_model.parents` and `self.adj_old` (the un-normalised,
+symmetrised garment-mesh adjacency, :299-303) are passed explicitly because this function is not a method of the model.
+Differences that do not change results: ONE K-nearest search serves the K, min(64,K) and K=1 queries of :321-324 (the
+sorted K=256 list contains the others as prefixes); the (V,J) weight table is never `.repeat`-ed K times -- the blend
+kernel gathers rows; the per-frame weights are blended with the clip's neighbour list without materialising the
+(B*T, Vg, K, J) tensor of :381-382.  Forward only.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import lbs as L
+from .gcn import _to_csr, normalize
+from .knn import KNN, knn_points
+
+
+def _blend(W, idx32, dists, frames_per_clip):
+    """W (F,V,J), idx32/dists (F/frames_per_clip, Vg, K) -> (F,Vg,J)."""
+    F_, V, J = W.shape
+    _, Vg, K = idx32.shape
+    out = torch.empty((F_, Vg, J), dtype=torch.float32, device=W.device)
+    _lib.call("g4d_knn_blend_weights_f32", F_, frames_per_clip, Vg, V, K, J, W.data_ptr(), idx32.data_ptr(), dists.data_ptr(),
+              out.data_ptr(), _lib.stream_ptr())
+    return out
+
+
+def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100):
+    """100 Jacobi steps  W <- W + coeff * ((D^-1 A - I) . W)  over the garment mesh (:385-390)."""
+    import scipy.sparse as sp
+    adj = normalize(adj_old) - sp.eye(adj_old.shape[0])
+    rowptr, colidx, vals, n = _to_csr(sp.csr_matrix(adj), nn_W.device)
+    F_, Vg, J = nn_W.shape
+    assert n == Vg
+    a, b = nn_W.contiguous(), torch.empty_like(nn_W)
+    st = _lib.stream_ptr()
+    for _ in range(iters):
+        _lib.call("g4d_spmm_axpy_rows_f32", F_, Vg, J, a.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), float(coeff),
+                  b.data_ptr(), st)
+        a, b = b, a
+    return a
+
+
+def lbs_garment_interpolation(pred_template_garment_v, Tpose_vertices, Tpose_root_joints, zeropose_vertices, parents, gt_pose,
+                              T_J_regressor, T_lbs_weights, adj_old, K=3):
+    """pred_template_garment_v (B,Vg,3); Tpose_vertices (B,[1,]V,3); Tpose_root_joints (B,[1,]3); zeropose_vertices (B,T,V,3);
+    gt_pose (B,T,72); T_J_regressor (B,T,J,V); T_lbs_weights (B,T,V,J); adj_old scipy sparse (Vg,Vg).
+    Returns (posed garment (B,T,Vg,3), nearest-neighbour KNN (K=1), un-posed garment repeated over T (B,T,Vg,3))."""
+    assert pred_template_garment_v.dim() == 3 and pred_template_garment_v.shape[2] == 3
+    assert gt_pose.dim() == 3 and gt_pose.shape[2] == 72
+    B, T = gt_pose.shape[0], gt_pose.shape[1]
+    dev = gt_pose.device
+    J = T_J_regressor.shape[2]
+    gt_pose_mat = L.batch_rodrigues(gt_pose.reshape(-1, 3).contiguous()).reshape(B * T, 24, 3, 3)
+    garment = (pred_template_garment_v + Tpose_root_joints.reshape(B, 3).unsqueeze(1)).contiguous()
+    body = Tpose_vertices.reshape(B, -1, 3).contiguous()
+    V = body.shape[1]
+    nnk = knn_points(garment, body, K=K)                      # :321
+    K64 = min(64, K)
+    idx_k, d_k = nnk.idx.int().contiguous(), nnk.dists
+    idx_64, d_64 = idx_k[..., :K64].contiguous(), d_k[..., :K64].contiguous()   # == knn_points(..., K=K64)  (:323)
+    nn1 = KNN(dists=d_k[..., :1].contiguous(), idx=nnk.idx[..., :1].contiguous(), knn=None)  # == knn_points(...)  (:324)
+
+    inv_pose = torch.zeros((B, 24, 3), dtype=torch.float32, device=dev)
+    inv_pose[:, 0, 0] = -np.pi / 2
+    inv_pose[:, 1, 1] = 0.15
+    inv_pose[:, 2, 1] = -0.15
+    inv_pose_mat = L.batch_rodrigues(inv_pose.reshape(-1, 3)).reshape(B, 24, 3, 3)
+    inv_J = L.vertices2jointsB(T_J_regressor[:, 0].contiguous(), body)
+    _, inv_A = L.batch_rigid_transform(inv_pose_mat, inv_J, parents)
+    inv_nn_W = _blend(T_lbs_weights[:, 0].contiguous(), idx_64, d_64, 1)          # (B,Vg,J)   :339-347
+    inv_garment = L.skin(inv_nn_W, inv_A, garment)                                 # :348, :361-362
+    inv_template_garment_v = inv_garment.reshape(B, 1, -1, 3).repeat(1, T, 1, 1).reshape(B * T, -1, 3).contiguous()
+
+    zero_v = zeropose_vertices.reshape(B * T, -1, 3).contiguous()
+    Jf = L.vertices2jointsB(T_J_regressor.reshape(B * T, J, V).contiguous(), zero_v)
+    _, A = L.batch_rigid_transform(gt_pose_mat, Jf, parents)
+    nn_W = _blend(T_lbs_weights.reshape(B * T, V, J).contiguous(), idx_k, d_k.contiguous(), T)   # (B*T,Vg,J)  :374-382
+    if K > 1:
+        nn_W = smooth_weights(nn_W, adj_old, 0.1, 100)                             # :385-390
+    verts = L.skin(nn_W, A, inv_template_garment_v)                                # :393, :406-408
+    return verts.reshape(B, T, -1, 3), nn1, inv_template_garment_v.reshape(B, T, -1, 3)

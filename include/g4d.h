@@ -209,6 +209,25 @@ int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const 
                           const float *posedirs, const float *weights, int weights_batched, const float *A,
                           float *v_posed_scratch, float *verts, g4d_stream_t stream);
 
+/* ---- callers around the hot path ---------------------------------------------- */
+
+/* K nearest neighbours, K <= 256: for every query (B,P1,3) the K points of (B,P2,3) that are smallest under
+ * (squared distance, index), ascending.  dists (B,P1,K) fp32 squared L2, idx (B,P1,K) int32.  Stands in for the
+ * un-vendored chamferdist.knn_points used by modules/mesh_encoder.py:321-324 (parity unpinned: dependency absent). */
+int g4d_knn_f32(int b, int p1, int p2, int k, const float *queries, const float *points, float *dists, int *idx,
+                g4d_stream_t stream);
+
+/* Inverse-distance blend of the K nearest body vertices' skinning weights (modules/mesh_encoder.py:339-347, 374-382):
+ * out (F,Vg,J) = sum_k w_k W[f, idx[c,v,k], :],  c = f / frames_per_clip,  w = normalised 1/d with the reference's two
+ * "inf -> 0" fix-ups.  W (F,V,J); idx / dists (F/frames_per_clip, Vg, K) from g4d_knn_f32.  J <= 64. */
+int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, int k, int j, const float *W, const int *idx,
+                              const float *dists, float *out, g4d_stream_t stream);
+
+/* One Jacobi smoothing step of the blended weights over the garment mesh (modules/mesh_encoder.py:385-390):
+ * out (F,Vg,C) = S + coeff * (adj (CSR) . S).  out must not alias S (ping-pong two buffers for the 100 steps). */
+int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
+                           const float *vals, float coeff, float *out, g4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
