@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) interp_concat_kernel(long long rows, int 
 __global__ void __launch_bounds__(256) spmm_rows_kernel(long long rows, int vg, int c, const float *__restrict__ S,
                                                        const int *__restrict__ rowptr, const int *__restrict__ colidx,
                                                        const float *__restrict__ vals, const float *__restrict__ bias,
-                                                       float *__restrict__ out) {
+                                                       int relu, float *__restrict__ out) {
     const int per_row = (c + 3) >> 2;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= rows * per_row) return;
@@ -247,7 +247,10 @@ __global__ void __launch_bounds__(256) spmm_rows_kernel(long long rows, int vg, 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (c0 + j < c) out[(size_t)row * c + c0 + j] = acc[j] + (bias ? bias[c0 + j] : 0.f);
+        if (c0 + j < c) {
+            const float y = acc[j] + (bias ? bias[c0 + j] : 0.f);
+            out[(size_t)row * c + c0 + j] = relu ? fmaxf(y, 0.f) : y;
+        }
 }
 
 static inline int launch_group(int b, int c, int n, long long e_total, const float *points, const int *idx, float *out,
@@ -372,7 +375,7 @@ extern "C" int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const 
 }
 
 extern "C" int g4d_spmm_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
-                                 const float *vals, const float *bias, float *out, g4d_stream_t stream) {
+                                 const float *vals, const float *bias, int relu, float *out, g4d_stream_t stream) {
     G4D_DIMS_OK("g4d_spmm_rows_f32", frames, vg, c);
     const long long rows = (long long)frames * vg;
     if (rows == 0 || c == 0) return G4D_OK;
@@ -380,6 +383,6 @@ extern "C" int g4d_spmm_rows_f32(int frames, int vg, int c, const float *S, cons
     const long long work = rows * ((c + 3) / 4);
     G4D_REQUIRE((work + 255) / 256 < (1ll << 31), "g4d_spmm_rows_f32: too large");
     hipLaunchKernelGGL(spmm_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, G4D_STREAM(stream), rows, vg, c, S, rowptr,
-                       colidx, vals, bias, out);
+                       colidx, vals, bias, relu, out);
     return check_launch("g4d_spmm_rows_f32");
 }

@@ -68,11 +68,15 @@ def temporal_attention(last_feat_local: torch.Tensor, frame_ids_local: torch.Ten
     """The reference's temporal attention (mesh_encoder.py:467-476) for frame-sharded features: k, v of ALL T frames
     of a clip are needed, so the per-frame features are all-gathered once, q/k/v are computed locally, and each rank
     evaluates the softmax(q k^T / sqrt(T)) v rows of its own frames.
-    last_feat_local (f_local, Vg, C); qkv: a Linear(Vg*C -> 3*Vg*C)-like callable applied to flattened frames."""
-    feats = allgather_frames(last_feat_local, n_frames, group)          # (F, Vg, C)
+    last_feat_local (f_local, Vg, C); qkv: the per-vertex Linear(C -> 3C) (`temporal_qkv_*`, bias-free), any callable
+    mapping (..., C) -> (..., 3C).  The two T x T x (Vg*C) contractions are plain library GEMMs (torch.matmul)."""
+    feats = allgather_frames(last_feat_local, n_frames, group) if (dist.is_initialized() and group is not False) else last_feat_local
     F_, Vg, C = feats.shape
     n_clips = F_ // T
-    q, k, v = qkv(feats.reshape(n_clips, T, Vg * C)).chunk(3, dim=-1)   # each (clips, T, Vg*C)
-    att = torch.softmax(torch.matmul(q, k.transpose(1, 2)) / (T ** 0.5), dim=-1)
+    q, k, v = qkv(feats.reshape(n_clips, T, Vg, C)).chunk(3, dim=-1)              # each (clips, T, Vg, C)
+    q = q.reshape(n_clips, T, Vg * C)
+    k = k.reshape(n_clips, T, Vg * C)
+    v = v.reshape(n_clips, T, Vg * C)
+    att = torch.softmax(torch.matmul(q, k.transpose(1, 2)).reshape(n_clips, T, T) / (T ** 0.5), dim=-1)
     out = torch.matmul(att, v).reshape(F_, Vg, C)
     return out[frame_ids_local.long()]

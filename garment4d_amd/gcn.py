@@ -116,8 +116,9 @@ class GraphConvolution(torch.nn.Module):
             self._g4d_packed = hit
         return hit[1]
 
-    def forward(self, input, adj, ismlp=False):
-        """input (B,N,Fin) or (N,Fin); adj sparse (N,N).  ismlp=True skips the aggregation (layers.py:43,51)."""
+    def forward(self, input, adj, ismlp=False, relu=False):
+        """input (B,N,Fin) or (N,Fin); adj sparse (N,N).  ismlp=True skips the aggregation (layers.py:43,51).
+        relu=True (extension) fuses the caller's F.relu into the SpMM epilogue."""
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
             raise NotImplementedError("garment4d_amd.gcn.GraphConvolution is forward-only: call it under torch.no_grad()")
         if not (input.is_cuda and input.dtype == torch.float32):
@@ -137,7 +138,10 @@ class GraphConvolution(torch.nn.Module):
             assert n == N, "adjacency size does not match the number of vertices"
             support = linear(x.view(B * N, Fin), L_support)                          # layers.py:42  matmul(input, weight)
             _lib.call("g4d_spmm_rows_f32", B, N, self.out_features, support.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(),
-                      vals.data_ptr(), 0 if bias is None else bias.data_ptr(), out.data_ptr(), _lib.stream_ptr())  # :46-55
+                      vals.data_ptr(), 0 if bias is None else bias.data_ptr(), int(bool(relu)), out.data_ptr(), _lib.stream_ptr())  # :46-55
+            relu = False
+        if relu:
+            out.clamp_(min=0)
         return out[0] if squeeze else out
 
     def __repr__(self):

@@ -1,0 +1,137 @@
+"""The temporal garment refinement loop around the hot path -- `PCALBSGarmentUseSegEncoderSeg.forward`'s
+ITERATION rounds (/root/reference/modules/mesh_encoder.py:445-486) with the reference's sub-module names
+(`body_positional_encoding{0,1,2}`, `garment_positional_encoding{0,1,2}`, `temporal_qkv_{1,2}`,
+`lbs_graph_regress{1,2,3}`) so that the corresponding slices of a reference checkpoint load by key.
+
+Per round: 3 body + 3 garment positional encoders (ball query -> grouped [xyz-offset | feature] rows -> Linear-ReLU-Linear
+-> max over the samples: ONE fused MFMA stack launch each, written straight into its 32-column slot of the GCN input),
+temporal attention over the T frames of a clip (rounds 1, 2), four GCN layers, residual update of the vertices.
+Frame sharding: pass `group` + `frame_ids`; the only exchange is the all-gather inside dist.temporal_attention.
+Inference only.  SURVEY.md section 8f rank 1 -- parity unpinned (mesh_encoder.py cannot be imported here), checked
+against oracle/refine_oracle.py."""
+import torch
+import torch.nn as nn
+
+from . import dist as gdist
+from . import fused
+from .gcn import GraphConvolution
+
+
+def _pack_linear_mlp(seq):
+    """nn.Sequential(Linear, ReLU, Linear) -> packed layers (cached on the module)."""
+    key = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    hit = getattr(seq, "_g4d_packed", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    layers, mods = [], list(seq.children())
+    with torch.no_grad():
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Linear):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                dev = m.weight.device
+                bias = m.bias.detach().float() if m.bias is not None else torch.zeros(m.out_features, device=dev)
+                layers.append(fused.PackedLayer(m.weight.detach().float(), torch.ones(m.out_features, device=dev), bias, relu=relu))
+    seq._g4d_packed = (key, layers)
+    return layers
+
+
+def positional_encoding(mlp, radius, nsample, xyz, new_xyz, feats_pm, out, col0):
+    """QueryAndGroup(radius, nsample, use_xyz=True) -> mlp -> max over samples, into out[..., col0:col0+Cout].
+    xyz (F,N,3) cloud, new_xyz (F,Vg,3) queries, feats_pm (F,N,C) point-major."""
+    F_, N, _ = xyz.shape
+    Vg = new_xyz.shape[1]
+    C = feats_pm.shape[2]
+    layers = _pack_linear_mlp(mlp)
+    idx = fused.ball_query_msg([radius], [nsample], xyz, new_xyz)[0]
+    rows = F_ * Vg * nsample
+    grp = (N, Vg, C, 1, xyz, new_xyz, feats_pm, idx)
+    if nsample in (16, 32, 64):
+        fused.mlp_stack(1, rows, 3 + C, layers, out, col0=col0, pool=1, S=nsample, group=grp)
+    else:  # 8 / 4 samples: un-pooled stack output, then the row-pool kernel
+        tmp = torch.empty((rows, layers[-1].Cout), dtype=torch.float32, device=xyz.device)
+        fused.mlp_stack(1, rows, 3 + C, layers, tmp, pool=0, S=nsample, group=grp)
+        fused._pool_rows(tmp, F_ * Vg, nsample, out, col0, True)
+
+
+class GarmentRefinementHead(nn.Module):
+    def __init__(self, garment_name="Tshirt", iteration=3, garment_pe_input_dim=(3 + 64, 3 + 32 + 64, 3 + 128 + 256)):
+        super().__init__()
+        self.iteration = iteration
+        self.garment_radius_list = [0.1, 0.2, 0.4]
+        self.garment_sample_num_list = [32, 8, 4] if garment_name == "Trousers" else [32, 16, 8]   # mesh_encoder.py:180-189
+        self.body_radius_list = [0.1, 0.2, 0.4]
+        self.body_sample_num_list = [8, 16, 32]
+        self.feat_num = 32
+        self.hidden_dim = 128
+        self.graph_start_feature_dim = self.feat_num * 6 + 3
+
+        def pe(cin):
+            return nn.Sequential(nn.Linear(cin, self.feat_num), nn.ReLU(), nn.Linear(self.feat_num, self.feat_num))
+
+        self.body_positional_encoding0, self.body_positional_encoding1, self.body_positional_encoding2 = pe(6), pe(6), pe(6)
+        self.garment_positional_encoding_input_dim = list(garment_pe_input_dim)
+        self.garment_positional_encoding0 = pe(garment_pe_input_dim[0])
+        self.garment_positional_encoding1 = pe(garment_pe_input_dim[1])
+        self.garment_positional_encoding2 = pe(garment_pe_input_dim[2])
+        self.temporal_qkv_1 = nn.Linear(self.hidden_dim, self.hidden_dim * 3, bias=False)
+        self.temporal_qkv_2 = nn.Linear(self.hidden_dim, self.hidden_dim * 3, bias=False)
+
+        def gcn(first):
+            return nn.ModuleList([GraphConvolution(first, self.hidden_dim), GraphConvolution(self.hidden_dim, self.hidden_dim),
+                                  GraphConvolution(self.hidden_dim, self.hidden_dim), GraphConvolution(self.hidden_dim, 3)])
+
+        self.lbs_graph_regress1 = gcn(self.graph_start_feature_dim)
+        self.lbs_graph_regress2 = gcn(self.graph_start_feature_dim + self.hidden_dim)
+        self.lbs_graph_regress3 = gcn(self.graph_start_feature_dim + self.hidden_dim)
+
+    def _qkv(self, lin):
+        key = (lin.weight.data_ptr(), lin.weight._version)
+        hit = getattr(lin, "_g4d_packed", None)
+        if hit is None or hit[0] != key:
+            dev = lin.weight.device
+            with torch.no_grad():
+                L = fused.PackedLayer(lin.weight.detach().float(), torch.ones(lin.out_features, device=dev),
+                                      torch.zeros(lin.out_features, device=dev), relu=False)
+            hit = (key, L)
+            lin._g4d_packed = hit
+        L = hit[1]
+        return lambda x: fused.linear(x.reshape(-1, x.shape[-1]).contiguous(), L).view(*x.shape[:-1], -1)
+
+    def forward(self, cur_garment_v, body_v, body_vn, garment_v_list, garment_f_list, adj, nbatch, T, group=None, frame_ids=None):
+        """cur_garment_v (F,Vg,3) LBS-posed garment; body_v / body_vn (F,V,3) body vertices / normals; garment_v_list[i] (F,N_i,3)
+        and garment_f_list[i] (F,N_i,C_i) POINT-major encoder levels; adj the normalised garment adjacency; F = local frames
+        (= nbatch*T without sharding; with sharding pass the process group and the global ids of the local frames).
+        Returns the list of refined vertices per round (mesh_encoder.py:485)."""
+        assert not torch.is_grad_enabled(), "GarmentRefinementHead is inference-only: call under torch.no_grad()"
+        body_pe = [self.body_positional_encoding0, self.body_positional_encoding1, self.body_positional_encoding2]
+        garm_pe = [self.garment_positional_encoding0, self.garment_positional_encoding1, self.garment_positional_encoding2]
+        qkvs = [self.temporal_qkv_1, self.temporal_qkv_2]
+        regress = [self.lbs_graph_regress1, self.lbs_graph_regress2, self.lbs_graph_regress3]
+        F_, Vg, _ = cur_garment_v.shape
+        dev = cur_garment_v.device
+        if frame_ids is None:
+            frame_ids = torch.arange(F_, device=dev)
+        n_frames = nbatch * T
+        cur = cur_garment_v.contiguous()
+        outs, lbs_iter_feat = [], []
+        for it in range(self.iteration):
+            width = self.graph_start_feature_dim + (self.hidden_dim if it > 0 else 0)
+            feat = torch.empty((F_, Vg, width), dtype=torch.float32, device=dev)
+            feat[..., :3] = cur                                                      # cur_positional_encoding (:465)
+            col = 3
+            for i in range(3):                                                       # :452-457
+                positional_encoding(body_pe[i], self.body_radius_list[i], self.body_sample_num_list[i], body_v, cur, body_vn, feat, col)
+                col += self.feat_num
+            for i in range(3):                                                       # :459-464
+                positional_encoding(garm_pe[i], self.garment_radius_list[i], self.garment_sample_num_list[i], garment_v_list[i], cur,
+                                    garment_f_list[i], feat, col)
+                col += self.feat_num
+            if it > 0:                                                               # :467-476
+                feat[..., col:] = gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group)
+            h = feat
+            for i, m in enumerate(regress[it]):                                      # :477-481
+                h = m(h, adj, False, relu=(i != 3))
+                lbs_iter_feat.append(h)
+            cur = (cur + h).contiguous()                                             # :482-483
+            outs.append(cur)
+        return outs

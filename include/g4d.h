@@ -156,10 +156,11 @@ int g4d_mlp_wave_f32(int mode, long long rows, int K0, const float *X, int ldx, 
                      const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
                      const int *relu, int pool, float *out, int ldo, int col0, g4d_stream_t stream);
 
-/* Batched SpMM of the GCN layer: out (frames,Vg,C) = Ahat (CSR) . S (frames,Vg,C) + bias (C, may be NULL), all
- * point-major (modules/pygcn/layers.py:44-55 without the transposes).  GraphConvolution = g4d_linear_f32 then this. */
+/* Batched SpMM of the GCN layer: out (frames,Vg,C) = Ahat (CSR) . S (frames,Vg,C) + bias (C, may be NULL), optional ReLU
+ * (the caller's F.relu, modules/mesh_encoder.py:479-480, fused), all point-major (modules/pygcn/layers.py:44-55 without
+ * the transposes).  GraphConvolution = g4d_linear_f32 then this. */
 int g4d_spmm_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
-                      const float *bias, float *out, g4d_stream_t stream);
+                      const float *bias, int relu, float *out, g4d_stream_t stream);
 
 /* max (is_max=1) / mean over S consecutive rows, any S: in (groups*S, ldi) -> out (groups, ldo) at col0. */
 int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0, int is_max,

@@ -70,3 +70,65 @@ def lbs_garment_interpolation(garment_t, Tpose_vertices, Tpose_root_joints, zero
             nn_W = (nn_W + F32(0.1) * adj.dot(flat).astype(F32).reshape(Vg, B * T, J).transpose(1, 0, 2)).astype(F32)
     verts = LO.skin(nn_W, A, inv_template)
     return verts.reshape(B, T, -1, 3), (dk[..., :1], ik[..., :1]), inv_template.reshape(B, T, -1, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The refinement loop of PCALBSGarmentUseSegEncoderSeg.forward (/root/reference/modules/mesh_encoder.py:445-486),
+# restated with numpy on top of the pinned pointnet2 / gcn oracles.  PARITY UNPINNED as a whole (mesh_encoder.py imports
+# chamferdist / smplx and cannot be run here); its pieces (ball query, grouping, GCN layer) are the pinned ones.
+def _linear(x, w, b=None):
+    y = x.astype(np.float32) @ w.T.astype(np.float32)
+    return y if b is None else y + b.astype(np.float32)
+
+
+def positional_encoding(sd, prefix, radius, nsample, xyz, new_xyz, feats_cm):
+    """QueryAndGroup(radius, nsample, use_xyz=True)(xyz, new_xyz, feats (B,C,N)) -> (B,3+C,P,S); permute(0,2,3,1);
+    Sequential(Linear, ReLU, Linear); max over the samples (mesh_encoder.py:452-463).  Returns (B,P,Cout)."""
+    from . import modules_oracle as MO
+    g = MO.query_and_group(radius, nsample, xyz, new_xyz, feats_cm, use_xyz=True)   # (B,3+C,P,S)
+    h = np.transpose(g, (0, 2, 3, 1))
+    h = np.maximum(_linear(h, sd[prefix + ".0.weight"], sd[prefix + ".0.bias"]), 0)
+    h = _linear(h, sd[prefix + ".2.weight"], sd[prefix + ".2.bias"])
+    return h.max(axis=-2)
+
+
+def temporal_attention(last_feat, w_qkv, nbatch, T):
+    """mesh_encoder.py:467-476.  last_feat (nbatch*T, Vg, C)."""
+    F_, Vg, C = last_feat.shape
+    qkv = _linear(last_feat.reshape(nbatch, T, Vg, C), w_qkv)
+    q, k, v = [z.reshape(nbatch, T, -1).astype(np.float64) for z in np.split(qkv, 3, axis=-1)]
+    a = q @ np.transpose(k, (0, 2, 1)) / np.sqrt(T)
+    a = np.exp(a - a.max(-1, keepdims=True))
+    a /= a.sum(-1, keepdims=True)
+    return (a @ v).reshape(F_, Vg, C).astype(np.float32)
+
+
+def refinement_head(sd, cur_garment_v, body_v, body_vn, garment_v_list, garment_f_list_pm, adj_csr, nbatch, T,
+                    garment_samples=(32, 16, 8), iteration=3):
+    """sd: numpy state dict with the reference's keys.  garment_f_list_pm[i] (F,N_i,C_i) point-major."""
+    from . import gcn_oracle as GO
+    radii = [0.1, 0.2, 0.4]
+    body_samples = [8, 16, 32]
+    cur = cur_garment_v.astype(np.float32)
+    outs, feats = [], []
+    body_vn_cm = np.ascontiguousarray(np.transpose(body_vn, (0, 2, 1)))
+    gf_cm = [np.ascontiguousarray(np.transpose(f, (0, 2, 1))) for f in garment_f_list_pm]
+    for it in range(iteration):
+        parts = [cur]
+        for i in range(3):
+            parts.append(positional_encoding(sd, "body_positional_encoding%d" % i, radii[i], body_samples[i], body_v, cur, body_vn_cm))
+        for i in range(3):
+            parts.append(positional_encoding(sd, "garment_positional_encoding%d" % i, radii[i], garment_samples[i], garment_v_list[i], cur,
+                                             gf_cm[i]))
+        h = np.concatenate(parts, axis=-1)
+        if it > 0:
+            h = np.concatenate([h, temporal_attention(feats[-2], sd["temporal_qkv_%d.weight" % it], nbatch, T)], axis=-1)
+        for l in range(4):
+            p = "lbs_graph_regress%d.%d" % (it + 1, l)
+            h = GO.graph_convolution(h, sd[p + ".weight"], sd[p + ".bias"], adj_csr)
+            if l != 3:
+                h = np.maximum(h, 0)
+            feats.append(h)
+        cur = cur + h
+        outs.append(cur)
+    return outs

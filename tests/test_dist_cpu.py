@@ -33,13 +33,13 @@ def _worker(rank, world, port, n_frames, T, ret):
         assert torch.equal(back, full)
         mx = gd.clip_max_over_frames(frame_feat[b:e], ids[b:e], n_frames // T, T)
         assert torch.equal(mx, frame_feat.view(n_frames // T, T, 6).max(1)[0])
-        qkv = torch.nn.Linear(20, 60)
+        qkv = torch.nn.Linear(4, 12, bias=False)  # per-vertex Linear(C, 3C) like temporal_qkv_*
         torch.manual_seed(1)
         for p in qkv.parameters():
             p.data.normal_()
         with torch.no_grad():
             got = gd.temporal_attention(local, ids[b:e], n_frames, T, qkv)
-            q, k, v = qkv(full.reshape(n_frames // T, T, 20)).chunk(3, -1)
+            q, k, v = [z.reshape(n_frames // T, T, 20) for z in qkv(full.reshape(n_frames // T, T, 5, 4)).chunk(3, -1)]
             want = (torch.softmax(q @ k.transpose(1, 2) / T ** 0.5, -1) @ v).reshape(n_frames, 5, 4)[b:e]
         assert torch.allclose(got, want, atol=1e-6)
         ret[rank] = True

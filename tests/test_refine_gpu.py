@@ -1,0 +1,95 @@
+"""The refinement loop (mesh_encoder.py:445-486) on the HIP kernels against the numpy restatement."""
+import numpy as np
+import pytest
+import torch
+
+from garment4d_amd import gcn as G
+from garment4d_amd import synthetic as syn
+from garment4d_amd.refine import GarmentRefinementHead
+from oracle import gcn_oracle as GO
+from oracle import refine_oracle as RO
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _case(nbatch, T, V=700, seed=0, garment="Tshirt"):
+    rng = np.random.default_rng(seed)
+    F_ = nbatch * T
+    verts, faces = syn.quad_cylinder(12, 16)
+    Vg = verts.shape[0]
+    body_v = (syn.unit_cloud(F_, V, seed=seed + 1) - 0.5).astype(np.float32) * 0.8
+    body_vn = rng.standard_normal((F_, V, 3)).astype(np.float32)
+    body_vn /= np.linalg.norm(body_vn, axis=-1, keepdims=True)
+    cur = (body_v[:, rng.permutation(V)[:Vg]] + rng.standard_normal((F_, Vg, 3)).astype(np.float32) * 0.03).astype(np.float32)
+    gv, gf = [], []
+    for n, c in ((512, 64), (128, 96), (32, 384)):
+        sel = rng.integers(0, Vg, n)
+        gv.append((cur[:, sel] + rng.standard_normal((F_, n, 3)).astype(np.float32) * 0.05).astype(np.float32))
+        gf.append(rng.standard_normal((F_, n, c)).astype(np.float32))
+    adj = GO.adjacency_from_faces(faces, Vg)
+    torch.manual_seed(seed)
+    head = GarmentRefinementHead(garment_name=garment).cuda().eval()
+    with torch.no_grad():  # GraphConvolution's uniform(-1/sqrt(out)) init makes the 3-channel layer huge; tame it
+        for p in head.parameters():
+            p.mul_(0.5)
+    sd = {k: v.detach().cpu().numpy() for k, v in head.state_dict().items()}
+    return head, sd, cur, body_v, body_vn, gv, gf, adj
+
+
+def _run(head, cur, body_v, body_vn, gv, gf, adj, nbatch, T):
+    adj_t = G.sparse_mx_to_torch_sparse_tensor(adj).cuda()
+    with torch.no_grad():
+        return head(dev(cur), dev(body_v), dev(body_vn), [dev(x) for x in gv], [dev(x) for x in gf], adj_t, nbatch, T)
+
+
+def test_state_dict_keys_match_reference_names():
+    head = GarmentRefinementHead()
+    keys = set(head.state_dict().keys())
+    for k in ("body_positional_encoding0.0.weight", "body_positional_encoding2.2.bias", "garment_positional_encoding1.0.weight",
+              "temporal_qkv_1.weight", "temporal_qkv_2.weight", "lbs_graph_regress1.0.weight", "lbs_graph_regress3.3.bias"):
+        assert k in keys
+    assert "temporal_qkv_1.bias" not in keys
+    assert head.lbs_graph_regress1[0].weight.shape == (195, 128) and head.lbs_graph_regress2[0].weight.shape == (323, 128)
+    assert head.garment_positional_encoding2[0].weight.shape == (32, 387)
+
+
+@pytest.mark.parametrize("garment", ["Tshirt", "Trousers"])
+def test_first_round_vs_oracle(garment):
+    nbatch, T = 2, 3
+    head, sd, cur, body_v, body_vn, gv, gf, adj = _case(nbatch, T, seed=3, garment=garment)
+    head.iteration = 1
+    got = _run(head, cur, body_v, body_vn, gv, gf, adj, nbatch, T)
+    want = RO.refinement_head(sd, cur, body_v, body_vn, gv, gf, adj, nbatch, T, garment_samples=tuple(head.garment_sample_num_list),
+                              iteration=1)
+    assert len(got) == 1
+    np.testing.assert_allclose(got[0].cpu().numpy(), want[0], rtol=1e-4, atol=1e-4)
+
+
+def test_three_rounds_vs_oracle():
+    """Rounds 2, 3 re-query the balls around vertices that differ by rounding between the two implementations, so a
+    vertex sitting within 1e-6 of a ball boundary may legitimately change membership: compare all but a sliver."""
+    nbatch, T = 2, 3
+    head, sd, cur, body_v, body_vn, gv, gf, adj = _case(nbatch, T, seed=5)
+    got = _run(head, cur, body_v, body_vn, gv, gf, adj, nbatch, T)
+    want = RO.refinement_head(sd, cur, body_v, body_vn, gv, gf, adj, nbatch, T)
+    assert len(got) == 3
+    for g, w in zip(got, want):
+        err = np.abs(g.cpu().numpy() - w).max(-1)
+        scale = np.abs(w).max()
+        assert np.quantile(err, 0.99) <= 2e-4 * max(scale, 1.0), (np.quantile(err, 0.99), err.max(), scale)
+
+
+def test_attention_only_mixes_frames_of_a_clip():
+    """Changing clip 1's inputs must leave clip 0's refined vertices untouched (the attention is per clip)."""
+    nbatch, T = 2, 3
+    head, sd, cur, body_v, body_vn, gv, gf, adj = _case(nbatch, T, seed=7)
+    a = _run(head, cur, body_v, body_vn, gv, gf, adj, nbatch, T)
+    cur2 = cur.copy()
+    cur2[T:] += 0.01
+    b = _run(head, cur2, body_v, body_vn, gv, gf, adj, nbatch, T)
+    assert torch.equal(a[-1][:T], b[-1][:T])
+    assert not torch.equal(a[-1][T:], b[-1][T:])
