@@ -38,9 +38,9 @@ def sparse_mx_to_torch_sparse_tensor(sparse_mx):
     return torch.sparse_coo_tensor(indices, torch.from_numpy(coo.data), torch.Size(coo.shape))
 
 
-def adjacency_from_faces(faces, num_verts):
-    """Row-normalised (A + I) of a quad or triangle mesh, built like the reference model does: four edge slots per
-    face, duplicate entries summed, symmetrised by element-wise max, no binarisation."""
+def adjacency_old_from_faces(faces, num_verts):
+    """The un-normalised symmetrised adjacency (`self.adj_old`, modules/mesh_encoder.py:281-300) of a quad or triangle
+    mesh: four edge slots per face, duplicate entries summed, symmetrised by element-wise max, no binarisation."""
     import scipy.sparse as sp
     faces = np.asarray(faces)
     nf, k = faces.shape
@@ -55,8 +55,13 @@ def adjacency_from_faces(faces, num_verts):
         edges[0, slot::4] = faces[:, a]
         edges[1, slot::4] = faces[:, b]
     adj = sp.coo_matrix((np.ones(edges.shape[1]), (edges[0], edges[1])), shape=(num_verts, num_verts), dtype=np.float32).tocsr()
-    adj = adj.maximum(adj.T)
-    return normalize(adj + sp.eye(num_verts))
+    return adj.maximum(adj.T)
+
+
+def adjacency_from_faces(faces, num_verts):
+    """Row-normalised (A + I) of the mesh (`self.adj`, modules/mesh_encoder.py:301)."""
+    import scipy.sparse as sp
+    return normalize(adjacency_old_from_faces(faces, num_verts) + sp.eye(num_verts))
 
 
 def _to_csr(adj, device):
@@ -73,6 +78,8 @@ def _to_csr(adj, device):
     else:
         m = adj.tocsr()
     m.sort_indices()
+    if len(_csr_cache) > 32:
+        _csr_cache.clear()
     csr = (torch.from_numpy(m.indptr.astype(np.int32)).to(device), torch.from_numpy(m.indices.astype(np.int32)).to(device),
            torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
     _csr_cache[key] = (adj, csr)

@@ -86,3 +86,49 @@ def quad_cylinder(rows, cols):
             b = r * cols + (c + 1) % cols
             faces.append([a, b, b + cols, a + cols])
     return verts, np.asarray(faces, dtype=np.int32)
+
+
+def garment_scene(nbatch, T, N, body_rc=(25, 28), garment_rc=(12, 16), pca_dim=64, seed=0):
+    """A synthetic stand-in for one batch of the reference's data loader (utils/dataloader.py:186-300) plus the on-disk
+    assets of the model constructor (PCA basis pickle, garment template OBJ, SMPL body) -- none of which exist here.
+    Body = triangulated quad cylinder (V = rows*cols vertices), garment template = a wider quad cylinder (Vg vertices).
+    Returns dict(x (nbatch,T,N,3), batch {reference keys}, body {parents, faces, J_regressor, v_template},
+    pca {components, mean, explained, ss_scale}, template (verts, quad faces)); all numpy."""
+    rng = np.random.default_rng(seed)
+    bv, bq = quad_cylinder(*body_rc)
+    bv = (bv * np.array([0.75, 0.7, 0.5], dtype=F32) + np.array([0, -0.35, 0], dtype=F32)).astype(F32)
+    V = bv.shape[0]
+    faces = np.concatenate([bq[:, [0, 1, 2]], bq[:, [0, 2, 3]]], 0).astype(np.int64)
+    P = smpl_like_params(V=V, J=24, seed=seed + 1)
+    gv, gq = quad_cylinder(*garment_rc)
+    gv = (gv * np.array([1.0, 0.45, 0.7], dtype=F32) + np.array([0, -0.2, 0], dtype=F32)).astype(F32)
+    Vg = gv.shape[0]
+    pca = dict(components=(rng.standard_normal((pca_dim + 8, Vg * 3)) * 0.002).astype(F32), mean=gv.reshape(-1).copy(),
+               explained=rng.random(pca_dim + 8), ss_scale=np.ones(Vg * 3) * 1.0)
+    root = (rng.standard_normal((nbatch, 1, 3)) * 0.01).astype(F32)
+    shape_off = (rng.standard_normal((nbatch, 1, V, 3)) * 0.003).astype(F32)
+    tpose = (bv[None, None] + shape_off).astype(F32)                                   # (nbatch,1,V,3)
+    zeropose = np.repeat(tpose, T, 1).astype(F32)                                      # (nbatch,T,V,3)
+    pose = (rng.standard_normal((nbatch, T, 72)) * 0.1).astype(F32)
+    drift = np.cumsum(rng.standard_normal((nbatch, T, 1, 3)) * 0.004, axis=1).astype(F32)
+    smpl_v = (zeropose + drift + rng.standard_normal((nbatch, T, V, 3)).astype(F32) * 0.001).astype(F32)
+    # the scan: N points, ~55 % on the body, the rest on the (posed-ish) garment, jittered
+    nb = int(N * 0.55)
+    x = np.empty((nbatch, T, N, 3), F32)
+    for b in range(nbatch):
+        for t in range(T):
+            bi = rng.integers(0, V, nb)
+            gi = rng.integers(0, Vg, N - nb)
+            pts = np.concatenate([smpl_v[b, t, bi], gv[gi] + drift[b, t]], 0)
+            x[b, t] = pts[rng.permutation(N)] + rng.standard_normal((N, 3)).astype(F32) * 0.004
+    batch = {
+        "smpl_vertices_torch": smpl_v,
+        "Tpose_smpl_vertices_torch": tpose,
+        "Tpose_smpl_root_joints_torch": root,
+        "zeropose_smpl_vertices_torch": zeropose,
+        "pose_torch": pose,
+        "T_J_regressor": np.ascontiguousarray(np.broadcast_to(P["J_regressor"][None, None], (nbatch, T) + P["J_regressor"].shape)),
+        "T_lbs_weights": np.ascontiguousarray(np.broadcast_to(P["lbs_weights"][None, None], (nbatch, T) + P["lbs_weights"].shape)),
+    }
+    body = dict(parents=P["parents"], faces=faces, J_regressor=P["J_regressor"], v_template=bv)
+    return dict(x=x, batch=batch, body=body, pca=pca, template=(gv, gq))

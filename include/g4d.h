@@ -229,6 +229,22 @@ int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, in
 int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
                            const float *vals, float coeff, float *out, g4d_stream_t stream);
 
+/* Ordered per-frame compaction of `calc_segmentation_results` (modules/mesh_encoder.py:109-125): sel (frames,n_out) = the
+ * indices k (ascending) of the points whose arg-max over `classes` logits (first maximum wins) equals `target`, the
+ * first n_out of them, -1 padded; counts (frames, may be NULL) = number of matching points (may exceed n_out).
+ * logits (frames,n,classes) point-major. */
+int g4d_segment_select_f32(int frames, int n, int classes, int target, int n_out, const float *logits, int *sel, int *counts,
+                           g4d_stream_t stream);
+
+/* out (frames,n_out,c) = in (frames,n,c)[sel], zero rows where sel < 0 (the torch.cat with zeros, mesh_encoder.py:123-124). */
+int g4d_segment_take_f32(int frames, int n, int n_out, int c, const float *in, const int *sel, float *out, g4d_stream_t stream);
+
+/* Vertex normals (utils/mesh_utils.py:116-134 compute_fnorms + compute_vnorms): unit face normals (norm clamped at 1e-6)
+ * summed over each vertex's incident faces in the CSR order (vf_rowptr (v+1), vf_fid), re-normalised with the same
+ * clamp.  verts/out (frames,v,3); faces (nf,3) int32. */
+int g4d_vertex_normals_f32(int frames, int v, const float *verts, const int *faces, const int *vf_rowptr, const int *vf_fid,
+                           float *out, g4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,9 +21,9 @@ def normalize(mx):
     return sp.diags(r_inv).dot(mx)
 
 
-def adjacency_from_faces(faces, num_verts):
-    """mesh_encoder.py:288-307: symmetrised 0/1 edge matrix from quad (f0f1,f1f2,f2f3,f3f0) or
-    triangle edges, plus identity, row-normalised.  Returns scipy CSR fp32."""
+def adjacency_old_from_faces(faces, num_verts):
+    """mesh_encoder.py:281-300: `self.adj_old`, the symmetrised edge matrix from quad (f0f1,f1f2,f2f3,f3f0) or triangle
+    edges (duplicates summed).  Returns scipy CSR fp32."""
     faces = np.asarray(faces)
     nf, k = faces.shape
     # 4 edge slots per face (:288); a triangle fills slots 0,1,3 and leaves slot 2 = (0,0) (:295-298)
@@ -41,8 +41,12 @@ def adjacency_from_faces(faces, num_verts):
     # duplicate (i,j) entries SUM in COO (:299-301); no binarisation in the reference
     adj = sp.coo_matrix((np.ones(edges.shape[1]), (edges[0], edges[1])), shape=(num_verts, num_verts),
                         dtype=F32).tocsr()
-    adj = adj.maximum(adj.T)  # == adj + adj.T*(adj.T>adj) - adj*(adj.T>adj)  (:302)
-    adj = normalize(adj + sp.eye(num_verts))  # (:304)
+    return adj.maximum(adj.T)  # == adj + adj.T*(adj.T>adj) - adj*(adj.T>adj)  (:302)
+
+
+def adjacency_from_faces(faces, num_verts):
+    """mesh_encoder.py:288-307: adj_old plus identity, row-normalised.  Returns scipy CSR fp32."""
+    adj = normalize(adjacency_old_from_faces(faces, num_verts) + sp.eye(num_verts))  # (:304)
     return sp.csr_matrix(adj).astype(F32)
 
 

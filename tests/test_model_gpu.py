@@ -1,0 +1,124 @@
+"""The wired model (PCAGarmentEncoderSeg / PCALBSGarmentUseSegEncoderSeg, mesh_encoder.py:43-487) on
+the HIP kernels against the numpy restatement (oracle/model_oracle.py; parity unpinned as a whole)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from garment4d_amd import mesh_utils as MU
+from garment4d_amd import synthetic as syn
+from garment4d_amd.encoder import seed_encoder
+from garment4d_amd.mesh_encoder import PCALBSGarmentUseSegEncoderSeg, class_num, label_dict
+from oracle import model_oracle as MOr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _body_model(body):
+    return types.SimpleNamespace(parents=torch.from_numpy(body["parents"]).cuda(), faces=body["faces"],
+                                 J_regressor=dev(body["J_regressor"]), v_template=dev(body["v_template"]))
+
+
+def _model(scene, garment="Tshirt", lbs_k=64, seed=0):
+    m = PCALBSGarmentUseSegEncoderSeg(garment_name=garment, pca_dim=64, pca=scene["pca"], template=scene["template"], lbs_k=lbs_k,
+                                      iteration=3)
+    seed_encoder(m.PCA_garment_encoder, seed)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if not name.startswith("PCA_garment_encoder."):
+                p.mul_(0.5)
+    m = m.cuda().eval()
+    # random-weight logits rarely favour one class: shift the garment's bias so that ~35 % of the points are garment
+    with torch.no_grad():
+        x = dev(scene["x"]).reshape(-1, scene["x"].shape[2], 3)
+        logits = m.PCA_garment_encoder.pointnet.forward_fused(x)[1]
+        tgt = label_dict[garment] - 1
+        others = torch.cat([logits[..., :tgt], logits[..., tgt + 1:]], -1).max(-1)[0]
+        margin = (others - logits[..., tgt]).flatten()
+        m.PCA_garment_encoder.pointnet.FC_layer[2].conv.bias[tgt] += torch.quantile(margin, 0.35)
+    return m
+
+
+def test_state_dict_keys():
+    scene = syn.garment_scene(1, 2, 256, seed=1)
+    m = PCALBSGarmentUseSegEncoderSeg(garment_name="Tshirt", pca_dim=64, pca=scene["pca"], template=scene["template"], lbs_k=3, iteration=3)
+    keys = set(m.state_dict().keys())
+    for k in ("PCA_garment_encoder.pointnet.SA_modules.0.mlps.0.layer0.conv.weight", "PCA_garment_encoder.pointnet.FC_layer.2.conv.bias",
+              "PCA_garment_encoder.GarmentEncoder.1.mlps.1.layer1.bn.bn.running_var", "PCA_garment_encoder.GarmentSummarize.mlps.0.layer0.conv.weight",
+              "PCA_garment_encoder.PCAEncoder.0.weight", "PCA_garment_encoder.PCAEncoder.4.running_mean", "PCA_garment_encoder.PCAEncoder.6.bias",
+              "body_positional_encoding0.0.weight", "temporal_qkv_2.weight", "lbs_graph_regress2.0.weight"):
+        assert k in keys, k
+    assert m.PCA_garment_encoder.GarmentSummarize.mlps[0].layer0.conv.weight.shape[:2] == (512, 387)
+
+
+def test_vertex_normals_vs_oracle():
+    scene = syn.garment_scene(2, 2, 64, seed=2)
+    body = scene["body"]
+    v = scene["batch"]["smpl_vertices_torch"].reshape(4, -1, 3)
+    fid, vid = MU.calc_mesh_info(body["faces"], v.shape[1])
+    got = MU.compute_vnorms(dev(v), torch.from_numpy(body["faces"]).cuda(), vid.cuda(), fid.cuda()).cpu().numpy()
+    want = MOr.compute_vnorms(v, body["faces"])
+    np.testing.assert_allclose(got, want, atol=2e-5)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=-1), 1.0, atol=1e-5)
+    # shuffled (vertex, face) pairs give the same normals up to summation order
+    perm = torch.randperm(fid.numel())
+    got2 = MU.compute_vnorms(dev(v), torch.from_numpy(body["faces"]).cuda(), vid[perm].cuda(), fid[perm].cuda()).cpu().numpy()
+    np.testing.assert_allclose(got2, got, atol=1e-6)
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.2, 0.9])
+def test_segment_points_vs_oracle(frac):
+    rng = np.random.default_rng(3)
+    F_, N, C, n = 3, 1000, 5, 250
+    logits = rng.standard_normal((F_, N, class_num)).astype(np.float32)
+    logits[..., 6] += {0.0: -100.0, 0.2: 0.3, 0.9: 3.0}[frac]
+    logits[0, :10] = 0.0                                     # all-equal logits: the first class wins, not the garment
+    xyz = rng.standard_normal((F_, N, 3)).astype(np.float32)
+    feats = rng.standard_normal((F_, N, C)).astype(np.float32)
+    gv, gf, counts = MU.segment_points(dev(logits), 6, n, dev(xyz), dev(feats))
+    wv, wf = MOr.calc_segmentation_results(xyz, logits, n, 6, feats)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(gf.cpu().numpy(), wf)
+    assert np.array_equal(counts.cpu().numpy(), (np.argmax(logits, 2) == 6).sum(1))
+
+
+@pytest.mark.parametrize("garment,lbs_k", [("Tshirt", 64), ("Trousers", 3)])
+def test_full_forward_vs_oracle(garment, lbs_k):
+    nbatch, T, N = 2, 3, 2048
+    scene = syn.garment_scene(nbatch, T, N, seed=11)
+    m = _model(scene, garment, lbs_k)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out = m(dev(scene["x"]), _body_model(scene["body"]), {k: dev(v) for k, v in scene["batch"].items()})
+    want = MOr.full_forward(sd, scene["x"], scene["batch"], scene["body"], garment, scene["pca"], scene["template"][1], lbs_k)
+
+    def close(a, b, tol=2e-4):
+        np.testing.assert_allclose(a.cpu().numpy() if torch.is_tensor(a) else a, b, rtol=tol, atol=tol)
+
+    close(out["sem_logits"], want["sem_logits"])
+    n_garment = (np.argmax(want["sem_logits"], 2) == label_dict[garment] - 1).sum(1)
+    assert n_garment.min() > 100, "scene must exercise the compaction"
+    for a, b in zip(out["garment_v_list"], want["garment_v_list"]):
+        assert np.array_equal(a.cpu().numpy(), b)                 # same segmentation, same FPS picks
+    for a, b in zip(out["garment_f_list"], want["garment_f_list"]):
+        assert a.shape == b.shape                                 # channel-major, like the reference
+        close(a, b)
+    close(out["garment_summary"], want["garment_summary"])
+    close(out["garment_PCA_coeff"], want["garment_PCA_coeff"])
+    close(out["tpose_garment"], want["tpose_garment"])
+    assert out["lbs_pred_garment_v"].shape == (nbatch, T, scene["template"][0].shape[0], 3)
+
+    def mostly_close(a, b, tol):
+        err = np.abs(a.cpu().numpy().reshape(b.shape) - b).max(-1)
+        assert np.quantile(err, 0.99) <= tol, (np.quantile(err, 0.99), err.max())
+
+    mostly_close(out["lbs_stage1_pred_garment_v"], want["lbs_stage1_pred_garment_v"], 1e-4)
+    mostly_close(out["lbs_pred_garment_v"], want["lbs_pred_garment_v"], 2e-4)
+    assert len(out["iter_regressed_lbs_garment_v"]) == 3
+    for a, b in zip(out["iter_regressed_lbs_garment_v"], want["iter_regressed_lbs_garment_v"]):
+        mostly_close(a, b, 5e-4 * max(1.0, np.abs(b).max()))
