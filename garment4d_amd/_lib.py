@@ -43,6 +43,7 @@ SIGNATURES = {
     "g4d_spmm_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp],
     "g4d_knn_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_knn_blend_weights_f32": [_I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
+    "g4d_pos_encode_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp],
     "g4d_segment_select_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_segment_take_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_vertex_normals_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -9,7 +9,11 @@ namespace g4d {
 
 // out[f,v,:] = sum_k w_k * W[f, idx[c,v,k], :],  c = f / frames_per_clip,
 // w_k = (1/d_k with inf -> 0) / sum, again inf -> 0   (the reference's two isinf fix-ups, :342-345)
-// one wave per output row: lanes 0..J-1 own a joint, the K neighbours are walked with wave-uniform (idx, w).
+// One wave per output row.  The K <= 256 (index, weight) pairs of the row live in registers (lane l holds pairs l, l+64,
+// ...), are normalised once, and are handed out with v_readlane -- no dependent global load in the gather loop.  With
+// J <= 32 joints the wave walks TWO neighbours per step (lanes 0-31 the even k, lanes 32-63 the odd k; a 24-joint row is
+// 96 B, so a step gathers two rows) and the halves meet in one cross-lane add at the end: sum over even k + sum over odd k.
+template <int HALVES>
 __global__ void __launch_bounds__(256) knn_blend_weights_kernel(long long rows, int vg, int v, int K, int J, int frames_per_clip,
                                                                const float *__restrict__ W, const int *__restrict__ idx,
                                                                const float *__restrict__ dists, float *__restrict__ out) {
@@ -21,25 +25,53 @@ __global__ void __launch_bounds__(256) knn_blend_weights_kernel(long long rows, 
     const long long c = f / frames_per_clip;
     const int *ix = idx + ((size_t)c * vg + gv) * K;
     const float *dd = dists + ((size_t)c * vg + gv) * K;
-    // pass 1: normaliser  sum_k (1/d_k, inf -> 0), lanes stride over k
+    int iv[4];
+    float wv[4];
     float s = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        float w = 1.0f / dd[k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = q * 64 + lane;
+        iv[q] = k < K ? ix[k] : 0;
+        float w = k < K ? 1.0f / dd[k] : 0.f;
         if (__builtin_isinf(w)) w = 0.f;
+        wv[q] = w;
         s += w;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    // pass 2: blend
-    const float *Wf = W + (size_t)f * v * J;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) {
-        float w = 1.0f / dd[k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float w = wv[q] / s;
         if (__builtin_isinf(w)) w = 0.f;
-        w = w / s;
-        if (__builtin_isinf(w)) w = 0.f;
-        if (lane < J) acc += Wf[(size_t)ix[k] * J + lane] * w;  // (nn_W * interp).sum(-2), k ascending
+        wv[q] = w;
     }
+    const float *Wf = W + (size_t)f * v * J;
+    const int half = HALVES == 2 ? lane >> 5 : 0;
+    const int j = HALVES == 2 ? lane & 31 : lane;
+    float acc = 0.f;
+    auto walk = [&](const int ivq, const float wvq, const int kend) {  // kend <= 0 past the end of the list
+        for (int kk = 0; kk < kend; kk += HALVES) {
+            int i;
+            float w;
+            if (HALVES == 2) {
+                const int k1 = min(kk + 1, 63);
+                const int i0 = __builtin_amdgcn_readlane(ivq, kk), i1 = __builtin_amdgcn_readlane(ivq, k1);
+                const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wvq), kk));
+                const float w1 = kk + 1 < kend ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wvq), k1)) : 0.f;
+                i = half ? i1 : i0;
+                w = half ? w1 : w0;
+            } else {
+                i = __builtin_amdgcn_readlane(ivq, kk);
+                w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wvq), kk));
+            }
+            if (j < J) acc += Wf[(size_t)i * J + j] * w;
+        }
+    };
+    walk(iv[0], wv[0], min(64, K));
+    walk(iv[1], wv[1], min(64, K - 64));
+    walk(iv[2], wv[2], min(64, K - 128));
+    walk(iv[3], wv[3], min(64, K - 192));
+    if (HALVES == 2) acc += __shfl_xor(acc, 32);
     if (lane < J) out[(size_t)row * J + lane] = acc;
 }
 
@@ -74,14 +106,18 @@ using namespace g4d;
 
 extern "C" int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, int k, int j, const float *W, const int *idx,
                                          const float *dists, float *out, g4d_stream_t stream) {
-    G4D_REQUIRE(frames >= 0 && frames_per_clip >= 1 && vg >= 0 && v > 0 && k >= 1 && j >= 1 && j <= 64,
-                "g4d_knn_blend_weights_f32: bad sizes (J <= 64)");
+    G4D_REQUIRE(frames >= 0 && frames_per_clip >= 1 && vg >= 0 && v > 0 && k >= 1 && k <= 256 && j >= 1 && j <= 64,
+                "g4d_knn_blend_weights_f32: bad sizes (K <= 256, J <= 64)");
     const long long rows = (long long)frames * vg;
     if (rows == 0) return G4D_OK;
     G4D_REQUIRE(W && idx && dists && out, "g4d_knn_blend_weights_f32: null pointer");
     G4D_REQUIRE((rows + 3) / 4 < (1ll << 31), "g4d_knn_blend_weights_f32: too large");
-    hipLaunchKernelGGL(knn_blend_weights_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows,
-                       vg, v, k, j, frames_per_clip, W, idx, dists, out);
+    if (j <= 32)
+        hipLaunchKernelGGL(knn_blend_weights_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           rows, vg, v, k, j, frames_per_clip, W, idx, dists, out);
+    else
+        hipLaunchKernelGGL(knn_blend_weights_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           rows, vg, v, k, j, frames_per_clip, W, idx, dists, out);
     return check_launch("g4d_knn_blend_weights_f32");
 }
 

@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
 // max / mean over S consecutive rows of a point-major matrix (any S) -- used when S is not 16/32/64.
 __global__ void __launch_bounds__(256) pool_rows_kernel(int groups, int S, int C, const float *__restrict__ in, int ldi,
                                                        float *__restrict__ out, int ldo, int col0, int is_max) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int g = blockIdx.y;
-    if (c >= C || g >= groups) return;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)groups * C) return;
+    const int g = (int)(gid / C), c = (int)(gid - (long long)g * C);
     const float *p = in + (size_t)g * S * ldi + c;
     float acc = p[0];
     for (int s = 1; s < S; ++s) {
@@ -294,10 +294,10 @@ extern "C" int g4d_gcn_linear_f32(int frames, int vg, int fin, const float *X, i
 
 extern "C" int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0,
                                  int is_max, g4d_stream_t stream) {
-    G4D_REQUIRE(groups >= 0 && s > 0 && c >= 0 && groups <= 65535 * 1, "g4d_pool_rows_f32: bad sizes (groups <= 65535)");
+    G4D_REQUIRE(groups >= 0 && s > 0 && c >= 0, "g4d_pool_rows_f32: bad sizes");
     if (groups == 0 || c == 0) return G4D_OK;
     G4D_REQUIRE(in && out, "g4d_pool_rows_f32: null pointer");
-    hipLaunchKernelGGL(pool_rows_kernel, dim3((c + 255) / 256, groups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)(((long long)groups * c + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        groups, s, c, in, ldi, out, ldo, col0, is_max);
     return check_launch("g4d_pool_rows_f32");
 }

@@ -162,6 +162,22 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
                     }
             } else {
                 const bool is_max = a.pool == 1;
+                if (a.S < 16) {  // S = 4 | 8: 4 | 2 neighbourhoods per accumulator tile (lane owns rows fq*4 .. fq*4+3)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
+                                         : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
+                        if (a.S == 8) {
+                            const float y = __shfl_xor(x, 16);
+                            x = is_max ? fmaxf(x, y) : x + y;
+                        }
+                        const int first_row = row0 + rh * 16 * MT + mt * 16 + (a.S == 8 ? (fq >> 1) * 8 : fq * 4);
+                        const bool writer = a.S == 8 ? (fq & 1) == 0 : true;
+                        if (writer && ch_ok && first_row < a.rows)
+                            a.out[(size_t)(first_row / a.S) * a.ldo + a.col0 + ch] = is_max ? x : x / (float)a.S;
+                    }
+                    continue;
+                }
                 float v[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -229,7 +245,7 @@ extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
     if (rows == 0) return G4D_OK;
     G4D_REQUIRE(W && scale && shift && Kpad && Cout && relu && out, "g4d_mlp_stack_f32: null pointer");
     G4D_REQUIRE(pool >= 0 && pool <= 2, "g4d_mlp_stack_f32: pool must be 0|1|2");
-    if (pool) G4D_REQUIRE((S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_stack_f32: pooling needs S in {16,32,64}");
+    if (pool) G4D_REQUIRE((S == 4 || S == 8 || S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_stack_f32: pooling needs S in {4,8,16,32,64}");
     StackArgs s = {};
     s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
     s.in.X = X; s.in.ldx = ldx;

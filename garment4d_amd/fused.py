@@ -152,10 +152,13 @@ def _use_bf16(rows):
     return PRECISION == "bf16" and (rows is None or rows >= _BF16_MIN_ROWS)
 
 
+_POOL_WINDOWS = (4, 8, 16, 32, 64)  # pool windows the LDS-resident kernels reduce in registers
+
+
 def stack_fits(layers, pool, S, rows=None):
-    """Can these packed layers run as ONE stack launch? (<= 4 layers, LDS budget, pool window 16/32/64).  In bf16 mode
+    """Can these packed layers run as ONE stack launch? (<= 4 layers, LDS budget, pool window 4/8/16/32/64).  In bf16 mode
     the activations take 2 bytes in LDS, so wider stacks fit -- but only launches with >= 8192 rows use that kernel."""
-    if not (1 <= len(layers) <= 4) or (pool and S not in (16, 32, 64)):
+    if not (1 <= len(layers) <= 4) or (pool and S not in _POOL_WINDOWS):
         return False
     w = [0, 0]
     for l, L in enumerate(layers):
@@ -167,7 +170,7 @@ def stack_fits(layers, pool, S, rows=None):
 
 def wave_fits(layers, pool, S):
     """Narrow stack (every hidden width <= 64): eligible for the wave-autonomous kernel (csrc/mlp_wave.hip)."""
-    if not USE_WAVE or not (1 <= len(layers) <= 4) or (pool and S not in (16, 32, 64)):
+    if not USE_WAVE or not (1 <= len(layers) <= 4) or (pool and S not in _POOL_WINDOWS):
         return False
     # measured: wins for xyz-only first levels (K0 <= 32); with wide gathered inputs the workgroup-cooperative
     # stack kernel is faster (its whole-tile gather keeps more loads in flight)

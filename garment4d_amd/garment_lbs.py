@@ -27,19 +27,66 @@ def _blend(W, idx32, dists, frames_per_clip):
     return out
 
 
-def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100):
-    """100 Jacobi steps  W <- W + coeff * ((D^-1 A - I) . W)  over the garment mesh (:385-390)."""
+_operator_cache = {}
+
+
+def smoothing_operator(adj_old, coeff, iters, device):
+    """The `iters` Jacobi steps  W <- W + coeff * ((D^-1 A - I) . W)  are ONE linear map along the vertex axis:
+    M = ((1 - coeff) I + coeff D^-1 A)^iters, a dense row-stochastic (Vg,Vg) matrix (100 hops cover the mesh).  Built once
+    per mesh by repeated squaring in fp64 on the device, kept in fp32."""
+    key = (id(adj_old), float(coeff), int(iters), str(device))
+    hit = _operator_cache.get(key)
+    if hit is not None and hit[0] is adj_old:
+        return hit[1]
+    import scipy.sparse as sp
+    n = adj_old.shape[0]
+    step = (sp.eye(n) * (1.0 - coeff) + normalize(adj_old) * coeff).tocoo()
+    base = torch.sparse_coo_tensor(torch.from_numpy(np.vstack((step.row, step.col)).astype(np.int64)), torch.from_numpy(step.data.astype(np.float64)),
+                                   (n, n)).to(device).to_dense()
+    M, e = None, int(iters)
+    while e:                                   # square-and-multiply, fp64 library GEMMs
+        if e & 1:
+            M = base if M is None else M @ base
+        e >>= 1
+        if e:
+            base = base @ base
+    M = (torch.eye(n, dtype=torch.float64, device=device) if M is None else M).float().contiguous()
+    if len(_operator_cache) > 4:
+        _operator_cache.clear()
+    _operator_cache[key] = (adj_old, M)
+    return M
+
+
+_SMOOTH_OPERATOR_MAX_VG = 8192   # dense operator up to 256 MB; larger meshes run the sparse steps
+
+
+def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100, method=None):
+    """100 Jacobi steps  W <- W + coeff * ((D^-1 A - I) . W)  over the garment mesh (:385-390).
+    method "jacobi": the steps as written, one SpMM-axpy kernel each (ping-pong buffers).
+    method "operator": the same linear map applied as one dense fp32 GEMM (see smoothing_operator); differs from the
+    step-by-step result only by rounding (both are ~1e-6 from the exact product).  Default: G4D_SMOOTH or "operator"
+    for meshes up to 8192 vertices."""
+    import os
+    F_, Vg, J = nn_W.shape
+    method = method or os.environ.get("G4D_SMOOTH") or ("operator" if Vg <= _SMOOTH_OPERATOR_MAX_VG else "jacobi")
+    if method == "operator":
+        M = smoothing_operator(adj_old, coeff, iters, nn_W.device)
+        x = nn_W.permute(1, 0, 2).reshape(Vg, F_ * J)                      # vertex-major view of all frames / joints
+        return torch.mm(M, x).view(Vg, F_, J).permute(1, 0, 2).contiguous()   # plain library GEMM
+    assert method == "jacobi", method
     import scipy.sparse as sp
     adj = normalize(adj_old) - sp.eye(adj_old.shape[0])
     rowptr, colidx, vals, n = _to_csr(sp.csr_matrix(adj), nn_W.device)
-    F_, Vg, J = nn_W.shape
     assert n == Vg
-    a, b = nn_W.contiguous(), torch.empty_like(nn_W)
+    a, b, spare = nn_W.contiguous(), torch.empty_like(nn_W), None   # the caller's tensor is read, never written
     st = _lib.stream_ptr()
-    for _ in range(iters):
+    for it in range(iters):
         _lib.call("g4d_spmm_axpy_rows_f32", F_, Vg, J, a.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), float(coeff),
                   b.data_ptr(), st)
-        a, b = b, a
+        if it == 0:
+            a, b = b, (torch.empty_like(nn_W) if iters > 1 else None)
+        else:
+            a, b = b, a
     return a
 
 

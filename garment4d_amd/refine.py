@@ -12,9 +12,13 @@ against oracle/refine_oracle.py."""
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import dist as gdist
 from . import fused
 from .gcn import GraphConvolution
+
+
+USE_PE_KERNEL = True   # tests flip this to cover the generic fused-stack route
 
 
 def _pack_linear_mlp(seq):
@@ -35,22 +39,92 @@ def _pack_linear_mlp(seq):
     return layers
 
 
-def positional_encoding(mlp, radius, nsample, xyz, new_xyz, feats_pm, out, col0):
-    """QueryAndGroup(radius, nsample, use_xyz=True) -> mlp -> max over samples, into out[..., col0:col0+Cout].
-    xyz (F,N,3) cloud, new_xyz (F,Vg,3) queries, feats_pm (F,N,C) point-major."""
+def _split_first_linear(seq):
+    """Sequential(Linear(3+C, H), ReLU, Linear(H, H)) -> (table layer C -> H with the bias, stack [3+H -> H (ReLU), H -> H]).
+    The first Linear is linear in its input, so  W [x_j - q ; f_j] + b = Wx (x_j - q) + (Wf f_j + b): the feature part
+    G_j = Wf f_j + b depends on the SOURCE point only and is computed once per level (N_i rows) instead of once per
+    (query, sample) pair (Vg * S rows), and the grouped row shrinks from 3 + C (up to 387) to 3 + H = 35 columns
+    [x_j - q ; G_j] against the weight [Wx | I].  The coordinate difference is still formed first, in fp32, as the
+    reference does; only the summation order of the feature dot product changes."""
+    key = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    hit = getattr(seq, "_g4d_split", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    lin0, lin2 = seq[0], seq[2]
+    H, dev = lin0.out_features, lin0.weight.device
+    with torch.no_grad():
+        W = lin0.weight.detach().float()
+        ones, zeros = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+        table = fused.PackedLayer(W[:, 3:].contiguous(), ones, lin0.bias.detach().float(), relu=False)
+        first = fused.PackedLayer(torch.cat([W[:, :3], torch.eye(H, device=dev)], 1), ones, zeros, relu=True)
+        second = fused.PackedLayer(lin2.weight.detach().float(), torch.ones(lin2.out_features, device=dev), lin2.bias.detach().float(),
+                                   relu=False)
+    seq._g4d_split = (key, table, [first, second])
+    return table, [first, second]
+
+
+def _pe_stack(layers, idx, nsample, xyz, new_xyz, feats_pm, out, col0):
+    """grouped [x_j - q ; feats_j] rows -> layers -> max over the samples, into out[..., col0:col0+Cout]."""
     F_, N, _ = xyz.shape
     Vg = new_xyz.shape[1]
     C = feats_pm.shape[2]
-    layers = _pack_linear_mlp(mlp)
-    idx = fused.ball_query_msg([radius], [nsample], xyz, new_xyz)[0]
     rows = F_ * Vg * nsample
     grp = (N, Vg, C, 1, xyz, new_xyz, feats_pm, idx)
-    if nsample in (16, 32, 64):
+    if fused.stack_fits(layers, 1, nsample, rows=rows):
         fused.mlp_stack(1, rows, 3 + C, layers, out, col0=col0, pool=1, S=nsample, group=grp)
-    else:  # 8 / 4 samples: un-pooled stack output, then the row-pool kernel
+    else:  # other window sizes: un-pooled stack output, then the row-pool kernel
         tmp = torch.empty((rows, layers[-1].Cout), dtype=torch.float32, device=xyz.device)
         fused.mlp_stack(1, rows, 3 + C, layers, tmp, pool=0, S=nsample, group=grp)
         fused._pool_rows(tmp, F_ * Vg, nsample, out, col0, True)
+
+
+def _pe_kernel_weights(seq, n_in):
+    """Operands of g4d_pos_encode_f32 for Sequential(Linear(3+C, 32), ReLU, Linear(32, 32)): W1 restricted to the first
+    n_in input columns (row-major), b1, the second Linear in MFMA fragment order, b2.  None when the shapes differ."""
+    if not (len(seq) == 3 and isinstance(seq[0], nn.Linear) and isinstance(seq[1], nn.ReLU) and isinstance(seq[2], nn.Linear)
+            and seq[0].out_features == 32 and seq[2].in_features == 32 and seq[2].out_features == 32 and seq[2].bias is not None
+            and seq[0].bias is not None):
+        return None
+    key = (tuple((p.data_ptr(), p._version) for p in seq.parameters()), n_in)
+    hit = getattr(seq, "_g4d_pe", None)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            W1 = seq[0].weight.detach().float()[:, :n_in].contiguous()
+            second = fused.PackedLayer(seq[2].weight.detach().float(), torch.ones(32, device=W1.device), seq[2].bias.detach().float(), relu=False)
+            hit = (key, (W1, seq[0].bias.detach().float().contiguous(), second.Wf, seq[2].bias.detach().float().contiguous()))
+        seq._g4d_pe = hit
+    return hit[1]
+
+
+def positional_encoding(mlp, radius, nsample, xyz, new_xyz, feats_pm, out, col0, idx=None, table=None):
+    """QueryAndGroup(radius, nsample, use_xyz=True) -> mlp -> max over samples, into out[..., col0:col0+Cout].
+    xyz (F,N,3) cloud, new_xyz (F,Vg,3) queries, feats_pm (F,N,C) point-major.  idx: precomputed ball query;
+    table: precomputed per-source-point first-layer feature part (see _split_first_linear) for wide features.
+    The reference's shapes (hidden = out = 32, nsample a power of two <= 64, C <= 5 or a table) run on the dedicated
+    wave-autonomous kernel (csrc/pos_encode.hip); anything else on the generic fused stack."""
+    if idx is None:
+        idx = fused.ball_query_msg([radius], [nsample], xyz, new_xyz)[0]
+    F_, N, _ = xyz.shape
+    Vg = new_xyz.shape[1]
+    C = feats_pm.shape[2]
+    n_extra = 0 if table is not None else C
+    w = _pe_kernel_weights(mlp, 3 + n_extra) if (USE_PE_KERNEL and nsample in (4, 8, 16, 32, 64) and n_extra <= 5) else None
+    if w is not None:
+        W1, b1, W2f, b2 = w
+        _lib.call("g4d_pos_encode_f32", F_, N, Vg, nsample, n_extra, xyz.data_ptr(), new_xyz.data_ptr(),
+                  feats_pm.data_ptr() if n_extra else 0, table.data_ptr() if table is not None else 0, idx.data_ptr(), W1.data_ptr(),
+                  0 if table is not None else b1.data_ptr(), W2f.data_ptr(), b2.data_ptr(), out.data_ptr(), out.shape[-1], col0, _lib.stream_ptr())
+    elif table is not None:
+        _pe_stack(_split_first_linear(mlp)[1], idx, nsample, xyz, new_xyz, table, out, col0)
+    else:
+        _pe_stack(_pack_linear_mlp(mlp), idx, nsample, xyz, new_xyz, feats_pm, out, col0)
+
+
+def feature_table(mlp, feats_pm):
+    """G = Wf f + b for every source point: (F,N,C) -> (F,N,H).  Constant over the refinement rounds."""
+    t = _split_first_linear(mlp)[0]
+    F_, N, C = feats_pm.shape
+    return fused.linear(feats_pm.reshape(F_ * N, C), t).view(F_, N, -1)
 
 
 class GarmentRefinementHead(nn.Module):
@@ -114,17 +188,22 @@ class GarmentRefinementHead(nn.Module):
         n_frames = nbatch * T
         cur = cur_garment_v.contiguous()
         outs, lbs_iter_feat = [], []
+        # per-source-point first-layer tables of the garment encoders: the garment levels do not change over the rounds
+        tables = [feature_table(garm_pe[i], garment_f_list[i].contiguous()) if garment_f_list[i].shape[2] > self.feat_num else None
+                  for i in range(3)]
         for it in range(self.iteration):
             width = self.graph_start_feature_dim + (self.hidden_dim if it > 0 else 0)
             feat = torch.empty((F_, Vg, width), dtype=torch.float32, device=dev)
             feat[..., :3] = cur                                                      # cur_positional_encoding (:465)
             col = 3
+            body_idx = fused.ball_query_msg(self.body_radius_list, self.body_sample_num_list, body_v, cur)   # one pass, 3 radii
             for i in range(3):                                                       # :452-457
-                positional_encoding(body_pe[i], self.body_radius_list[i], self.body_sample_num_list[i], body_v, cur, body_vn, feat, col)
+                positional_encoding(body_pe[i], self.body_radius_list[i], self.body_sample_num_list[i], body_v, cur, body_vn, feat, col,
+                                    idx=body_idx[i])
                 col += self.feat_num
             for i in range(3):                                                       # :459-464
                 positional_encoding(garm_pe[i], self.garment_radius_list[i], self.garment_sample_num_list[i], garment_v_list[i], cur,
-                                    garment_f_list[i], feat, col)
+                                    garment_f_list[i], feat, col, table=tables[i])
                 col += self.feat_num
             if it > 0:                                                               # :467-476
                 feat[..., col:] = gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group)

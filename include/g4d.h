@@ -125,7 +125,7 @@ int g4d_gcn_linear_f32(int frames, int vg, int fin, const float *X, int ldx, con
  * 2 INTERP (n,m,C2,C1,known_feats,skip,dist2,nn_idx) | 3 CSR (X,ldx,Vg,rowptr,colidx,vals); arguments of the other
  * modes are ignored.  Layers are parallel HOST arrays of length nlayers; scale/shift as for g4d_linear_f32, but W[l]
  * is in FRAGMENT order [CoutPad64/16][Kpad/16][64][4]: element ((t*(Kpad/16) + s)*64 + q*16 + i)*4 + e holds
- * W[16t + i][16s + 4q + e], so that one B-fragment load of a wave is a contiguous 1 KB read.  pool over S in {16,32,64} rows applies to the last layer.  tap_out (or NULL): hidden layer
+ * W[16t + i][16s + 4q + e], so that one B-fragment load of a wave is a contiguous 1 KB read.  pool over S in {4,8,16,32,64} rows applies to the last layer.  tap_out (or NULL): hidden layer
  * `tap_layer`'s output is also stored, rows x tap_ld. */
 int g4d_mlp_stack_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
                       const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
@@ -220,7 +220,7 @@ int g4d_knn_f32(int b, int p1, int p2, int k, const float *queries, const float 
 
 /* Inverse-distance blend of the K nearest body vertices' skinning weights (modules/mesh_encoder.py:339-347, 374-382):
  * out (F,Vg,J) = sum_k w_k W[f, idx[c,v,k], :],  c = f / frames_per_clip,  w = normalised 1/d with the reference's two
- * "inf -> 0" fix-ups.  W (F,V,J); idx / dists (F/frames_per_clip, Vg, K) from g4d_knn_f32.  J <= 64. */
+ * "inf -> 0" fix-ups.  W (F,V,J); idx / dists (F/frames_per_clip, Vg, K) from g4d_knn_f32.  K <= 256, J <= 64. */
 int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, int k, int j, const float *W, const int *idx,
                               const float *dists, float *out, g4d_stream_t stream);
 
@@ -228,6 +228,17 @@ int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, in
  * out (F,Vg,C) = S + coeff * (adj (CSR) . S).  out must not alias S (ping-pong two buffers for the 100 steps). */
 int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
                            const float *vals, float coeff, float *out, g4d_stream_t stream);
+
+/* One positional encoder of the refinement loop (modules/mesh_encoder.py:452-464): for every query q of new_xyz
+ * (frames,p,3) and its nsample ball-query hits j = idx (frames,p,nsample) in xyz (frames,n,3):
+ *   h = relu(W1 [x_j - q ; extra_j] + b1 + table_j),   y = W2 h + b2,   out[f*p + q, col0 .. col0+32) = max_j y
+ * extra (frames,n,n_extra) or NULL (n_extra = 0); table (frames,n,32) or NULL: per-source-point part of the first
+ * Linear (Wf f_j + b, see garment4d_amd/refine.py); W1 (32, 3+n_extra) row-major; b1 (32) or NULL (then table must be
+ * given); W2_frag: the 32x32 second Linear in the fragment order of g4d_mlp_stack_f32; b2 (32).  nsample in
+ * {4,8,16,32,64}.  Hidden and output width are the reference's feat_num = 32. */
+int g4d_pos_encode_f32(int frames, int n, int p, int nsample, int n_extra, const float *xyz, const float *new_xyz,
+                       const float *extra, const float *table, const int *idx, const float *W1, const float *b1,
+                       const float *W2_frag, const float *b2, float *out, int ldo, int col0, g4d_stream_t stream);
 
 /* Ordered per-frame compaction of `calc_segmentation_results` (modules/mesh_encoder.py:109-125): sel (frames,n_out) = the
  * indices k (ascending) of the points whose arg-max over `classes` logits (first maximum wins) equals `target`, the

@@ -1,0 +1,55 @@
+"""Time the full wired model (BASELINE cfg4 shape: encoder + garment encoder + LBS garment interpolation + 3 refinement
+rounds) on one GPU.  usage: python scripts/time_model.py [nbatch] [T] [N] [iters]"""
+import os
+import sys
+import time
+import types
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from garment4d_amd import synthetic as syn
+from garment4d_amd.encoder import seed_encoder
+from garment4d_amd.mesh_encoder import PCALBSGarmentUseSegEncoderSeg, label_dict
+
+nbatch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+scene = syn.garment_scene(nbatch, T, N, body_rc=(65, 106), garment_rc=(64, 64), seed=1)
+m = PCALBSGarmentUseSegEncoderSeg(garment_name="Tshirt", pca_dim=64, pca=scene["pca"], template=scene["template"], lbs_k=256, iteration=3)
+seed_encoder(m.PCA_garment_encoder, 0)
+with torch.no_grad():
+    for name, p in m.named_parameters():
+        if not name.startswith("PCA_garment_encoder."):
+            p.mul_(0.5)
+m = m.cuda().eval()
+m.PCA_garment_encoder.channel_major_outputs = False
+x = dev(scene["x"])
+batch = {k: dev(v) for k, v in scene["batch"].items()}
+body = scene["body"]
+bm = types.SimpleNamespace(parents=torch.from_numpy(body["parents"]).cuda(), faces=body["faces"], J_regressor=dev(body["J_regressor"]),
+                           v_template=dev(body["v_template"]))
+with torch.no_grad():
+    logits = m.PCA_garment_encoder.pointnet.forward_fused(x.reshape(-1, N, 3))[1]
+    tgt = label_dict["Tshirt"] - 1
+    others = torch.cat([logits[..., :tgt], logits[..., tgt + 1:]], -1).max(-1)[0]
+    m.PCA_garment_encoder.pointnet.FC_layer[2].conv.bias[tgt] += torch.quantile((others - logits[..., tgt]).flatten()[:1000000], 0.35)
+    for _ in range(2):
+        out = m(x, bm, batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = m(x, bm, batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+print(f"nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
+      f"{nbatch*T/dt:.1f} frames/s; finite={bool(torch.isfinite(out['iter_regressed_lbs_garment_v'][-1]).all())}")

@@ -125,3 +125,30 @@ def test_stack_kernel_equals_per_layer_kernels(use_stack, monkeypatch):
     for a, b in zip(f1[1:], f0[1:]):
         close(a, b.cpu().numpy())
     close(f1[0], f0[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("S", [4, 8, 16, 64])
+@pytest.mark.parametrize("widths,pool", [((6, 32, 32), 1), ((70, 32, 32), 1), ((70, 64, 48), 2)])
+def test_stack_pool_windows(S, widths, pool, precision, monkeypatch):
+    """Fused pooling over S = 4 / 8 (the refinement loop's ball sizes, mesh_encoder.py:180-189) .. 64 samples equals the
+    un-pooled stack followed by the row-pool kernel -- bit for bit, the reduction is a max / the same fp32 mean."""
+    monkeypatch.setattr(fused, "PRECISION", precision)
+    g = torch.Generator().manual_seed(S)
+    rows = 8192 + 3 * S * 4          # not a multiple of the 64-row tile; >= 8192 so that bf16 mode takes the bf16 kernel
+    layers = []
+    for cin, cout in zip(widths[:-1], widths[1:]):
+        layers.append(fused.PackedLayer(torch.randn(cout, cin, generator=g).cuda() * 0.3, (torch.rand(cout, generator=g) + 0.5).cuda(),
+                                        torch.randn(cout, generator=g).cuda() * 0.1, relu=True))
+    X = torch.randn(rows, widths[0], generator=g).cuda()
+    assert fused.stack_fits(layers, pool, S, rows=rows)
+    full = torch.empty((rows, widths[-1]), device="cuda")
+    fused.mlp_stack(0, rows, widths[0], layers, full, X=X, ldx=widths[0])
+    want = torch.empty((rows // S, widths[-1] + 3), device="cuda").fill_(7.0)
+    fused._pool_rows(full, rows // S, S, want, 2, pool == 1)
+    got = torch.empty_like(want).fill_(7.0)
+    fused.mlp_stack(0, rows, widths[0], layers, got, col0=2, pool=pool, S=S, X=X, ldx=widths[0])
+    if pool == 1:
+        assert torch.equal(got, want)
+    else:
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)

@@ -70,3 +70,31 @@ def test_lbs_garment_interpolation_vs_oracle(K):
     assert np.array_equal(nn1.idx.cpu().numpy(), wi)
     np.testing.assert_allclose(got_inv.cpu().numpy(), want_inv, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(got_v.cpu().numpy(), want_v, rtol=1e-4, atol=1e-4)  # 100 smoothing steps compound fp32 rounding
+
+
+def test_smoothing_operator_equals_jacobi_steps():
+    """(I + 0.1 (D^-1 A - I))^100 as one dense GEMM against the 100 sparse steps (mesh_encoder.py:385-390)."""
+    from garment4d_amd.garment_lbs import smooth_weights
+    _, adj_old = _quad_adj_old(20, 24)
+    Vg = adj_old.shape[0]
+    W = torch.rand(5, Vg, 24, device="cuda") ** 3
+    W = W / W.sum(-1, keepdim=True)
+    a = smooth_weights(W, adj_old, 0.1, 100, method="jacobi")
+    b = smooth_weights(W, adj_old, 0.1, 100, method="operator")
+    torch.testing.assert_close(b, a, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(b.sum(-1), torch.ones(5, Vg, device="cuda"), rtol=1e-5, atol=1e-5)   # rows stay convex weights
+
+
+@pytest.mark.parametrize("K,J", [(256, 24), (7, 24), (64, 40), (1, 3)])
+def test_knn_blend_weights_vs_oracle(K, J):
+    from garment4d_amd.garment_lbs import _blend
+    rng = np.random.default_rng(K)
+    F_, T, V, Vg = 6, 3, 500, 130
+    W = rng.random((F_, V, J)).astype(np.float32)
+    idx = rng.integers(0, V, (F_ // T, Vg, K)).astype(np.int32)
+    d = rng.random((F_ // T, Vg, K)).astype(np.float32)
+    d[0, :5, 0] = 0.0                      # a query sitting on a body vertex: 1/0 = inf -> weight 0 (the reference's fix-up)
+    got = _blend(dev(W), dev(idx), dev(d), T).cpu().numpy()
+    w = RO._interp_weights(d)              # (clips, Vg, K)
+    want = np.stack([(W[f][idx[f // T]] * w[f // T][..., None]).sum(-2) for f in range(F_)])
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
