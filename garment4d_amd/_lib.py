@@ -44,6 +44,8 @@ SIGNATURES = {
     "g4d_knn_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_knn_blend_weights_f32": [_I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_pos_encode_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp],
+    "g4d_temporal_attention_scratch_floats": [_I, _I, _I],
+    "g4d_temporal_attention_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp],
     "g4d_segment_select_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_segment_take_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_vertex_normals_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -57,6 +59,9 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+RESTYPES = {"g4d_temporal_attention_scratch_floats": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):
@@ -75,7 +80,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.argtypes = args
-            fn.restype = _I
+            fn.restype = RESTYPES.get(name, _I)
         L.g4d_version.restype = _I
         L.g4d_last_error.restype = ctypes.c_char_p
         _lib = L

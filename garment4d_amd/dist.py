@@ -64,19 +64,41 @@ def clip_max_over_frames(frame_feats_local: torch.Tensor, frame_ids_local: torch
 
 
 def temporal_attention(last_feat_local: torch.Tensor, frame_ids_local: torch.Tensor, n_frames: int, T: int, qkv,
-                       group=None) -> torch.Tensor:
+                       group=None, out=None, col0: int = 0) -> torch.Tensor:
     """The reference's temporal attention (mesh_encoder.py:467-476) for frame-sharded features: k, v of ALL T frames
-    of a clip are needed, so the per-frame features are all-gathered once, q/k/v are computed locally, and each rank
-    evaluates the softmax(q k^T / sqrt(T)) v rows of its own frames.
+    of a clip are needed, so the per-frame features are all-gathered once (RCCL all-gather; skipped with group=False or
+    without an initialised process group), q/k/v are computed locally, and each rank keeps the rows of its own frames.
     last_feat_local (f_local, Vg, C); qkv: the per-vertex Linear(C -> 3C) (`temporal_qkv_*`, bias-free), any callable
-    mapping (..., C) -> (..., 3C).  The two T x T x (Vg*C) contractions are plain library GEMMs (torch.matmul)."""
-    feats = allgather_frames(last_feat_local, n_frames, group) if (dist.is_initialized() and group is not False) else last_feat_local
+    mapping (..., C) -> (..., 3C).  On the GPU the two skinny contractions run on the HIP kernels of csrc/attention.hip
+    (T <= 32, C % 16 == 0); on CPU tensors (the gloo tests) with torch.matmul.
+    out/col0: optional (f_local, Vg, >= col0 + C) buffer to write the result into (only when nothing is sharded)."""
+    sharded = dist.is_initialized() and group is not False and dist.get_world_size(group) > 1
+    feats = allgather_frames(last_feat_local, n_frames, group) if sharded else last_feat_local
     F_, Vg, C = feats.shape
     n_clips = F_ // T
-    q, k, v = qkv(feats.reshape(n_clips, T, Vg, C)).chunk(3, dim=-1)              # each (clips, T, Vg, C)
-    q = q.reshape(n_clips, T, Vg * C)
-    k = k.reshape(n_clips, T, Vg * C)
-    v = v.reshape(n_clips, T, Vg * C)
-    att = torch.softmax(torch.matmul(q, k.transpose(1, 2)).reshape(n_clips, T, T) / (T ** 0.5), dim=-1)
-    out = torch.matmul(att, v).reshape(F_, Vg, C)
-    return out[frame_ids_local.long()]
+    qkv_all = qkv(feats.reshape(n_clips * T, Vg, C))                              # (F, Vg, 3C)
+    if feats.is_cuda and T <= 32 and C % 16 == 0:
+        from . import _lib
+        qkv_all = qkv_all.contiguous()
+        direct = out is not None and not sharded
+        res = out if direct else torch.empty((F_, Vg, C), dtype=torch.float32, device=feats.device)
+        nscr = _lib.lib().g4d_temporal_attention_scratch_floats(n_clips, Vg, C)
+        scratch = torch.empty(nscr, dtype=torch.float32, device=feats.device)
+        att = torch.empty((n_clips, T, T), dtype=torch.float32, device=feats.device)
+        _lib.call("g4d_temporal_attention_f32", n_clips, T, Vg, C, qkv_all.data_ptr(), scratch.data_ptr(), att.data_ptr(), res.data_ptr(),
+                  res.shape[-1], col0 if direct else 0, _lib.stream_ptr())
+        if direct:
+            return out
+        res = res if not sharded else res[frame_ids_local.long()]
+    else:
+        q, k, v = qkv_all.reshape(n_clips, T, Vg, 3 * C).chunk(3, dim=-1)             # each (clips, T, Vg, C)
+        q = q.reshape(n_clips, T, Vg * C)
+        k = k.reshape(n_clips, T, Vg * C)
+        v = v.reshape(n_clips, T, Vg * C)
+        att = torch.softmax(torch.matmul(q, k.transpose(1, 2)).reshape(n_clips, T, T) / (T ** 0.5), dim=-1)
+        res = torch.matmul(att, v).reshape(F_, Vg, C)
+        res = res if not sharded else res[frame_ids_local.long()]
+    if out is not None:
+        out[..., col0:col0 + C] = res
+        return out
+    return res

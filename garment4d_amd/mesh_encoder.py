@@ -179,8 +179,10 @@ class PCALBSGarmentUseSegEncoderSeg(GarmentRefinementHead):
         nbatch, T = x.size(0), x.size(1)
         dev = x.device
         out = self.PCA_garment_encoder(x, body_model)
-        lap_adj = sp.eye(self.adj_old.shape[0]) - gcn.normalize(self.adj_old)
-        out["lap_adj"] = gcn.sparse_mx_to_torch_sparse_tensor(lap_adj).to(dev)
+        if getattr(self, "_lap_adj", None) is None or self._lap_adj.device != dev:     # constant of the mesh: built once
+            lap_adj = sp.eye(self.adj_old.shape[0]) - gcn.normalize(self.adj_old)
+            self._lap_adj = gcn.sparse_mx_to_torch_sparse_tensor(lap_adj).to(dev)
+        out["lap_adj"] = self._lap_adj
         body_v = batch["smpl_vertices_torch"].to(dev).reshape(nbatch * T, -1, 3).contiguous()
         if self.vf_fid is None or self.vf_vid is None:
             self.vf_fid, self.vf_vid = mesh_utils.calc_body_mesh_info(body_model)

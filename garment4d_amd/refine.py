@@ -206,7 +206,7 @@ class GarmentRefinementHead(nn.Module):
                                     garment_f_list[i], feat, col, table=tables[i])
                 col += self.feat_num
             if it > 0:                                                               # :467-476
-                feat[..., col:] = gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group)
+                gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group, out=feat, col0=col)
             h = feat
             for i, m in enumerate(regress[it]):                                      # :477-481
                 h = m(h, adj, False, relu=(i != 3))

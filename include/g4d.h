@@ -19,6 +19,8 @@
 #ifndef G4D_H
 #define G4D_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -239,6 +241,14 @@ int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S, const int 
 int g4d_pos_encode_f32(int frames, int n, int p, int nsample, int n_extra, const float *xyz, const float *new_xyz,
                        const float *extra, const float *table, const int *idx, const float *W1, const float *b1,
                        const float *W2_frag, const float *b2, float *out, int ldo, int col0, g4d_stream_t stream);
+
+/* Temporal attention of a refinement round (modules/mesh_encoder.py:467-476) for nclips clips of t <= 32 frames:
+ * qkv (nclips*t, vg, 3c) = temporal_qkv(last_feat), [q | k | v] per vertex;  att (nclips, t, t) = softmax over the last axis
+ * of q k^T / sqrt(t) with q, k flattened over (vg, c);  out[(clip*t + frame), vertex, col0 .. col0+c) = att v, row stride
+ * ldo floats per vertex.  scratch: g4d_temporal_attention_scratch_floats(nclips, vg, c) floats.  c % 16 == 0. */
+size_t g4d_temporal_attention_scratch_floats(int nclips, int vg, int c);
+int g4d_temporal_attention_f32(int nclips, int t, int vg, int c, const float *qkv, float *scratch, float *att, float *out, int ldo,
+                               int col0, g4d_stream_t stream);
 
 /* Ordered per-frame compaction of `calc_segmentation_results` (modules/mesh_encoder.py:109-125): sel (frames,n_out) = the
  * indices k (ascending) of the points whose arg-max over `classes` logits (first maximum wins) equals `target`, the

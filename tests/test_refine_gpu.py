@@ -96,3 +96,20 @@ def test_attention_only_mixes_frames_of_a_clip():
     b = _run(head, cur2, body_v, body_vn, gv, gf, adj, nbatch, T)
     assert torch.equal(a[-1][:T], b[-1][:T])
     assert not torch.equal(a[-1][T:], b[-1][T:])
+
+
+@pytest.mark.parametrize("nclips,T,Vg,C", [(2, 30, 300, 128), (1, 3, 17, 16), (3, 32, 64, 48), (1, 1, 5, 32)])
+def test_temporal_attention_kernels(nclips, T, Vg, C):
+    """csrc/attention.hip against float64 torch (mesh_encoder.py:467-476), written at a column offset."""
+    from garment4d_amd import dist as gdist
+    g = torch.Generator().manual_seed(T)
+    feats = torch.randn(nclips * T, Vg, C, generator=g).cuda()
+    lin = torch.nn.Linear(C, 3 * C, bias=False).cuda()
+    with torch.no_grad():
+        lin.weight.mul_(0.3)
+        out = torch.full((nclips * T, Vg, C + 5), 9.0, device="cuda")
+        gdist.temporal_attention(feats, torch.arange(nclips * T).cuda(), nclips * T, T, lin, group=False, out=out, col0=3)
+        q, k, v = [z.reshape(nclips, T, Vg * C).double() for z in lin(feats).reshape(nclips, T, Vg, 3 * C).chunk(3, -1)]
+        want = (torch.softmax(q @ k.transpose(1, 2) / T ** 0.5, -1) @ v).reshape(nclips * T, Vg, C).float()
+    assert (out[..., :3] == 9.0).all() and (out[..., 3 + C:] == 9.0).all()
+    torch.testing.assert_close(out[..., 3:3 + C], want, rtol=2e-4, atol=2e-5)
