@@ -22,6 +22,7 @@ SIGNATURES = {
     "g4d_gather_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_ball_query_f32": [_I, _I, _I, _F, _I, _vp, _vp, _vp, _vp],
     "g4d_ball_query_msg_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_ball_query_boxes_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_group_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_group_grad_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_three_nn_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],

@@ -31,9 +31,39 @@ struct BqArgs {
 
 constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered
 
-template <int QW, int NS>
+// boxes: per (frame, 64-point block) axis-aligned bounds [lo.xyz, hi.xyz], written by ball_boxes_kernel
+__global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long long total, const float *__restrict__ xyz_all,
+                                                        float *__restrict__ boxes) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= total) return;
+    const long long b = w / nblk;
+    const int blk = (int)(w - b * nblk);
+    const int k = blk * 64 + lane;
+    const float inf = __builtin_inff();
+    float lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float v = k < n ? xyz_all[((size_t)b * n + k) * 3 + d] : 0.f;
+        lo[d] = k < n ? v : inf;
+        hi[d] = k < n ? v : -inf;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+        }
+    if (lane == 0) {
+        float *o = boxes + (size_t)w * 6;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+    }
+}
+
+template <int QW, int NS, bool BOXES>
 __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
-                                                        const float *__restrict__ xyz_all) {
+                                                        const float *__restrict__ xyz_all, const float *__restrict__ boxes_all) {
     __shared__ float sp[2][3][kStage];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -85,6 +115,55 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
         const bool more = base + kStage < n;
         if (more) load_stage(base + kStage);  // in flight while this stage is consumed
         const int cn = min(kStage, n - base);
+        if (BOXES) {
+            // Mesh-ordered clouds: consecutive indices are neighbours in space, so most 64-point blocks lie wholly outside
+            // a query's largest still-open ball.  Lane l < 16 tests block l of the stage against the query with the SAME
+            // un-fused fp32 expression as the point test: rounding is monotone, so box d2 <= d2 of every point inside
+            // the box and a block holding a hit is never skipped.  Blocks are then visited in ascending order, so the
+            // "first nsample hits by index" semantics is untouched.
+            const int nblk = (n + 63) >> 6;
+            const int sb = base >> 6, nb_stage = (cn + 63) >> 6;
+            const float *bx = boxes_all + ((size_t)b * nblk + sb + min(lane, nb_stage - 1)) * 6;
+            const float lox = bx[0], loy = bx[1], loz = bx[2], hix = bx[3], hiy = bx[4], hiz = bx[5];
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                float r2open = -1.f;  // largest radius^2 among this query's scales that still collect
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (cnt[i][s] < a.nsample[s]) r2open = fmaxf(r2open, a.radius2[s]);
+                if (r2open < 0.f) continue;
+                const float ex = fmaxf(fmaxf(lox - qx[i], qx[i] - hix), 0.f), ey = fmaxf(fmaxf(loy - qy[i], qy[i] - hiy), 0.f),
+                            ez = fmaxf(fmaxf(loz - qz[i], qz[i] - hiz), 0.f);
+                const float bd2 = ex * ex + ey * ey + ez * ez;
+                unsigned cand = (unsigned)__builtin_amdgcn_ballot_w64(lane < nb_stage && bd2 < r2open);
+                while (cand) {
+                    const int c = __builtin_ctz(cand) << 6;
+                    cand &= cand - 1;
+                    const int k = base + c + lane;
+                    const float x = sp[buf][0][c + lane], y = sp[buf][1][c + lane], z = sp[buf][2][c + lane];
+                    const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    if (__builtin_amdgcn_ballot_w64(d2 < r2open) == 0ull) continue;
+                    bool any_open = false;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
+                            const bool hit = d2 < a.radius2[s];
+                            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                            if (mask != 0ull) {
+                                if (cnt[i][s] == 0) first[i][s] = base + c + __builtin_ctzll(mask);
+                                const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
+                                cnt[i][s] += __builtin_popcountll(mask);
+                                if (cnt[i][s] >= a.nsample[s]) --open;
+                            }
+                            any_open |= cnt[i][s] < a.nsample[s];
+                        }
+                    }
+                    if (!any_open) break;
+                }
+            }
+        } else
         for (int c = 0; c < cn && open > 0; c += 64) {
             const int k = base + c + lane;
             // lanes past the end of the cloud hold +inf coordinates (stage loader) -> never a hit, no `valid` predicate
@@ -126,17 +205,18 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
 }
 
-template <int NS>
-static void launch_bq(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz) {
-    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
-    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
-    else hipLaunchKernelGGL((ball_query_kernel<1, NS>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
+template <int NS, bool BOXES>
+static void launch_bq(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
+                      const float *boxes) {
+    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS, BOXES>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS, BOXES>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+    else hipLaunchKernelGGL((ball_query_kernel<1, NS, BOXES>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
 }
 
 }  // namespace g4d
 
-extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
-                                      const float *new_xyz, const float *xyz, int *const *idx, g4d_stream_t stream) {
+static int ball_query_msg_impl(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                               const float *xyz, int *const *idx, float *boxes, g4d_stream_t stream) {
     using namespace g4d;
     G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nscales >= 1 && nscales <= 4 && b <= 65535, "g4d_ball_query_msg_f32: bad sizes");
     G4D_REQUIRE(radii && nsamples && idx, "g4d_ball_query_msg_f32: null pointer");
@@ -161,13 +241,36 @@ extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const fl
     int qw = 4;
     while (qw > 1 && queries / qw < 2048) qw >>= 1;
     dim3 grid((m + 4 * qw - 1) / (4 * qw), b);
+    if (boxes) {
+        const int nblk = (n + 63) / 64;
+        const long long total = (long long)b * nblk;
+        hipLaunchKernelGGL(ball_boxes_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
+        switch (nscales) {
+            case 1: launch_bq<1, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            case 2: launch_bq<2, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            case 3: launch_bq<3, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            default: launch_bq<4, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+        }
+        return check_launch("g4d_ball_query_boxes_f32");
+    }
     switch (nscales) {
-        case 1: launch_bq<1>(qw, grid, st, n, m, a, new_xyz, xyz); break;
-        case 2: launch_bq<2>(qw, grid, st, n, m, a, new_xyz, xyz); break;
-        case 3: launch_bq<3>(qw, grid, st, n, m, a, new_xyz, xyz); break;
-        default: launch_bq<4>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        case 1: launch_bq<1, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
+        case 2: launch_bq<2, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
+        case 3: launch_bq<3, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
+        default: launch_bq<4, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
     }
     return check_launch("g4d_ball_query_msg_f32");
+}
+
+extern "C" int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                      const float *new_xyz, const float *xyz, int *const *idx, g4d_stream_t stream) {
+    return ball_query_msg_impl(b, n, m, nscales, radii, nsamples, new_xyz, xyz, idx, nullptr, stream);
+}
+
+extern "C" int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                        const float *new_xyz, const float *xyz, int *const *idx, float *boxes, g4d_stream_t stream) {
+    G4D_REQUIRE(boxes != nullptr, "g4d_ball_query_boxes_f32: boxes scratch is NULL");
+    return ball_query_msg_impl(b, n, m, nscales, radii, nsamples, new_xyz, xyz, idx, boxes, stream);
 }
 
 extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,

@@ -256,8 +256,9 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
     _pool_rows(h, rows // S, S, out, col0, pool == 1)
 
 
-def ball_query_msg(radii, nsamples, xyz, new_xyz):
-    """All scales of an MSG layer in one pass over the cloud; returns one (B,P,nsample) int32 tensor per scale."""
+def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False):
+    """All scales of an MSG layer in one pass over the cloud; returns one (B,P,nsample) int32 tensor per scale.
+    coherent=True: the cloud's index order is spatially coherent (mesh vertices) -> block-bounds skipping (same results)."""
     import ctypes
     B, N, _ = xyz.shape
     P = new_xyz.shape[1]
@@ -268,8 +269,13 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz):
         R = (ctypes.c_float * n)(*[float(r) for r in radii[done:done + n]])
         NS = (ctypes.c_int * n)(*[int(v) for v in nsamples[done:done + n]])
         IP = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs[done:done + n]])
-        _lib.call("g4d_ball_query_msg_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
-                  new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), _lib.stream_ptr())
+        if coherent and N >= 256:
+            boxes = torch.empty((B, (N + 63) // 64, 6), dtype=torch.float32, device=xyz.device)
+            _lib.call("g4d_ball_query_boxes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
+                      new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), boxes.data_ptr(), _lib.stream_ptr())
+        else:
+            _lib.call("g4d_ball_query_msg_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
+                      new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), _lib.stream_ptr())
         done += n
     return outs
 

@@ -196,7 +196,7 @@ class GarmentRefinementHead(nn.Module):
             feat = torch.empty((F_, Vg, width), dtype=torch.float32, device=dev)
             feat[..., :3] = cur                                                      # cur_positional_encoding (:465)
             col = 3
-            body_idx = fused.ball_query_msg(self.body_radius_list, self.body_sample_num_list, body_v, cur)   # one pass, 3 radii
+            body_idx = fused.ball_query_msg(self.body_radius_list, self.body_sample_num_list, body_v, cur, coherent=True)   # one pass, 3 radii
             for i in range(3):                                                       # :452-457
                 positional_encoding(body_pe[i], self.body_radius_list[i], self.body_sample_num_list[i], body_v, cur, body_vn, feat, col,
                                     idx=body_idx[i])

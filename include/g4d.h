@@ -67,6 +67,14 @@ int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const flo
 int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
                            const float *new_xyz, const float *xyz, int *const *idx, g4d_stream_t stream);
 
+/* g4d_ball_query_msg_f32 for clouds whose index order is spatially coherent (mesh vertices in mesh order: the body and
+ * garment queries of modules/mesh_encoder.py:452-464): a pre-pass writes the bounds of every 64-point block into `boxes`
+ * (b * ceil(n/64) * 6 floats of scratch) and the search skips blocks that lie outside the largest still-open ball
+ * (monotone fp32 bound: never skips a hit).  Same results as g4d_ball_query_msg_f32 for ANY cloud; faster only for
+ * coherent ones (a few % slower for random order). */
+int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                             const float *xyz, int *const *idx, float *boxes, g4d_stream_t stream);
+
 /* group_points_kernel_launcher_fast (group_points_gpu.h:13-15): out[b,c,p,s] = points[b,c,idx[b,p,s]].
  * 64-bit offsets (the reference's int32 offsets wrap at 2^31 elements). */
 int g4d_group_f32(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,

@@ -181,6 +181,34 @@ def test_ball_query_msg_equals_single_scale(B, N, M, scales):
         assert np.array_equal(host(o), K.ball_query(r, ns, xyz, q))
 
 
+@pytest.mark.parametrize("kind", ["mesh", "random", "ties"])
+@pytest.mark.parametrize("B,N,M,scales", [(2, 6890, 700, [(0.1, 8), (0.2, 16), (0.4, 32)]), (1, 1030, 130, [(0.05, 4), (0.15, 64)]),
+                                          (3, 256, 50, [(0.3, 16)]), (1, 2500, 64, [(0.02, 8), (0.05, 8), (0.1, 8), (0.7, 32)])])
+def test_ball_query_block_bounds_skipping(B, N, M, scales, kind):
+    """g4d_ball_query_boxes_f32 (64-point block bounds; refinement-loop queries against mesh-ordered vertices) returns
+    exactly what the plain scan returns -- for mesh-ordered, random-ordered and duplicate-ridden clouds alike."""
+    from garment4d_amd import fused
+    rng = np.random.default_rng(N + M)
+    if kind == "mesh":      # a cylinder in row-major vertex order: consecutive indices are neighbours
+        cols = 53
+        rows = (N + cols - 1) // cols
+        v, _ = syn.quad_cylinder(rows, cols)
+        xyz = np.repeat(v[None, :N], B, 0) * np.array([1.5, 0.9, 1.5], np.float32) + rng.standard_normal((B, N, 3)).astype(np.float32) * 0.002
+    elif kind == "random":
+        xyz = syn.unit_cloud(B, N, seed=N)
+    else:
+        xyz = syn.body_like_cloud(B, N, seed=N, dup_frac=0.3, zero_frac=0.2)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    q = (xyz[:, rng.permutation(N)[:M]] + rng.standard_normal((B, M, 3)).astype(np.float32) * 0.03).astype(np.float32)
+    q[:, -1] = 9.0          # a query with no neighbour at all
+    radii, ns = [r for r, _ in scales], [n for _, n in scales]
+    plain = fused.ball_query_msg(radii, ns, dev(xyz), dev(q))
+    boxed = fused.ball_query_msg(radii, ns, dev(xyz), dev(q), coherent=True)
+    for (r, n_), a, b in zip(scales, plain, boxed):
+        assert torch.equal(a, b)
+        assert np.array_equal(host(b), K.ball_query(r, n_, xyz, q))
+
+
 def test_fps_without_scratch():
     """temp = NULL extension of g4d_fps_f32 (register-resident kernels)."""
     from garment4d_amd import _lib
