@@ -36,11 +36,11 @@ __global__ void __launch_bounds__(256) lbs_shape_kernel(int B, int V3, int NB, i
 }
 
 // joints[b,j,:] = sum_v jreg[(b),j,v] * verts[b,v,:]
-__global__ void __launch_bounds__(256) joint_regress_kernel(int J, int V, long long jreg_bstride, const float *__restrict__ jreg,
+__global__ void __launch_bounds__(256) joint_regress_kernel(int J, int V, long long jreg_bstride, int jreg_group, const float *__restrict__ jreg,
                                                            const float *__restrict__ verts, float *__restrict__ joints) {
     __shared__ float red[4][3];
     const int j = blockIdx.x, b = blockIdx.y;
-    const float *w = jreg + (size_t)b * jreg_bstride + (size_t)j * V;
+    const float *w = jreg + (size_t)(b / jreg_group) * jreg_bstride + (size_t)j * V;
     const float *vb = verts + (size_t)b * V * 3;
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int v = threadIdx.x; v < V; v += 256) {
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) lbs_pose_blend_kernel(int B, int E, int P
 
 // verts[b,v,:] = (sum_j W[(b),v,j] A[b,j]) . [v_in[b,v,:]; 1]   -- one thread per (frame, vertex), A[b] in LDS.
 __global__ void __launch_bounds__(256) lbs_skin_kernel(int V, int J, const float *__restrict__ v_in,
-                                                      const float *__restrict__ weights, long long w_bstride,
+                                                      const float *__restrict__ weights, long long w_bstride, int w_group,
                                                       const float *__restrict__ A, float *__restrict__ verts) {
     extern __shared__ float sA[];  // [J][12]
     const int b = blockIdx.y;
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(int V, int J, const float
     __syncthreads();
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
-    const float *w = weights + (size_t)b * w_bstride + (size_t)v * J;
+    const float *w = weights + (size_t)(b / w_group) * w_bstride + (size_t)v * J;
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
@@ -267,8 +267,9 @@ extern "C" int g4d_joint_regress_f32(int b, int j, int v, const float *jreg, int
     G4D_REQUIRE(b >= 0 && j >= 0 && v >= 0 && b <= 65535, "g4d_joint_regress_f32: bad size");
     if ((long long)b * j == 0) return G4D_OK;
     G4D_REQUIRE(jreg && verts && joints, "g4d_joint_regress_f32: null pointer");
+    G4D_REQUIRE(jreg_batched >= 0, "g4d_joint_regress_f32: jreg_batched must be >= 0");
     hipLaunchKernelGGL(joint_regress_kernel, dim3(j, b), dim3(256), 0, G4D_S(stream), j, v,
-                       jreg_batched ? (long long)j * v : 0ll, jreg, verts, joints);
+                       jreg_batched ? (long long)j * v : 0ll, jreg_batched ? jreg_batched : 1, jreg, verts, joints);
     return check_launch("g4d_joint_regress_f32");
 }
 
@@ -294,7 +295,7 @@ extern "C" int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *
 extern "C" int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const float *pose_feature,
                                      const float *posedirs, const float *weights, int weights_batched, const float *A,
                                      float *v_posed_scratch, float *verts, g4d_stream_t stream) {
-    G4D_REQUIRE(b >= 0 && v >= 0 && j > 0 && pf >= 0 && b <= 65535, "g4d_lbs_pose_skin_f32: bad size");
+    G4D_REQUIRE(b >= 0 && v >= 0 && j > 0 && pf >= 0 && b <= 65535 && weights_batched >= 0, "g4d_lbs_pose_skin_f32: bad size");
     if ((long long)b * v == 0) return G4D_OK;
     G4D_REQUIRE(v_in && weights && A && verts, "g4d_lbs_pose_skin_f32: null pointer");
     const float *skin_in = v_in;
@@ -309,6 +310,6 @@ extern "C" int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v
     }
     G4D_REQUIRE((size_t)j * 12 * sizeof(float) <= 64 * 1024, "g4d_lbs_pose_skin_f32: too many joints");
     hipLaunchKernelGGL(lbs_skin_kernel, dim3((v + 255) / 256, b), dim3(256), sizeof(float) * j * 12, G4D_S(stream), v, j, skin_in,
-                       weights, weights_batched ? (long long)v * j : 0ll, A, verts);
+                       weights, weights_batched ? (long long)v * j : 0ll, weights_batched > 0 ? weights_batched : 1, A, verts);
     return check_launch("g4d_lbs_pose_skin_f32");
 }

@@ -122,10 +122,21 @@ def lbs_garment_interpolation(pred_template_garment_v, Tpose_vertices, Tpose_roo
     inv_template_garment_v = inv_garment.reshape(B, 1, -1, 3).repeat(1, T, 1, 1).reshape(B * T, -1, 3).contiguous()
 
     zero_v = zeropose_vertices.reshape(B * T, -1, 3).contiguous()
-    Jf = L.vertices2jointsB(T_J_regressor.reshape(B * T, J, V).contiguous(), zero_v)
+    # A data loader on the GPU (body_models.smpl_clip_batch) hands the per-frame regressor / weights as stride-0 views of
+    # ONE table: then the blended, smoothed garment weights are the same for the T frames of a clip and are built once
+    # per clip (B rows instead of B*T).  Materialised per-frame copies (the reference's loader) take the general route.
+    shared_J = T > 1 and T_J_regressor.stride(1) == 0
+    shared_W = T > 1 and T_lbs_weights.stride(1) == 0
+    if shared_J:
+        Jf = L.vertices2jointsB(T_J_regressor[:, 0].contiguous(), zero_v, group=T)
+    else:
+        Jf = L.vertices2jointsB(T_J_regressor.reshape(B * T, J, V).contiguous(), zero_v)
     _, A = L.batch_rigid_transform(gt_pose_mat, Jf, parents)
-    nn_W = _blend(T_lbs_weights.reshape(B * T, V, J).contiguous(), idx_k, d_k.contiguous(), T)   # (B*T,Vg,J)  :374-382
+    if shared_W:
+        nn_W = _blend(T_lbs_weights[:, 0].contiguous(), idx_k, d_k.contiguous(), 1)               # (B,Vg,J)
+    else:
+        nn_W = _blend(T_lbs_weights.reshape(B * T, V, J).contiguous(), idx_k, d_k.contiguous(), T)   # (B*T,Vg,J)  :374-382
     if K > 1:
         nn_W = smooth_weights(nn_W, adj_old, 0.1, 100)                             # :385-390
-    verts = L.skin(nn_W, A, inv_template_garment_v)                                # :393, :406-408
+    verts = L.skin(nn_W, A, inv_template_garment_v, group=T if shared_W else 1)   # :393, :406-408
     return verts.reshape(B, T, -1, 3), nn1, inv_template_garment_v.reshape(B, T, -1, 3)

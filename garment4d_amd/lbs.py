@@ -54,13 +54,15 @@ def vertices2joints(J_regressor, vertices):
     return out
 
 
-def vertices2jointsB(J_regressor_B, vertices):
-    """Per-sample regressor: J_regressor_B (B,J,V), vertices (B,V,3) -> (B,J,3)."""
+def vertices2jointsB(J_regressor_B, vertices, group=1):
+    """Per-sample regressor: J_regressor_B (B,J,V), vertices (B,V,3) -> (B,J,3).
+    group = g > 1 (extension): J_regressor_B is (B/g,J,V), one regressor per g consecutive samples (a clip's frames)."""
     J_regressor_B, vertices = _f32(J_regressor_B, "J_regressor_B"), _f32(vertices, "vertices")
     B, V, _ = vertices.shape
     J = J_regressor_B.shape[1]
+    assert J_regressor_B.shape[0] * group == B
     out = torch.empty((B, J, 3), dtype=torch.float32, device=vertices.device)
-    _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor_B.data_ptr(), 1, vertices.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+    _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor_B.data_ptr(), int(group), vertices.data_ptr(), out.data_ptr(), _lib.stream_ptr())
     return out
 
 
@@ -86,14 +88,16 @@ def batch_rigid_transform(rot_mats, joints, parents, dtype=torch.float32):
     return posed, A
 
 
-def skin(weights, A, verts):
+def skin(weights, A, verts, group=1):
     """Skinning step alone (lbs.py:233-246 / mesh_encoder.py:393,406-408): weights (V,J) or (B,V,J), A (B,J,4,4),
-    verts (B,V,3) -> (B,V,3)."""
+    verts (B,V,3) -> (B,V,3).  group = g > 1 (extension): weights (B/g,V,J), one table per g consecutive samples."""
     weights, A, verts = _f32(weights, "weights"), _f32(A, "A"), _f32(verts, "verts")
     B, V, _ = verts.shape
     J = A.shape[1]
     out = torch.empty_like(verts)
-    _lib.call("g4d_lbs_pose_skin_f32", B, V, J, 0, verts.data_ptr(), 0, 0, weights.data_ptr(), int(weights.dim() == 3),
+    if weights.dim() == 3:
+        assert weights.shape[0] * group == B
+    _lib.call("g4d_lbs_pose_skin_f32", B, V, J, 0, verts.data_ptr(), 0, 0, weights.data_ptr(), int(group) if weights.dim() == 3 else 0,
               A.data_ptr(), 0, out.data_ptr(), _lib.stream_ptr())
     return out
 

@@ -64,6 +64,14 @@ def smpl_like_params(V=6890, J=24, num_betas=10, seed=0):
                 parents=parents, lbs_weights=lbs_weights)
 
 
+def smpl_data_struct(P, faces):
+    """SMPL .pkl-shaped dict (the fields smplx/smplx/body_models.py:133-270 reads) from smpl_like_params output."""
+    V = P["v_template"].shape[0]
+    kin = np.stack([P["parents"].astype(np.int64), np.arange(P["parents"].shape[0], dtype=np.int64)])
+    return dict(shapedirs=P["shapedirs"], f=faces, v_template=P["v_template"], J_regressor=P["J_regressor"],
+                posedirs=np.ascontiguousarray(P["posedirs"].T).reshape(V, 3, -1), kintree_table=kin, weights=P["lbs_weights"])
+
+
 def smpl_like_pose(B, J=24, num_betas=10, seed=1):
     """betas ~ N(0,1) (B,nb); axis-angle pose ~ N(0,0.2^2) (B,J*3)."""
     rng = np.random.default_rng(seed)

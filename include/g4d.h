@@ -197,7 +197,8 @@ int g4d_lbs_shape_f32(int b, int v, int nb, const float *betas, int betas_bstrid
                       const float *shapedirs, float *v_shaped, g4d_stream_t stream);
 
 /* joints (B,J,3) = jreg . verts (B,V,3); jreg (J,V) shared (vertices2joints, lbs.py:251-268) or, with
- * jreg_batched != 0, (B,J,V) per sample (vertices2jointsB, lbs.py:270-286). */
+ * jreg_batched = g > 0, (ceil(B/g),J,V): one regressor per g consecutive samples -- g = 1 per sample (vertices2jointsB,
+ * lbs.py:270-286), g = T per clip of T frames. */
 int g4d_joint_regress_f32(int b, int j, int v, const float *jreg, int jreg_batched, const float *verts, float *joints,
                           g4d_stream_t stream);
 
@@ -214,7 +215,8 @@ int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *pose, const
 
 /* verts (B,V,3) = (W . A) [v_in + pose_feature . posedirs ; 1]     (lbs.py:223-246).  v_in (B,V,3);
  * pose_feature (B,PF), posedirs (PF, V*3) -- pass pf = 0 to skip the pose blend shapes (plain skinning, e.g. the
- * garment skinning of modules/mesh_encoder.py:393,406-408); weights (V,J), or (B,V,J) when weights_batched != 0;
+ * garment skinning of modules/mesh_encoder.py:393,406-408); weights (V,J), or, with weights_batched = g > 0,
+ * (ceil(B/g),V,J): one weight table per g consecutive samples (1 = per sample, T = per clip);
  * A (B,J,4,4); v_posed_scratch (B,V,3) receives v_posed when pf > 0 (may be NULL when pf == 0). */
 int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const float *pose_feature,
                           const float *posedirs, const float *weights, int weights_batched, const float *A,

@@ -106,3 +106,21 @@ def skin(weights, A, v_posed):
     T = np.matmul(W, A.reshape(B, A.shape[1], 16).astype(F32)).reshape(B, -1, 4, 4).astype(F32)
     homo = np.concatenate([v_posed.astype(F32), np.ones((B, v_posed.shape[1], 1), dtype=F32)], axis=2)
     return np.matmul(T, homo[..., None]).astype(F32)[:, :, :3, 0].copy()
+
+
+# smplx/smplx/vertex_ids.py:24-46 ('smplh') in the order VertexJointSelector concatenates them
+# (vertex_joint_selector.py:37-68): face, feet, left-hand tips, right-hand tips
+SMPLH_EXTRA_JOINTS = [332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
+                      2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133]
+
+
+def smpl_layer_forward(P, betas, rot_mats, transl=None):
+    """SMPLLayer.forward (smplx/smplx/body_models.py:391-478): lbs(pose2rot=False) + VertexJointSelector + transl.
+    P: synthetic.smpl_like_params dict; rot_mats (B,24,3,3).  Returns (vertices (B,V,3), joints (B,45,3))."""
+    verts, joints = lbs(betas, rot_mats, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"],
+                        pose2rot=False)
+    joints = np.concatenate([joints, verts[:, SMPLH_EXTRA_JOINTS]], axis=1)
+    if transl is not None:
+        joints = joints + transl[:, None]
+        verts = verts + transl[:, None]
+    return verts.astype(np.float32), joints.astype(np.float32)

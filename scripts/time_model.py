@@ -1,5 +1,7 @@
 """Time the full wired model (BASELINE cfg4 shape: encoder + garment encoder + LBS garment interpolation + 3 refinement
-rounds) on one GPU.  usage: python scripts/time_model.py [nbatch] [T] [N] [iters]"""
+rounds) on one GPU.  usage: python scripts/time_model.py [nbatch] [T] [N] [iters] [loader]
+loader = "gpu" (default): the body batch comes from body_models.smpl_clip_batch (SMPLLayer on the GPU, timed inside the
+forward loop, weights / regressor as stride-0 views); "copies": precomputed per-frame copies like the reference's loader."""
 import os
 import sys
 import time
@@ -18,6 +20,7 @@ nbatch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+loader = sys.argv[5] if len(sys.argv) > 5 else "gpu"
 
 
 def dev(a):
@@ -36,20 +39,34 @@ m.PCA_garment_encoder.channel_major_outputs = False
 x = dev(scene["x"])
 batch = {k: dev(v) for k, v in scene["batch"].items()}
 body = scene["body"]
-bm = types.SimpleNamespace(parents=torch.from_numpy(body["parents"]).cuda(), faces=body["faces"], J_regressor=dev(body["J_regressor"]),
-                           v_template=dev(body["v_template"]))
+if loader == "gpu":
+    from garment4d_amd.body_models import SMPLLayer, Struct, smpl_clip_batch
+    P = syn.smpl_like_params(V=body["v_template"].shape[0], J=24, seed=2)
+    P["v_template"] = body["v_template"]
+    bm = SMPLLayer("", data_struct=Struct(**syn.smpl_data_struct(P, body["faces"])), gender="female", num_betas=10).cuda()
+    pose_in = batch["pose_torch"]
+    shape_in = dev(np.repeat(np.random.default_rng(3).standard_normal((nbatch, 1, 10)).astype(np.float32) * 0.3, T, 1))
+
+    def make_batch():
+        return smpl_clip_batch(bm, pose_in, shape_in)
+else:
+    bm = types.SimpleNamespace(parents=torch.from_numpy(body["parents"]).cuda(), faces=body["faces"], J_regressor=dev(body["J_regressor"]),
+                               v_template=dev(body["v_template"]))
+
+    def make_batch():
+        return batch
 with torch.no_grad():
     logits = m.PCA_garment_encoder.pointnet.forward_fused(x.reshape(-1, N, 3))[1]
     tgt = label_dict["Tshirt"] - 1
     others = torch.cat([logits[..., :tgt], logits[..., tgt + 1:]], -1).max(-1)[0]
     m.PCA_garment_encoder.pointnet.FC_layer[2].conv.bias[tgt] += torch.quantile((others - logits[..., tgt]).flatten()[:1000000], 0.35)
     for _ in range(2):
-        out = m(x, bm, batch)
+        out = m(x, bm, make_batch())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        out = m(x, bm, batch)
+        out = m(x, bm, make_batch())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-print(f"nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
+print(f"loader={loader} nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
       f"{nbatch*T/dt:.1f} frames/s; finite={bool(torch.isfinite(out['iter_regressed_lbs_garment_v'][-1]).all())}")

@@ -35,6 +35,11 @@ def golden_lbs():
 
 
 @pytest.fixture(scope="session")
+def golden_smpl():
+    return load_golden("smpl.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_gcn():
     return load_golden("gcn.npz")
 

@@ -46,6 +46,34 @@ def load_reference():
     return p2u, p2m, ptu, lbs, gl, gu
 
 
+def gen_smpl():
+    """SMPL / SMPLLayer front door (body_models.py:287-478) incl. VertexJointSelector: outputs of the reference's own
+    classes on a synthetic SMPL-shaped model (V = 6890 so the smplh key-point vertex ids exist).  Inputs are regenerated
+    from seeds at test time; outputs + input checksums are stored."""
+    bm = importlib.import_module("smplx.body_models")
+    lbs = importlib.import_module("smplx.lbs")
+    utils = importlib.import_module("smplx.utils")
+    P = syn.smpl_like_params(V=6890, J=24, num_betas=10, seed=50)
+    faces = np.random.default_rng(51).integers(0, 6890, (100, 3)).astype(np.int64)
+    ds = utils.Struct(**syn.smpl_data_struct(P, faces))
+    betas, pose = syn.smpl_like_pose(3, seed=52)
+    transl = (np.random.default_rng(53).standard_normal((3, 3)) * 0.1).astype(np.float32)
+    layer = bm.SMPLLayer("", data_struct=ds, gender="female", num_betas=10)
+    rot = lbs.batch_rodrigues(T(pose).view(-1, 3)).view(3, 24, 3, 3)
+    o1 = layer(betas=T(betas), body_pose=rot[:, 1:], global_orient=rot[:, :1], transl=T(transl), return_full_pose=True)
+    o2 = layer(betas=T(betas), body_pose=rot[:, 1:], global_orient=rot[:, 0])            # no transl, (B,3,3) orient
+    o3 = layer(betas=T(betas)[:1])                                                        # everything else defaulted
+    smpl = bm.SMPL("", data_struct=ds, gender="female", num_betas=10, batch_size=3, create_transl=False)
+    o4 = smpl(betas=T(betas), body_pose=T(pose)[:, 3:], global_orient=T(pose)[:, :3])    # axis-angle front door
+    out = dict(layer_verts=N(o1.vertices), layer_joints=N(o1.joints), layer_full_pose=N(o1.full_pose), layer_verts_notransl=N(o2.vertices),
+               layer_joints_notransl=N(o2.joints), layer_default_verts=N(o3.vertices), layer_default_joints=N(o3.joints),
+               smpl_verts=N(o4.vertices), smpl_joints=N(o4.joints), extra_idx=N(layer.vertex_joint_selector.extra_joints_idxs),
+               checksum=np.array([float(v.astype(np.float64).sum()) for k, v in sorted(P.items())]
+                                 + [float(betas.astype(np.float64).sum()), float(pose.astype(np.float64).sum()), float(transl.astype(np.float64).sum())]))
+    np.savez_compressed(os.path.join(OUT, "smpl.npz"), **out)
+    print("smpl.npz", len(out), "arrays")
+
+
 def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
@@ -290,6 +318,7 @@ if __name__ == "__main__":
     gen_modules(p2u, p2m)
     gen_lbs(lbs)
     gen_gcn(gl, gu)
+    gen_smpl()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -115,6 +115,37 @@ def test_lbs_full_size(golden_lbs):
     np.testing.assert_allclose(j, g["full_joints"], **TOL)
 
 
+def smpl_case():
+    """The inputs tests/golden/make_golden.py:gen_smpl saw (regenerated from the same seeds)."""
+    P = syn.smpl_like_params(V=6890, J=24, num_betas=10, seed=50)
+    betas, pose = syn.smpl_like_pose(3, seed=52)
+    transl = (np.random.default_rng(53).standard_normal((3, 3)) * 0.1).astype(np.float32)
+    chk = np.array([float(v.astype(np.float64).sum()) for k, v in sorted(P.items())]
+                   + [float(betas.astype(np.float64).sum()), float(pose.astype(np.float64).sum()), float(transl.astype(np.float64).sum())])
+    return P, betas, pose, transl, chk
+
+
+def test_smpl_layer(golden_smpl):
+    """SMPLLayer / SMPL front door + VertexJointSelector (body_models.py:287-478) restated, against the reference classes."""
+    g = golden_smpl
+    P, betas, pose, transl, chk = smpl_case()
+    np.testing.assert_allclose(chk, g["checksum"], rtol=1e-12)
+    assert list(g["extra_idx"]) == lbs_oracle.SMPLH_EXTRA_JOINTS
+    rot = lbs_oracle.batch_rodrigues(pose.reshape(-1, 3)).reshape(3, 24, 3, 3)
+    v, j = lbs_oracle.smpl_layer_forward(P, betas, rot, transl)
+    np.testing.assert_allclose(v, g["layer_verts"], **TOL)
+    np.testing.assert_allclose(j, g["layer_joints"], **TOL)
+    assert j.shape == (3, 45, 3)
+    v, j = lbs_oracle.smpl_layer_forward(P, betas, rot)
+    np.testing.assert_allclose(v, g["layer_verts_notransl"], **TOL)
+    np.testing.assert_allclose(j, g["layer_joints_notransl"], **TOL)
+    np.testing.assert_allclose(v, g["smpl_verts"], **TOL)          # the axis-angle front door gives the same body
+    eye = np.broadcast_to(np.eye(3, dtype=np.float32), (1, 24, 3, 3))
+    v, j = lbs_oracle.smpl_layer_forward(P, betas[:1], eye)
+    np.testing.assert_allclose(v, g["layer_default_verts"], **TOL)
+    np.testing.assert_allclose(j, g["layer_default_joints"], **TOL)
+
+
 def test_gcn(golden_gcn):
     import scipy.sparse as sp
     g = golden_gcn
