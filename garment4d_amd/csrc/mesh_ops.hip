@@ -130,3 +130,32 @@ extern "C" int g4d_vertex_normals_f32(int frames, int v, const float *verts, con
                        verts, faces, vf_rowptr, vf_fid, out);
     return check_launch("g4d_vertex_normals_f32");
 }
+
+// Interpenetration penalty of `calc_interpenetration_loss` (/root/reference/smplx/loss/temporal_loss.py:20-46), forward:
+// per garment vertex g with nearest body vertex b (index from the nearest-neighbour search) and its normal n,
+//   pen = relu(-(n . (g - b)))     -- positive when the garment vertex lies behind the body surface.
+namespace g4d {
+__global__ void __launch_bounds__(256) interpenetration_kernel(long long total, int vg, int v, const float *__restrict__ garment,
+                                                              const float *__restrict__ body, const float *__restrict__ normals,
+                                                              const int *__restrict__ nn_idx, int idx_stride, float *__restrict__ pen) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const long long f = gid / vg;
+    const size_t b = (size_t)f * v + nn_idx[gid * idx_stride];
+    const float dx = garment[gid * 3 + 0] - body[b * 3 + 0], dy = garment[gid * 3 + 1] - body[b * 3 + 1], dz = garment[gid * 3 + 2] - body[b * 3 + 2];
+    const float d = normals[b * 3 + 0] * dx + normals[b * 3 + 1] * dy + normals[b * 3 + 2] * dz;  // torch.mul(...).sum(-1), left to right
+    pen[gid] = fmaxf(-d, 0.f);
+}
+}  // namespace g4d
+
+extern "C" int g4d_interpenetration_f32(int frames, int vg, int v, const float *garment, const float *body, const float *normals,
+                                        const int *nn_idx, int idx_stride, float *pen, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(frames >= 0 && vg >= 0 && v > 0 && idx_stride >= 1, "g4d_interpenetration_f32: bad sizes");
+    const long long total = (long long)frames * vg;
+    if (total == 0) return G4D_OK;
+    G4D_REQUIRE(garment && body && normals && nn_idx && pen, "g4d_interpenetration_f32: null pointer");
+    hipLaunchKernelGGL(interpenetration_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), total, vg, v,
+                       garment, body, normals, nn_idx, idx_stride, pen);
+    return check_launch("g4d_interpenetration_f32");
+}

@@ -276,6 +276,13 @@ int g4d_segment_take_f32(int frames, int n, int n_out, int c, const float *in, c
 int g4d_vertex_normals_f32(int frames, int v, const float *verts, const int *faces, const int *vf_rowptr, const int *vf_fid,
                            float *out, g4d_stream_t stream);
 
+/* Per-vertex interpenetration penalty (smplx/loss/temporal_loss.py:20-46, forward): pen (frames,vg) =
+ * relu(-(n_b . (g - b))) with b = body[f, nn_idx[(f*vg + i) * idx_stride]] the nearest body vertex of garment vertex i and
+ * n_b its unit normal.  garment (frames,vg,3); body / normals (frames,v,3); nn_idx int32 with idx_stride ints per
+ * garment vertex (3 for the output of g4d_three_nn_f32, whose first column is the nearest vertex). */
+int g4d_interpenetration_f32(int frames, int vg, int v, const float *garment, const float *body, const float *normals,
+                             const int *nn_idx, int idx_stride, float *pen, g4d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,17 @@ def full_forward(sd, x, batch, body, garment_name, pca, template_faces, lbs_k, i
         [np.ascontiguousarray(np.transpose(f, (0, 2, 1))) for f in enc["garment_f_list"]], adj, nbatch, T, garment_samples=samples,
         iteration=iteration)
     return enc
+
+
+def interpenetration_loss(body_v, faces, garment_v, reduce_fn="sum"):
+    """smplx/loss/temporal_loss.py:20-46 in numpy (nearest vertex: smallest squared distance, lowest index on ties)."""
+    vn = compute_vnorms(body_v, faces).astype(np.float64)
+    out = []
+    for f in range(body_v.shape[0]):
+        d = ((garment_v[f][:, None, :].astype(F32) - body_v[f][None].astype(F32)) ** 2)
+        d2 = (d[..., 0] + d[..., 1]) + d[..., 2]
+        i = np.argmin(d2, axis=1)
+        dots = (vn[f][i] * (garment_v[f].astype(np.float64) - body_v[f][i].astype(np.float64))).sum(-1)
+        out.append(np.maximum(-dots, 0))
+    pen = np.stack(out)
+    return (pen.sum(-1).mean() if reduce_fn == "sum" else pen.mean()), pen

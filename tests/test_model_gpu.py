@@ -122,3 +122,22 @@ def test_full_forward_vs_oracle(garment, lbs_k):
     assert len(out["iter_regressed_lbs_garment_v"]) == 3
     for a, b in zip(out["iter_regressed_lbs_garment_v"], want["iter_regressed_lbs_garment_v"]):
         mostly_close(a, b, 5e-4 * max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("reduce_fn", ["sum", "mean"])
+def test_interpenetration_loss_vs_oracle(reduce_fn):
+    """calc_interpenetration_loss (smplx/loss/temporal_loss.py:20-46): normals + nearest body vertex + penalty kernels."""
+    from garment4d_amd.losses import calc_interpenetration_loss
+    scene = syn.garment_scene(2, 2, 64, seed=9)
+    body = scene["body"]
+    bv = scene["batch"]["smpl_vertices_torch"].reshape(4, -1, 3)
+    rng = np.random.default_rng(10)
+    gv = (bv[:, rng.integers(0, bv.shape[1], 300)] + rng.standard_normal((4, 300, 3)).astype(np.float32) * 0.02).astype(np.float32)
+    bm = types.SimpleNamespace(faces=body["faces"], v_template=dev(body["v_template"]))
+    so = {"vertices": dev(bv), "joints": dev(bv[:, :1])}
+    got = calc_interpenetration_loss(bm, so, dev(gv), reduce_fn=reduce_fn)
+    want, pen = MOr.interpenetration_loss(bv, body["faces"], gv, reduce_fn)
+    assert (pen > 0).mean() > 0.2 and (pen == 0).mean() > 0.2, "scene must have vertices on both sides of the surface"
+    np.testing.assert_allclose(float(got), want, rtol=2e-4)
+    got4 = calc_interpenetration_loss(bm, so, dev(gv).reshape(2, 2, 300, 3), reduce_fn=reduce_fn, to_root_joint=False)
+    assert float(got4) == float(got)
