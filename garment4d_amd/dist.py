@@ -32,6 +32,12 @@ def shard_frames(x: torch.Tensor, rank: int = None, world: int = None) -> torch.
     return x[b:e]
 
 
+def _stage(t: torch.Tensor, group=None) -> torch.Tensor:
+    """gloo has no device collectives: with that backend (CPU tests, or a 1-GPU box shared by two test ranks) CUDA tensors are
+    staged through the host.  With nccl (= RCCL) tensors stay on the device."""
+    return t.cpu() if (t.is_cuda and dist.get_backend(group) == "gloo") else t
+
+
 def allgather_frames(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Inverse of shard_frames: every rank gets the (n_total, ...) tensor.  Ragged blocks (n_total % world != 0) are
     padded to the largest block for the collective and trimmed afterwards."""
@@ -43,8 +49,10 @@ def allgather_frames(local: torch.Tensor, n_total: int, group=None) -> torch.Ten
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
-    out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    src = _stage(pad.contiguous(), group)
+    out = src.new_empty((world * mx,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, src, group=group)
+    out = out.to(local.device)
     if all(e - b == mx for b, e in sizes):
         return out
     return torch.cat([out[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], dim=0)
@@ -58,8 +66,10 @@ def clip_max_over_frames(frame_feats_local: torch.Tensor, frame_ids_local: torch
     out = frame_feats_local.new_full((n_clips, C), float("-inf"))
     clip = (frame_ids_local // T).long()
     out.scatter_reduce_(0, clip[:, None].expand(-1, C), frame_feats_local, reduce="amax", include_self=True)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.MAX, group=group)
+    if dist.is_initialized() and group is not False and dist.get_world_size(group) > 1:
+        red = _stage(out, group)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX, group=group)
+        out = red.to(out.device)
     return out
 
 

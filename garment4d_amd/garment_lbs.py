@@ -91,7 +91,7 @@ def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100, method=None):
 
 
 def lbs_garment_interpolation(pred_template_garment_v, Tpose_vertices, Tpose_root_joints, zeropose_vertices, parents, gt_pose,
-                              T_J_regressor, T_lbs_weights, adj_old, K=3):
+                              T_J_regressor, T_lbs_weights, adj_old, K=3, clip_J_regressor=None, clip_lbs_weights=None):
     """pred_template_garment_v (B,Vg,3); Tpose_vertices (B,[1,]V,3); Tpose_root_joints (B,[1,]3); zeropose_vertices (B,T,V,3);
     gt_pose (B,T,72); T_J_regressor (B,T,J,V); T_lbs_weights (B,T,V,J); adj_old scipy sparse (Vg,Vg).
     Returns (posed garment (B,T,Vg,3), nearest-neighbour KNN (K=1), un-posed garment repeated over T (B,T,Vg,3))."""
@@ -115,9 +115,13 @@ def lbs_garment_interpolation(pred_template_garment_v, Tpose_vertices, Tpose_roo
     inv_pose[:, 1, 1] = 0.15
     inv_pose[:, 2, 1] = -0.15
     inv_pose_mat = L.batch_rodrigues(inv_pose.reshape(-1, 3)).reshape(B, 24, 3, 3)
-    inv_J = L.vertices2jointsB(T_J_regressor[:, 0].contiguous(), body)
+    # the un-posing uses the regressor / weights of the clip's FIRST frame (:333, :338); a rank that holds a later segment of
+    # the clip passes them explicitly (clip_J_regressor (B,J,V), clip_lbs_weights (B,V,J))
+    cJ = T_J_regressor[:, 0] if clip_J_regressor is None else clip_J_regressor
+    cW = T_lbs_weights[:, 0] if clip_lbs_weights is None else clip_lbs_weights
+    inv_J = L.vertices2jointsB(cJ.contiguous(), body)
     _, inv_A = L.batch_rigid_transform(inv_pose_mat, inv_J, parents)
-    inv_nn_W = _blend(T_lbs_weights[:, 0].contiguous(), idx_64, d_64, 1)          # (B,Vg,J)   :339-347
+    inv_nn_W = _blend(cW.contiguous(), idx_64, d_64, 1)                            # (B,Vg,J)   :339-347
     inv_garment = L.skin(inv_nn_W, inv_A, garment)                                 # :348, :361-362
     inv_template_garment_v = inv_garment.reshape(B, 1, -1, 3).repeat(1, T, 1, 1).reshape(B * T, -1, 3).contiguous()
 

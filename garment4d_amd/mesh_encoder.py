@@ -198,3 +198,48 @@ class PCALBSGarmentUseSegEncoderSeg(GarmentRefinementHead):
         out["iter_regressed_lbs_garment_v"] = GarmentRefinementHead.forward(
             self, cur, body_v, body_vn, out["garment_v_list"], out["_garment_f_list_pm"], self._adj_scipy, nbatch, T, group=False)
         return out
+
+    def forward_frames(self, x, body_model, batch, *, nbatch, T, frame_ids, group=None):
+        """Frame-sharded forward: this rank holds the frames `frame_ids` (ascending global ids, clip =
+        id // T) of the nbatch x T frames.  x (F_local, N, 3); batch: per-FRAME tensors for the local frames only
+        (`smpl_vertices_torch`, `zeropose_smpl_vertices_torch` (F_local,V,3), `pose_torch` (F_local,72), `T_J_regressor`
+        (F_local,J,V), `T_lbs_weights` (F_local,V,J)) and per-CLIP tensors for all clips (`Tpose_smpl_vertices_torch`
+        (nbatch,V,3), `Tpose_smpl_root_joints_torch` (nbatch,3), `clip_J_regressor` (nbatch,J,V), `clip_lbs_weights`
+        (nbatch,V,J) = the first frame's tables of each clip).  Exchanges: all-reduce MAX of the (nbatch, 512) garment summary;
+        one all-gather of (frames, Vg, 128) per attention round.  Same output keys as `forward`, for the local frames."""
+        assert not torch.is_grad_enabled() and not self.training, "inference only: model.eval() under torch.no_grad()"
+        dev = x.device
+        ids = [int(i) for i in frame_ids]
+        assert ids == sorted(ids) and len(ids) == x.shape[0]
+        fid_t = torch.tensor(ids, dtype=torch.long, device=dev)
+        out = self.PCA_garment_encoder(x, body_model, nbatch=nbatch, T=T, frame_ids=fid_t, group=group)
+        body_v = batch["smpl_vertices_torch"].to(dev).reshape(len(ids), -1, 3).contiguous()
+        if self.vf_fid is None or self.vf_vid is None:
+            self.vf_fid, self.vf_vid = mesh_utils.calc_body_mesh_info(body_model)
+            self.vf_fid, self.vf_vid = self.vf_fid.to(dev), self.vf_vid.to(dev)
+            self._body_faces = torch.from_numpy(np.asarray(body_model.faces).astype(np.int64)).to(dev)
+        body_vn = mesh_utils.compute_vnorms(body_v, self._body_faces, self.vf_vid, self.vf_fid)
+        regressed = out["tpose_garment"].reshape(nbatch, -1, 3)                  # replicated on every rank (after the all-reduce)
+        Vg = regressed.shape[1]
+        posed = torch.empty((len(ids), Vg, 3), dtype=torch.float32, device=dev)
+        stage1 = torch.empty_like(posed)
+        lo = 0
+        while lo < len(ids):                                                     # one call per clip segment held by this rank
+            c = ids[lo] // T
+            hi = lo
+            while hi < len(ids) and ids[hi] // T == c:
+                hi += 1
+            seg = slice(lo, hi)
+            p, _, s1 = lbs_garment_interpolation(
+                regressed[c:c + 1], batch["Tpose_smpl_vertices_torch"][c:c + 1].to(dev), batch["Tpose_smpl_root_joints_torch"][c:c + 1].to(dev),
+                batch["zeropose_smpl_vertices_torch"][seg].to(dev).unsqueeze(0), body_model.parents, batch["pose_torch"][seg].to(dev).unsqueeze(0),
+                batch["T_J_regressor"][seg].to(dev).unsqueeze(0), batch["T_lbs_weights"][seg].to(dev).unsqueeze(0), self.adj_old, K=self.lbs_k,
+                clip_J_regressor=batch["clip_J_regressor"][c:c + 1].to(dev), clip_lbs_weights=batch["clip_lbs_weights"][c:c + 1].to(dev))
+            posed[seg], stage1[seg] = p[0], s1[0]
+            lo = hi
+        out["lbs_pred_garment_v"], out["lbs_stage1_pred_garment_v"] = posed, stage1
+        out["iter_regressed_lbs_garment_v"] = GarmentRefinementHead.forward(
+            self, posed, body_v, body_vn, out["garment_v_list"], out["_garment_f_list_pm"], self._adj_scipy, nbatch, T, group=group,
+            frame_ids=fid_t)
+        return out
+

@@ -25,6 +25,7 @@ def _body_model(body):
 
 
 def _model(scene, garment="Tshirt", lbs_k=64, seed=0):
+    torch.manual_seed(seed)                  # the refinement head keeps its constructor initialisation: same in every process
     m = PCALBSGarmentUseSegEncoderSeg(garment_name=garment, pca_dim=64, pca=scene["pca"], template=scene["template"], lbs_k=lbs_k,
                                       iteration=3)
     seed_encoder(m.PCA_garment_encoder, seed)
@@ -141,3 +142,64 @@ def test_interpenetration_loss_vs_oracle(reduce_fn):
     np.testing.assert_allclose(float(got), want, rtol=2e-4)
     got4 = calc_interpenetration_loss(bm, so, dev(gv).reshape(2, 2, 300, 3), reduce_fn=reduce_fn, to_root_joint=False)
     assert float(got4) == float(got)
+
+
+def _rank_worker(rank, world, port, nbatch, T, N, ret):
+    """One rank of the frame-sharded forward; both ranks share cuda:0, collectives over gloo (staged through the host)."""
+    import os
+    import torch.distributed as dist
+    from garment4d_amd import dist as gd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        scene = syn.garment_scene(nbatch, T, N, seed=21)
+        m = _model(scene, "Tshirt", 16)
+        b, e = gd.shard_range(nbatch * T, rank, world)
+        flat = {k: v.reshape((nbatch * T,) + v.shape[2:]) for k, v in scene["batch"].items()
+                if k in ("smpl_vertices_torch", "zeropose_smpl_vertices_torch", "pose_torch", "T_J_regressor", "T_lbs_weights")}
+        batch = {k: dev(v[b:e]) for k, v in flat.items()}
+        batch["Tpose_smpl_vertices_torch"] = dev(scene["batch"]["Tpose_smpl_vertices_torch"].reshape(nbatch, -1, 3))
+        batch["Tpose_smpl_root_joints_torch"] = dev(scene["batch"]["Tpose_smpl_root_joints_torch"].reshape(nbatch, 3))
+        batch["clip_J_regressor"] = dev(scene["batch"]["T_J_regressor"][:, 0])
+        batch["clip_lbs_weights"] = dev(scene["batch"]["T_lbs_weights"][:, 0])
+        x = dev(scene["x"].reshape(nbatch * T, N, 3)[b:e])
+        with torch.no_grad():
+            out = m.forward_frames(x, _body_model(scene["body"]), batch, nbatch=nbatch, T=T, frame_ids=range(b, e))
+        ret[rank] = dict(range=(b, e), coeff=out["garment_PCA_coeff"].cpu().numpy(), posed=out["lbs_pred_garment_v"].cpu().numpy(),
+                         final=out["iter_regressed_lbs_garment_v"][-1].cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forward_frames_two_ranks_equals_unsharded():
+    """Frames of the clips split over two ranks (rank boundary INSIDE a clip): clip max by all-reduce, attention by all-gather
+    (garment4d_amd/dist.py); the union of the ranks' outputs equals the single-process forward."""
+    import socket
+    import torch.multiprocessing as mp
+    nbatch, T, N = 3, 3, 2048            # 9 frames -> 5 + 4: the boundary cuts clip 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, nbatch, T, N, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    scene = syn.garment_scene(nbatch, T, N, seed=21)
+    m = _model(scene, "Tshirt", 16)
+    with torch.no_grad():
+        ref = m(dev(scene["x"]), _body_model(scene["body"]), {k: dev(v) for k, v in scene["batch"].items()})
+    posed = np.concatenate([ret[0]["posed"], ret[1]["posed"]], 0)
+    final = np.concatenate([ret[0]["final"], ret[1]["final"]], 0)
+    assert ret[0]["range"] == (0, 5) and ret[1]["range"] == (5, 9)
+    for r in (0, 1):
+        np.testing.assert_allclose(ret[r]["coeff"], ref["garment_PCA_coeff"].cpu().numpy(), rtol=1e-6, atol=1e-6, err_msg="coeff")  # replicated
+    np.testing.assert_allclose(posed, ref["lbs_pred_garment_v"].reshape(nbatch * T, -1, 3).cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg="posed")
+    want = ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy()
+    err = np.abs(final - want).reshape(nbatch * T, -1).max(1)
+    np.testing.assert_allclose(final, want, rtol=1e-4, atol=1e-5, err_msg=f"final; per-frame max err {err}")
