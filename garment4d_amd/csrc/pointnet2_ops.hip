@@ -75,7 +75,7 @@ __device__ __forceinline__ void nn_insert_lex(float d, int k, float &b1, float &
 __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                       const float *__restrict__ known_all, float *__restrict__ dist2_all,
                                                       int *__restrict__ idx_all) {
-    __shared__ float4 sk[kNNChunk];
+    __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];  // SoA: 4 points per ds_read_b128
     __shared__ float sd[3][64][3];
     __shared__ int si[3][64][3];
     const int b = blockIdx.y;
@@ -91,19 +91,34 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
     for (int base = 0; base < m; base += kNNChunk) {
         const int cm = min(kNNChunk, m - base);
         __syncthreads();
-        for (int j = threadIdx.x; j < cm; j += 256) {
-            const float *kp = known + (size_t)(base + j) * 3;
-            sk[j] = make_float4(kp[0], kp[1], kp[2], 0.f);
+        for (int j = threadIdx.x; j < kNNChunk; j += 256) {  // beyond the cloud: +inf coordinates, d = +inf, never inserted
+            const bool ok = j < cm;
+            const float *kp = known + (size_t)(base + (ok ? j : 0)) * 3;
+            const float inf = __builtin_inff();
+            skx[j] = ok ? kp[0] : inf; sky[j] = ok ? kp[1] : inf; skz[j] = ok ? kp[2] : inf;
         }
         __syncthreads();
-        const int per = (cm + 3) >> 2;
-        const int j0 = ks * per, j1 = min(cm, j0 + per);
-        for (int j = j0; j < j1; ++j) {
-            const float4 kq = sk[j];
-            const float dx = ux - kq.x, dy = uy - kq.y, dz = uz - kq.z;
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (__builtin_amdgcn_ballot_w64(d < b3) != 0ull)  // wave-uniform skip
-                nn_insert(d, base + j, b1, b2, b3, i1, i2, i3);
+        // each of the 4 waves scans a quarter of the chunk (multiple of 4 points), 4 points per step: three 16-byte LDS
+        // broadcasts, four distances, ONE wave-uniform test; the ordered inserts run only when some lane needs one
+        const int per = (((cm + 3) >> 2) + 3) & ~3;
+        const int j0 = ks * per, j1 = min((cm + 3) & ~3, j0 + per);
+        for (int j = j0; j < j1; j += 4) {
+            const float4 kx = *reinterpret_cast<const float4 *>(&skx[j]), ky = *reinterpret_cast<const float4 *>(&sky[j]),
+                         kz = *reinterpret_cast<const float4 *>(&skz[j]);
+            float dx = ux - kx.x, dy = uy - ky.x, dz = uz - kz.x;
+            const float d0 = dx * dx + dy * dy + dz * dz;
+            dx = ux - kx.y; dy = uy - ky.y; dz = uz - kz.y;
+            const float d1 = dx * dx + dy * dy + dz * dz;
+            dx = ux - kx.z; dy = uy - ky.z; dz = uz - kz.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            dx = ux - kx.w; dy = uy - ky.w; dz = uz - kz.w;
+            const float d3 = dx * dx + dy * dy + dz * dz;
+            if (__builtin_amdgcn_ballot_w64(fminf(fminf(d0, d1), fminf(d2, d3)) < b3) != 0ull) {  // wave-uniform skip
+                nn_insert(d0, base + j, b1, b2, b3, i1, i2, i3);
+                nn_insert(d1, base + j + 1, b1, b2, b3, i1, i2, i3);
+                nn_insert(d2, base + j + 2, b1, b2, b3, i1, i2, i3);
+                nn_insert(d3, base + j + 3, b1, b2, b3, i1, i2, i3);
+            }
         }
     }
     if (ks > 0) {
