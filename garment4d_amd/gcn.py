@@ -7,7 +7,9 @@ forward(input, adj):  out = adj @ (input @ W) + b  -- the reference's order, two
 contraction on the matrix cores (g4d_linear_f32, point-major rows) and a batched CSR SpMM whose threads own 4
 channels of one (frame, vertex) row (g4d_spmm_rows_f32); the reference transposes X W to (N, B*F), runs torch.spmm
 and transposes back.  (A fused CSR-aggregate-then-contract kernel exists too, g4d_gcn_linear_f32; it redoes the
-aggregation per 64-channel tile and only pays for Fin <= 64.)  Inference only: no autograd graph is built.
+aggregation per 64-channel tile and only pays for Fin <= 64; the stack kernel's CSR loader gathers each row tile once,
+but for the 128 -> 128 layers at 240 x 4096 rows it still measured 1.41 ms against 0.92 ms for linear + SpMM: the
+aggregation in the loader is a latency-bound gather in front of the MFMAs.)  Inference only: no autograd graph is built.
 """
 import math
 
