@@ -1,0 +1,340 @@
+// Register-resident shared-MLP stack: the activations never leave the VGPRs between layers -- no LDS, no barrier.
+//
+// v_mfma_f32_16x16x4_f32 computes D (16x16) += A (16x4) B (4x16) with lane l = (fi = l & 15, fq = l >> 4) supplying
+// A[i = fi][k = fq], B[k = fq][j = fi] and holding D[i = 4 fq + r][j = fi], r = 0..3.  A and B have the SAME lane
+// layout; D has the transposed one.  So if a layer is evaluated TRANSPOSED,
+//
+//      out^T (channels x rows) = W (channels x K)  .  h^T (K x rows)            A = weights, B = activations,
+//
+// lane (fi, fq) ends up with out[row = fi][channel = 16 ct + 4 fq + r] -- exactly the B-fragment
+// h[row = fi][k = 16 ks + 4 fq + e] the NEXT layer wants (ct -> ks, r -> e).  The accumulators of one layer ARE the
+// operand registers of the next: bias / BN affine / ReLU are applied in place and the chain continues.  The LAST layer
+// swaps the operands (A = activations, B = weights): its output comes out row-major (rows on 4 fq + r, channels on fi),
+// which is what the max / mean over the S samples (registers + two cross-lane steps) and the coalesced stores want.
+//
+// One wave owns 16 * MT rows; the first layer streams its input straight from the gather (GROUP: [x_j - q ; f_j], or a
+// DIRECT matrix) 16 columns at a time; weights come from L2 in the fragment order the host already packs
+// (garment4d_amd/fused.py: [16-channel tile][16-wide k-step][lane][4]), one 16-byte load per 4 * MT MFMAs.
+// The LDS-staged kernels (mlp_stack.hip, mlp_wave.hip) pay an LDS round trip plus a fence or barrier per layer for the
+// re-layout this kernel gets for free; they remain the route for stacks too wide for the register file (the widest tile
+// combination here is 128-128-256 at 32 rows per wave: 173 VGPRs + 200 AGPRs) and for the INTERP / CSR loaders.
+#include <cstdlib>
+
+#include "mlp_common.h"
+
+namespace g4d {
+
+struct ChainLayer {
+    const float *W;      // fragment order, [CoutPad64 / 16][Kpad / 16][64][4]
+    const float *scale;  // [CoutPad64]
+    const float *shift;
+    int kst;             // Kpad / 16: k-steps per channel tile in W
+    int relu, cout;
+};
+
+struct ChainArgs {
+    LinearArgs in;  // loader + output description (W / scale / shift / Kpad / Cout unused)
+    ChainLayer layer[3];
+};
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// affine + ReLU of a TRANSPOSED accumulator tile (lane holds channels 16 ct + 4 fq + r)
+template <int TOUT, int MT>
+__device__ __forceinline__ void affine_t(const ChainLayer &L, int fq, f32x4 (&acc)[TOUT][MT]) {
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct) {
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(L.scale + ct * 16 + fq * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(L.shift + ct * 16 + fq * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = acc[ct][mt][r] * sc[r] + sh[r];
+                if (L.relu) y = fmaxf(y, 0.f);
+                acc[ct][mt][r] = y;
+            }
+    }
+}
+
+// affine + ReLU of a ROW-MAJOR accumulator tile (lane holds channel 16 ct + fi)
+template <int TOUT, int MT>
+__device__ __forceinline__ void affine_r(const ChainLayer &L, int fi, f32x4 (&acc)[TOUT][MT]) {
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct) {
+        const float sc = L.scale[ct * 16 + fi], sh = L.shift[ct * 16 + fi];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = acc[ct][mt][r] * sc + sh;
+                if (L.relu) y = fmaxf(y, 0.f);
+                acc[ct][mt][r] = y;
+            }
+    }
+}
+
+template <int TOUT, int MT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[TOUT][MT]) {
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// first layer: the input is streamed from the loader, 16 columns per step
+template <int MODE, int TOUT, int MT, bool LAST>
+__device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLayer &L, int lane, int row0, f32x4 (&acc)[TOUT][MT]) {
+    const int fi = lane & 15, fq = lane >> 4;
+    RowCtx<MODE> ctx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ctx[mt] = make_ctx<MODE>(a, row0 + mt * 16 + fi);
+    zero_acc<TOUT, MT>(acc);
+    const int kst0 = (a.K + 15) >> 4;
+    for (int ks = 0; ks < kst0; ++ks) {
+        f32x4 b[MT];
+        const int k0 = ks * 16 + fq * 4;  // this lane's 4 consecutive input columns
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            // 4 consecutive columns of one source row = ONE 16-byte load (4-byte aligned) whenever they do not straddle the
+            // [xyz | features] seam or the end of the row
+            if (MODE == LOAD_GROUP && ctx[mt].valid && a.use_xyz && k0 >= 3 && k0 + 3 < a.K) {
+                b[mt] = *reinterpret_cast<const f32x4u *>(a.feats + ctx[mt].pt_base * a.C + (k0 - 3));
+            } else if (MODE == LOAD_GROUP && ctx[mt].valid && !a.use_xyz && k0 + 3 < a.K) {
+                b[mt] = *reinterpret_cast<const f32x4u *>(a.feats + ctx[mt].pt_base * a.C + k0);
+            } else if (MODE == LOAD_DIRECT && ctx[mt].valid && k0 + 3 < a.K) {
+                b[mt] = *reinterpret_cast<const f32x4u *>(a.X + (size_t)(row0 + mt * 16 + fi) * a.ldx + k0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[mt][e] = load_elem<MODE>(a, ctx[mt], row0 + mt * 16 + fi, k0 + e);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < TOUT; ++ct) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = LAST ? mfma4(b[mt][e], w[e], acc[ct][mt]) : mfma4(w[e], b[mt][e], acc[ct][mt]);
+        }
+    }
+    if (LAST) affine_r<TOUT, MT>(L, fi, acc);
+    else affine_t<TOUT, MT>(L, fq, acc);
+}
+
+// later layers: the previous layer's accumulators are the operand fragments
+template <int TIN, int TOUT, int MT, bool LAST>
+__device__ __forceinline__ void chain_layer(const ChainLayer &L, int lane, const f32x4 (&hin)[TIN][MT], f32x4 (&acc)[TOUT][MT]) {
+    const int fi = lane & 15, fq = lane >> 4;
+    zero_acc<TOUT, MT>(acc);
+#pragma unroll
+    for (int ks = 0; ks < TIN; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < TOUT; ++ct) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[ct][mt] = LAST ? mfma4(hin[ks][mt][e], w[e], acc[ct][mt]) : mfma4(w[e], hin[ks][mt][e], acc[ct][mt]);
+        }
+    if (LAST) affine_r<TOUT, MT>(L, fi, acc);
+    else affine_t<TOUT, MT>(L, fq, acc);
+}
+
+// row-major output tile: acc[ct][mt][r] = out[row0 + 16 mt + 4 fq + r][16 ct + fi]; pool over S consecutive rows or store
+template <int TOUT, int MT>
+__device__ __forceinline__ void finish(const LinearArgs &a, int cout, int lane, int wave, int row0, f32x4 (&acc)[TOUT][MT], float *xch) {
+    const int fi = lane & 15, fq = lane >> 4;
+    if (a.pool == 0) {
+#pragma unroll
+        for (int ct = 0; ct < TOUT; ++ct) {
+            const int ch = ct * 16 + fi;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + mt * 16 + fq * 4 + r;
+                    if (ch < cout && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = acc[ct][mt][r];
+                }
+        }
+        return;
+    }
+    const bool is_max = a.pool == 1;
+    const float inv = is_max ? 1.f : 1.f / (float)a.S;
+    const int S = a.S;
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct) {
+        const int ch = ct * 16 + fi;
+        const bool ch_ok = ch < cout;
+        float v[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            v[mt] = is_max ? fmaxf(fmaxf(acc[ct][mt][0], acc[ct][mt][1]), fmaxf(acc[ct][mt][2], acc[ct][mt][3]))
+                           : ((acc[ct][mt][0] + acc[ct][mt][1]) + (acc[ct][mt][2] + acc[ct][mt][3]));
+        if (S < 16) {  // 4 | 8 rows: 4 | 2 groups per tile
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float x = v[mt];
+                if (S == 8) {
+                    const float y = __shfl_xor(x, 16);
+                    x = is_max ? fmaxf(x, y) : x + y;
+                }
+                const int first_row = row0 + mt * 16 + (S == 8 ? (fq >> 1) * 8 : fq * 4);
+                const bool writer = S == 8 ? (fq & 1) == 0 : true;
+                if (writer && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {  // the 16 rows of a tile: across the four fq groups
+            const float y = __shfl_xor(v[mt], 16);
+            v[mt] = is_max ? fmaxf(v[mt], y) : v[mt] + y;
+            const float z = __shfl_xor(v[mt], 32);
+            v[mt] = is_max ? fmaxf(v[mt], z) : v[mt] + z;
+        }
+        constexpr int R = 16 * MT;  // rows per wave
+        if (S <= R) {
+            const int tiles_per_group = S >> 4;  // 1 | 2 | 4
+#pragma unroll
+            for (int g = 0; g < MT; ++g) {
+                if (g * tiles_per_group >= MT) break;
+                float x = v[g * tiles_per_group];
+#pragma unroll
+                for (int t = 1; t < MT; ++t)
+                    if (t < tiles_per_group) x = is_max ? fmaxf(x, v[g * tiles_per_group + t]) : x + v[g * tiles_per_group + t];
+                const int first_row = row0 + g * S;
+                if (lane < 16 && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
+            }
+        } else {  // a group spans S / R consecutive waves of the workgroup: partials meet in LDS
+            float x = v[0];
+#pragma unroll
+            for (int t = 1; t < MT; ++t) x = is_max ? fmaxf(x, v[t]) : x + v[t];
+            if (lane < 16) xch[wave * (TOUT * 16) + ch] = x;
+        }
+    }
+    constexpr int R = 16 * MT;
+    if (a.pool != 0 && S > R) {  // wave-uniform; every wave of the workgroup takes this branch
+        __syncthreads();
+        const int span = S / R;  // 2 | 4 waves per group
+        if ((wave % span) == 0) {
+            const int first_row = row0;
+            for (int ch = lane; ch < TOUT * 16; ch += 64) {
+                float x = xch[wave * (TOUT * 16) + ch];
+                for (int w = 1; w < span; ++w) {
+                    const float y = xch[(wave + w) * (TOUT * 16) + ch];
+                    x = is_max ? fmaxf(x, y) : x + y;
+                }
+                if (ch < cout && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
+            }
+        }
+    }
+}
+
+template <int MODE, int T1, int T2, int T3, int MT>
+__global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
+    __shared__ float xch[4 * 256];  // pooling partials of the 4 waves when a group spans waves (<= 256 channels)
+    const LinearArgs &a = s.in;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * 4 + wave) * (16 * MT);
+    f32x4 h1[T1][MT];
+    if constexpr (T2 == 0) {
+        first_layer<MODE, T1, MT, true>(a, s.layer[0], lane, row0, h1);
+        finish<T1, MT>(a, s.layer[0].cout, lane, wave, row0, h1, xch);
+    } else {
+        first_layer<MODE, T1, MT, false>(a, s.layer[0], lane, row0, h1);
+        f32x4 h2[T2][MT];
+        if constexpr (T3 == 0) {
+            chain_layer<T1, T2, MT, true>(s.layer[1], lane, h1, h2);
+            finish<T2, MT>(a, s.layer[1].cout, lane, wave, row0, h2, xch);
+        } else {
+            chain_layer<T1, T2, MT, false>(s.layer[1], lane, h1, h2);
+            f32x4 h3[T3][MT];
+            chain_layer<T2, T3, MT, true>(s.layer[2], lane, h2, h3);
+            finish<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
+        }
+    }
+}
+
+template <int T1, int T2, int T3, int MT>
+static void launch_chain(int mode, const ChainArgs &s, hipStream_t st) {
+    const long long rows_per_wg = 4ll * 16 * MT;
+    dim3 grid((unsigned)((s.in.rows + rows_per_wg - 1) / rows_per_wg)), block(256);
+    if (mode == LOAD_GROUP) hipLaunchKernelGGL((mlp_chain_kernel<LOAD_GROUP, T1, T2, T3, MT>), grid, block, 0, st, s);
+    else hipLaunchKernelGGL((mlp_chain_kernel<LOAD_DIRECT, T1, T2, T3, MT>), grid, block, 0, st, s);
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+
+// tile counts (16 channels each) of the supported stacks; the host mirrors this table (garment4d_amd/fused.py:chain_fits)
+extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
+    if (nlayers < 1 || nlayers > 3 || !Cout) return 0;
+    int t[3] = {0, 0, 0};
+    for (int l = 0; l < nlayers; ++l) t[l] = (Cout[l] + 15) / 16;
+    const int key = t[0] * 10000 + t[1] * 100 + t[2];
+    switch (key) {
+        case 10102: case 20204: case 40408: case 80816:             // 16-16-32, 32-32-64, 64-64-128, 128-128-256
+        case 20200: case 40400: case 80800:                         // 32-32, 64-64, 128-128
+        case 10000: case 20000: case 40000: case 80000:             // single layers up to 128
+            return 1;
+        default: return 0;
+    }
+}
+
+extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                                 const float *xyz, const float *new_xyz, const float *feats, const int *idx, int nlayers,
+                                 const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
+                                 const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, g4d_stream_t stream) {
+    G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP, "g4d_mlp_chain_f32: mode must be 0 (direct) or 1 (group)");
+    G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
+    if (rows == 0) return G4D_OK;
+    G4D_REQUIRE(W && scale && shift && Kpad && Cout && relu && out, "g4d_mlp_chain_f32: null pointer");
+    G4D_REQUIRE(g4d_mlp_chain_supported(nlayers, Cout), "g4d_mlp_chain_f32: unsupported layer widths (see g4d_mlp_chain_supported)");
+    G4D_REQUIRE(pool >= 0 && pool <= 2, "g4d_mlp_chain_f32: pool must be 0|1|2");
+    if (pool) G4D_REQUIRE((S == 4 || S == 8 || S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_chain_f32: pooling needs S in {4,8,16,32,64}");
+    ChainArgs s = {};
+    s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
+    s.in.X = X; s.in.ldx = ldx;
+    s.in.xyz = xyz; s.in.new_xyz = new_xyz; s.in.feats = feats; s.in.idx = idx; s.in.N = N; s.in.P = P; s.in.C = C; s.in.use_xyz = use_xyz;
+    for (int l = 0; l < nlayers; ++l) {
+        G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 16 == 0 && Cout[l] > 0, "g4d_mlp_chain_f32: bad layer %d", l);
+        G4D_REQUIRE(Kpad[l] >= (l == 0 ? K0 : Cout[l - 1]), "g4d_mlp_chain_f32: Kpad of layer %d too small", l);
+        s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
+        s.layer[l].kst = Kpad[l] / 16; s.layer[l].relu = relu[l]; s.layer[l].cout = Cout[l];
+    }
+    int t[3] = {0, 0, 0};
+    for (int l = 0; l < nlayers; ++l) t[l] = (Cout[l] + 15) / 16;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // rows per wave (16 * MT).  Measured on the cfg2 stacks (scripts/time_stacks.py, G4D_CHAIN_MT sweep): 32 rows per wave win
+    // once the launch still has >= 2048 waves (each weight fragment load then feeds 8 MFMAs), and for the 128-wide stack already
+    // at 1024 waves (its weight traffic dominates); 16 rows per wave otherwise (small launches need the waves); 64 rows per
+    // wave never won.
+    const long long waves32 = (rows + 31) / 32;
+    static const int mt_env = getenv("G4D_CHAIN_MT") ? atoi(getenv("G4D_CHAIN_MT")) : 0;  // tuning hook: 1 | 2
+    const bool wide = t[0] >= 8;
+    const int mt = mt_env ? (mt_env >= 2 ? 2 : 1) : ((waves32 >= 2048 || (wide && waves32 >= 1024)) ? 2 : 1);
+#define G4D_CHAIN(T1, T2, T3)                                   \
+    if (mt == 2) launch_chain<T1, T2, T3, 2>(mode, s, st);      \
+    else launch_chain<T1, T2, T3, 1>(mode, s, st);              \
+    break;
+    switch (t[0] * 10000 + t[1] * 100 + t[2]) {
+        case 10102: G4D_CHAIN(1, 1, 2)
+        case 20204: G4D_CHAIN(2, 2, 4)
+        case 40408: G4D_CHAIN(4, 4, 8)
+        case 80816: G4D_CHAIN(8, 8, 16)
+        case 20200: G4D_CHAIN(2, 2, 0)
+        case 40400: G4D_CHAIN(4, 4, 0)
+        case 80800: G4D_CHAIN(8, 8, 0)
+        case 10000: G4D_CHAIN(1, 0, 0)
+        case 20000: G4D_CHAIN(2, 0, 0)
+        case 40000: G4D_CHAIN(4, 0, 0)
+        default: G4D_CHAIN(8, 0, 0)
+    }
+#undef G4D_CHAIN
+    return check_launch("g4d_mlp_chain_f32");
+}

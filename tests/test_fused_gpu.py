@@ -109,12 +109,13 @@ def test_transpose_roundtrip():
     assert torch.equal(fused.to_channel_major(pm), x)
 
 
-@pytest.mark.parametrize("use_stack", [True, False])
-def test_stack_kernel_equals_per_layer_kernels(use_stack, monkeypatch):
+@pytest.mark.parametrize("use_stack,use_chain", [(True, True), (True, False), (False, False)])
+def test_stack_kernel_equals_per_layer_kernels(use_stack, use_chain, monkeypatch):
     """mlp_stack.hip (whole stack per launch) and mlp.hip (one launch per layer) against the op-by-op path on every
     SA / FP / head shape of the cfg2 encoder (smaller clouds)."""
     from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
     monkeypatch.setattr(fused, "USE_STACK", use_stack)
+    monkeypatch.setattr(fused, "USE_CHAIN", use_chain)
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=True), seed=5).cuda().eval()
     x = dev(syn.body_like_cloud(2, 3000, seed=11))
     with torch.no_grad():
@@ -152,3 +153,35 @@ def test_stack_pool_windows(S, widths, pool, precision, monkeypatch):
         assert torch.equal(got, want)
     else:
         torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("widths", [(3, 16, 16, 32), (3, 32, 32, 64), (99, 64, 64, 128), (195, 128, 128, 256), (67, 32, 32), (99, 128, 128), (40, 64),
+                                    (128, 7)])
+@pytest.mark.parametrize("S,pool", [(16, 1), (32, 1), (64, 1), (8, 1), (4, 2), (64, 2), (1, 0)])
+def test_chain_kernel_equals_lds_kernels(widths, S, pool, monkeypatch):
+    """csrc/mlp_chain.hip (activations chained through the MFMA accumulators, no LDS) against the LDS-staged stack / wave
+    kernels on the same grouped input: every supported tile combination, every pool window, ragged row counts."""
+    g = torch.Generator().manual_seed(len(widths) * 100 + S)
+    B, N, P = 3, 500, 37 if S > 1 else 2100          # rows = B*P*S: not a multiple of the 32/64-row wave tiles
+    S_ = max(S, 1)
+    C = widths[0] - 3
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    new_xyz = torch.rand(B, P, 3, generator=g).cuda()
+    feats = torch.randn(B, N, max(C, 1), generator=g).cuda() if C > 0 else None
+    idx = torch.randint(0, N, (B, P, S_), generator=g, dtype=torch.int32).cuda()
+    layers = []
+    for i, (cin, cout) in enumerate(zip(widths[:-1], widths[1:])):
+        layers.append(fused.PackedLayer(torch.randn(cout, cin, generator=g).cuda() * (1.5 / cin ** 0.5), (torch.rand(cout, generator=g) + 0.5).cuda(),
+                                        torch.randn(cout, generator=g).cuda() * 0.1, relu=i < len(widths) - 2 or pool != 0))
+    rows = B * P * S_
+    assert fused.chain_fits(layers, pool, S_, 1)
+    grp = (N, P, max(C, 0), 1, xyz, new_xyz, feats, idx)
+    outs = {}
+    for chain in (True, False):
+        monkeypatch.setattr(fused, "USE_CHAIN", chain)
+        o = torch.full((rows // S_ if pool else rows, widths[-1] + 5), 3.0, device="cuda")
+        fused.mlp_stack(1, rows, widths[0], layers, o, col0=2, pool=pool, S=S_, group=grp)
+        outs[chain] = o
+    assert (outs[True][:, :2] == 3.0).all() and (outs[True][:, 2 + widths[-1]:] == 3.0).all()
+    scale = float(outs[False].abs().max())
+    assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * max(scale, 1.0)
