@@ -34,7 +34,10 @@ struct ChainLayer {
 
 struct ChainArgs {
     LinearArgs in;  // loader + output description (W / scale / shift / Kpad / Cout unused)
-    ChainLayer layer[3];
+    ChainLayer layer[4];
+    int tap_layer;   // hidden layer whose activations are also written to HBM (-1: none)
+    float *tap_out;
+    int tap_ld;
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
@@ -106,6 +109,14 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
                 b[mt] = *reinterpret_cast<const f32x4u *>(a.feats + ctx[mt].pt_base * a.C + k0);
             } else if (MODE == LOAD_DIRECT && ctx[mt].valid && k0 + 3 < a.K) {
                 b[mt] = *reinterpret_cast<const f32x4u *>(a.X + (size_t)(row0 + mt * 16 + fi) * a.ldx + k0);
+            } else if (MODE == LOAD_INTERP && ctx[mt].valid && k0 + 3 < a.C2) {  // three_interpolate of 4 consecutive channels
+                const f32x4 f0 = *reinterpret_cast<const f32x4u *>(a.known_feats + ctx[mt].k0 + k0);
+                const f32x4 f1 = *reinterpret_cast<const f32x4u *>(a.known_feats + ctx[mt].k1 + k0);
+                const f32x4 f2 = *reinterpret_cast<const f32x4u *>(a.known_feats + ctx[mt].k2 + k0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[mt][e] = ctx[mt].w0 * f0[e] + ctx[mt].w1 * f1[e] + ctx[mt].w2 * f2[e];  // load_elem's order
+            } else if (MODE == LOAD_INTERP && ctx[mt].valid && k0 >= a.C2 && k0 + 3 < a.K) {
+                b[mt] = *reinterpret_cast<const f32x4u *>(a.skip + ctx[mt].sk + (k0 - a.C2));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[mt][e] = load_elem<MODE>(a, ctx[mt], row0 + mt * 16 + fi, k0 + e);
@@ -233,7 +244,24 @@ __device__ __forceinline__ void finish(const LinearArgs &a, int cout, int lane, 
     }
 }
 
-template <int MODE, int T1, int T2, int T3, int MT>
+// hidden-layer tap: the transposed tile holds out[row = 16 mt + fi][channels 16 ct + 4 fq .. + 3]
+template <int TOUT, int MT>
+__device__ __forceinline__ void tap_store(const ChainArgs &s, int cout, int lane, int row0, const f32x4 (&h)[TOUT][MT]) {
+    const int fi = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = row0 + mt * 16 + fi;
+            if (row >= s.in.rows) continue;
+            float *dst = s.tap_out + (size_t)row * s.tap_ld + ct * 16 + fq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ct * 16 + fq * 4 + r < cout) dst[r] = h[ct][mt][r];
+        }
+}
+
+template <int MODE, int T1, int T2, int T3, int T4, int MT>
 __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
     __shared__ float xch[4 * 256];  // pooling partials of the 4 waves when a group spans waves (<= 256 channels)
     const LinearArgs &a = s.in;
@@ -246,25 +274,36 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
         finish<T1, MT>(a, s.layer[0].cout, lane, wave, row0, h1, xch);
     } else {
         first_layer<MODE, T1, MT, false>(a, s.layer[0], lane, row0, h1);
+        if (s.tap_layer == 0) tap_store<T1, MT>(s, s.layer[0].cout, lane, row0, h1);
         f32x4 h2[T2][MT];
         if constexpr (T3 == 0) {
             chain_layer<T1, T2, MT, true>(s.layer[1], lane, h1, h2);
             finish<T2, MT>(a, s.layer[1].cout, lane, wave, row0, h2, xch);
         } else {
             chain_layer<T1, T2, MT, false>(s.layer[1], lane, h1, h2);
+            if (s.tap_layer == 1) tap_store<T2, MT>(s, s.layer[1].cout, lane, row0, h2);
             f32x4 h3[T3][MT];
-            chain_layer<T2, T3, MT, true>(s.layer[2], lane, h2, h3);
-            finish<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
+            if constexpr (T4 == 0) {
+                chain_layer<T2, T3, MT, true>(s.layer[2], lane, h2, h3);
+                finish<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
+            } else {
+                chain_layer<T2, T3, MT, false>(s.layer[2], lane, h2, h3);
+                if (s.tap_layer == 2) tap_store<T3, MT>(s, s.layer[2].cout, lane, row0, h3);
+                f32x4 h4[T4][MT];
+                chain_layer<T3, T4, MT, true>(s.layer[3], lane, h3, h4);
+                finish<T4, MT>(a, s.layer[3].cout, lane, wave, row0, h4, xch);
+            }
         }
     }
 }
 
-template <int T1, int T2, int T3, int MT>
+template <int T1, int T2, int T3, int T4, int MT>
 static void launch_chain(int mode, const ChainArgs &s, hipStream_t st) {
     const long long rows_per_wg = 4ll * 16 * MT;
     dim3 grid((unsigned)((s.in.rows + rows_per_wg - 1) / rows_per_wg)), block(256);
-    if (mode == LOAD_GROUP) hipLaunchKernelGGL((mlp_chain_kernel<LOAD_GROUP, T1, T2, T3, MT>), grid, block, 0, st, s);
-    else hipLaunchKernelGGL((mlp_chain_kernel<LOAD_DIRECT, T1, T2, T3, MT>), grid, block, 0, st, s);
+    if (mode == LOAD_GROUP) hipLaunchKernelGGL((mlp_chain_kernel<LOAD_GROUP, T1, T2, T3, T4, MT>), grid, block, 0, st, s);
+    else if (mode == LOAD_INTERP) hipLaunchKernelGGL((mlp_chain_kernel<LOAD_INTERP, T1, T2, T3, T4, MT>), grid, block, 0, st, s);
+    else hipLaunchKernelGGL((mlp_chain_kernel<LOAD_DIRECT, T1, T2, T3, T4, MT>), grid, block, 0, st, s);
 }
 
 }  // namespace g4d
@@ -272,25 +311,31 @@ static void launch_chain(int mode, const ChainArgs &s, hipStream_t st) {
 using namespace g4d;
 
 // tile counts (16 channels each) of the supported stacks; the host mirrors this table (garment4d_amd/fused.py:chain_fits)
+static int chain_key(int nlayers, const int *Cout) {
+    if (nlayers < 1 || nlayers > 4 || !Cout) return -1;
+    int key = 0;
+    for (int l = 0; l < 4; ++l) key = key * 100 + (l < nlayers ? (Cout[l] + 15) / 16 : 0);
+    return key;
+}
+
 extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
-    if (nlayers < 1 || nlayers > 3 || !Cout) return 0;
-    int t[3] = {0, 0, 0};
-    for (int l = 0; l < nlayers; ++l) t[l] = (Cout[l] + 15) / 16;
-    const int key = t[0] * 10000 + t[1] * 100 + t[2];
-    switch (key) {
-        case 10102: case 20204: case 40408: case 80816:             // 16-16-32, 32-32-64, 64-64-128, 128-128-256
-        case 20200: case 40400: case 80800:                         // 32-32, 64-64, 128-128
-        case 10000: case 20000: case 40000: case 80000:             // single layers up to 128
+    switch (chain_key(nlayers, Cout)) {
+        case 1010200: case 2020400: case 4040800: case 8081600:     // 16-16-32, 32-32-64, 64-64-128, 128-128-256
+        case 2020000: case 4040000: case 8080000: case 8040000:     // 32-32, 64-64, 128-128, 128-64
+        case 1000000: case 2000000: case 4000000: case 8000000:     // single layers up to 128
+        case 8040201:                                               // 128-64-32-(<=16): last FP level + segmentation head
             return 1;
         default: return 0;
     }
 }
 
 extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
-                                 const float *xyz, const float *new_xyz, const float *feats, const int *idx, int nlayers,
-                                 const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
-                                 const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, g4d_stream_t stream) {
-    G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP, "g4d_mlp_chain_f32: mode must be 0 (direct) or 1 (group)");
+                                 const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                                 int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
+                                 int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
+                                 const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
+                                 int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
+    G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP || mode == LOAD_INTERP, "g4d_mlp_chain_f32: mode must be 0 (direct), 1 (group) or 2 (interp)");
     G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
     if (rows == 0) return G4D_OK;
     G4D_REQUIRE(W && scale && shift && Kpad && Cout && relu && out, "g4d_mlp_chain_f32: null pointer");
@@ -301,14 +346,16 @@ extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *
     s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
     s.in.X = X; s.in.ldx = ldx;
     s.in.xyz = xyz; s.in.new_xyz = new_xyz; s.in.feats = feats; s.in.idx = idx; s.in.N = N; s.in.P = P; s.in.C = C; s.in.use_xyz = use_xyz;
+    s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
+    s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
+    G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
     for (int l = 0; l < nlayers; ++l) {
         G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 16 == 0 && Cout[l] > 0, "g4d_mlp_chain_f32: bad layer %d", l);
         G4D_REQUIRE(Kpad[l] >= (l == 0 ? K0 : Cout[l - 1]), "g4d_mlp_chain_f32: Kpad of layer %d too small", l);
         s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
         s.layer[l].kst = Kpad[l] / 16; s.layer[l].relu = relu[l]; s.layer[l].cout = Cout[l];
     }
-    int t[3] = {0, 0, 0};
-    for (int l = 0; l < nlayers; ++l) t[l] = (Cout[l] + 15) / 16;
+    const int key = chain_key(nlayers, Cout);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // rows per wave (16 * MT).  Measured on the cfg2 stacks (scripts/time_stacks.py, G4D_CHAIN_MT sweep): 32 rows per wave win
     // once the launch still has >= 2048 waves (each weight fragment load then feeds 8 MFMAs), and for the 128-wide stack already
@@ -316,24 +363,26 @@ extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *
     // wave never won.
     const long long waves32 = (rows + 31) / 32;
     static const int mt_env = getenv("G4D_CHAIN_MT") ? atoi(getenv("G4D_CHAIN_MT")) : 0;  // tuning hook: 1 | 2
-    const bool wide = t[0] >= 8;
+    const bool wide = key >= 8000000;
     const int mt = mt_env ? (mt_env >= 2 ? 2 : 1) : ((waves32 >= 2048 || (wide && waves32 >= 1024)) ? 2 : 1);
-#define G4D_CHAIN(T1, T2, T3)                                   \
-    if (mt == 2) launch_chain<T1, T2, T3, 2>(mode, s, st);      \
-    else launch_chain<T1, T2, T3, 1>(mode, s, st);              \
+#define G4D_CHAIN(T1, T2, T3, T4)                                   \
+    if (mt == 2) launch_chain<T1, T2, T3, T4, 2>(mode, s, st);      \
+    else launch_chain<T1, T2, T3, T4, 1>(mode, s, st);              \
     break;
-    switch (t[0] * 10000 + t[1] * 100 + t[2]) {
-        case 10102: G4D_CHAIN(1, 1, 2)
-        case 20204: G4D_CHAIN(2, 2, 4)
-        case 40408: G4D_CHAIN(4, 4, 8)
-        case 80816: G4D_CHAIN(8, 8, 16)
-        case 20200: G4D_CHAIN(2, 2, 0)
-        case 40400: G4D_CHAIN(4, 4, 0)
-        case 80800: G4D_CHAIN(8, 8, 0)
-        case 10000: G4D_CHAIN(1, 0, 0)
-        case 20000: G4D_CHAIN(2, 0, 0)
-        case 40000: G4D_CHAIN(4, 0, 0)
-        default: G4D_CHAIN(8, 0, 0)
+    switch (key) {
+        case 1010200: G4D_CHAIN(1, 1, 2, 0)
+        case 2020400: G4D_CHAIN(2, 2, 4, 0)
+        case 4040800: G4D_CHAIN(4, 4, 8, 0)
+        case 8081600: G4D_CHAIN(8, 8, 16, 0)
+        case 2020000: G4D_CHAIN(2, 2, 0, 0)
+        case 4040000: G4D_CHAIN(4, 4, 0, 0)
+        case 8080000: G4D_CHAIN(8, 8, 0, 0)
+        case 8040000: G4D_CHAIN(8, 4, 0, 0)
+        case 1000000: G4D_CHAIN(1, 0, 0, 0)
+        case 2000000: G4D_CHAIN(2, 0, 0, 0)
+        case 4000000: G4D_CHAIN(4, 0, 0, 0)
+        case 8000000: G4D_CHAIN(8, 0, 0, 0)
+        default: G4D_CHAIN(8, 4, 2, 1)
     }
 #undef G4D_CHAIN
     return check_launch("g4d_mlp_chain_f32");

@@ -169,13 +169,13 @@ def stack_fits(layers, pool, S, rows=None):
 
 
 USE_CHAIN = os.environ.get("G4D_MLP_CHAIN", "1") != "0"
-_CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (1,), (2,), (4,), (8,)}
+_CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (1,), (2,), (4,), (8,), (8, 4, 2, 1)}
 
 
 def chain_fits(layers, pool, S, mode):
     """Register-resident chain kernel (csrc/mlp_chain.hip): DIRECT / GROUP loader, 1..3 layers whose 16-channel tile counts
     are one of the instantiated combinations (mirrors g4d_mlp_chain_supported)."""
-    if not USE_CHAIN or mode not in (0, 1) or PRECISION != "fp32" or (pool and S not in _POOL_WINDOWS):
+    if not USE_CHAIN or mode not in (0, 1, 2) or PRECISION != "fp32" or (pool and S not in _POOL_WINDOWS):
         return False
     return tuple((L.Cout + 15) // 16 for L in layers) in _CHAIN_TILES
 
@@ -221,11 +221,11 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
                   ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
                   ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
         return out
-    if tap is None and chain_fits(layers, pool, S, mode):
-        _lib.call("g4d_mlp_chain_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, n, ctypes.cast(Wp, ctypes.c_void_p),
-                  ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p),
-                  ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0,
-                  _lib.stream_ptr())
+    if chain_fits(layers, pool, S, mode):
+        _lib.call("g4d_mlp_chain_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
+                  n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
+                  ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
+                  out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
         return out
     if tap is None and wave_fits(layers, pool, S):
         _lib.call("g4d_mlp_wave_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,

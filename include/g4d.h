@@ -168,14 +168,17 @@ int g4d_mlp_wave_f32(int mode, long long rows, int K0, const float *X, int ldx, 
 
 /* Register-resident variant of g4d_mlp_stack_f32 (garment4d_amd/csrc/mlp_chain.hip): hidden layers are evaluated
  * transposed, so a layer's MFMA accumulators ARE the next layer's operand fragments -- no LDS, no barrier between layers.
- * DIRECT (mode 0) or GROUP (mode 1) loader; 1..3 layers whose widths, rounded up to 16, form one of the combinations
- * g4d_mlp_chain_supported() accepts (16-16-32, 32-32-64, 64-64-128, 128-128-256, 32-32, 64-64, 128-128, single layers up to
- * 128).  Same layer arguments as g4d_mlp_stack_f32 (W in fragment order); pool over S in {4,8,16,32,64}; no tap. */
+ * DIRECT (mode 0), GROUP (1) or INTERP (2) loader; 1..4 layers whose widths, rounded up to 16, form one of the combinations
+ * g4d_mlp_chain_supported() accepts (16-16-32, 32-32-64, 64-64-128, 128-128-256, 32-32, 64-64, 128-128, 128-64, single layers
+ * up to 128, 128-64-32-16).  Same arguments as g4d_mlp_stack_f32 without the CSR loader (W in fragment order); pool over S
+ * in {4,8,16,32,64}; tap_out (or NULL): hidden layer tap_layer is also written to HBM. */
 int g4d_mlp_chain_supported(int nlayers, const int *Cout);
 int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
-                      const float *xyz, const float *new_xyz, const float *feats, const int *idx, int nlayers,
+                      const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                      int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int nlayers,
                       const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
-                      const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, g4d_stream_t stream);
+                      const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
+                      float *tap_out, int tap_ld, g4d_stream_t stream);
 
 /* Batched SpMM of the GCN layer: out (frames,Vg,C) = Ahat (CSR) . S (frames,Vg,C) + bias (C, may be NULL), optional ReLU
  * (the caller's F.relu, modules/mesh_encoder.py:479-480, fused), all point-major (modules/pygcn/layers.py:44-55 without

@@ -30,10 +30,10 @@ def dev(a):
 scene = syn.garment_scene(nbatch, T, N, body_rc=(65, 106), garment_rc=(64, 64), seed=1)
 m = PCALBSGarmentUseSegEncoderSeg(garment_name="Tshirt", pca_dim=64, pca=scene["pca"], template=scene["template"], lbs_k=256, iteration=3)
 seed_encoder(m.PCA_garment_encoder, 0)
-with torch.no_grad():
-    for name, p in m.named_parameters():
+with torch.no_grad():  # untrained offset regressors would throw the garment metres away from the body; a trained model moves it by
+    for name, p in m.named_parameters():  # centimetres per round, which is what the ball queries of the next round see
         if not name.startswith("PCA_garment_encoder."):
-            p.mul_(0.5)
+            p.mul_(0.02 if name.startswith("lbs_graph_regress") and name.split(".")[1] == "3" else 0.5)
 m = m.cuda().eval()
 m.PCA_garment_encoder.channel_major_outputs = False
 x = dev(scene["x"])
@@ -68,5 +68,8 @@ with torch.no_grad():
         out = m(x, bm, make_batch())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+offs = [float((b - a).norm(dim=-1).mean()) for a, b in zip([out["lbs_pred_garment_v"].reshape(-1, out["lbs_pred_garment_v"].shape[-2], 3)] + out["iter_regressed_lbs_garment_v"][:-1],
+                                                           out["iter_regressed_lbs_garment_v"])]
+print("mean per-round vertex offset (m):", [round(o, 4) for o in offs])
 print(f"loader={loader} nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
       f"{nbatch*T/dt:.1f} frames/s; finite={bool(torch.isfinite(out['iter_regressed_lbs_garment_v'][-1]).all())}")
