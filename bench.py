@@ -117,17 +117,23 @@ def kernel_rooflines(model, cloud):
                   "avg_launch_us": t * 1e6, "rounds_per_s_per_cloud": 1023 / t,
                   "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
                           "neither HBM nor MFMA limits it -- see DESIGN.md section 5"}
-    # 2. heaviest MFMA layer: FP1 layer 0 (interp + 128->128 over B*8192 rows)
-    rows, K, Cout = B_CLOUDS * N_POINTS, 128, 128
-    x = torch.randn(rows, K, device=cloud.device)
-    L = fused.PackedLayer(torch.randn(Cout, K, device=cloud.device), torch.ones(Cout, device=cloud.device),
-                          torch.zeros(Cout, device=cloud.device), relu=True)
-    out = torch.empty(rows, Cout, device=cloud.device)
-    t = timed(lambda: fused.linear(x, L, out=out))
-    flops = 2.0 * rows * K * Cout
-    res["mlp"] = {"kernel": "linear_kernel<DIRECT> (65536 x 128 -> 128)", "bound": "mfma", "achieved": flops / t / 1e12,
-                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                  "traffic": None, "avg_launch_us": t * 1e6}
+    # 2. heaviest MFMA launch of a step: SA3 scale 1, [195 -> 128 -> 128 -> 256] over B*64*64 grouped rows + max pool, one
+    #    register-chain launch (csrc/mlp_chain.hip).  Algorithmic flops = 2 * rows * sum(K_l * C_l), un-padded.
+    sa3 = model.SA_modules[2]
+    layers = fused.pack_conv_stack(sa3.mlps[1])
+    Bc, Nn, P, S, C = B_CLOUDS, 256, 64, 64, 192
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xyz3 = torch.rand(Bc, Nn, 3, generator=g).to(cloud.device)
+    new3 = xyz3[:, :P].contiguous()
+    f3 = torch.randn(Bc, Nn, C, generator=g).to(cloud.device)
+    idx3 = torch.randint(0, Nn, (Bc, P, S), generator=g, dtype=torch.int32).to(cloud.device)
+    out3 = torch.empty(Bc * P, layers[-1].Cout, device=cloud.device)
+    rows = Bc * P * S
+    t = timed(lambda: fused.mlp_stack(1, rows, 3 + C, layers, out3, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
+    flops = 2.0 * rows * sum(L.K * L.Cout for L in layers)
+    res["mlp"] = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", "bound": "mfma",
+                  "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_us": t * 1e6}
     return res
 
 
