@@ -18,6 +18,8 @@
 //     holds ~0.4 % of a unit cloud), the per-scale bookkeeping runs only behind it;
 //   * a wave stops testing once its queries are full; the workgroup leaves when all four are.
 // Algorithmic bytes: 12*B*(N+M) + 4*B*M*sum(nsample); B*M*N distance evaluations worst case.
+#include <cstdlib>
+
 #include "g4d_common.h"
 
 namespace g4d {
@@ -236,10 +238,11 @@ static int ball_query_msg_impl(int b, int n, int m, int nscales, const float *ra
         }
     }
     if (n == 0) return G4D_OK;
-    // queries per wave: keep >= ~2048 waves in the launch when the problem allows
+    // queries per wave: keep >= ~4096 waves in the launch when the problem allows
     const long long queries = (long long)b * m;
+    static const long long min_waves = getenv("G4D_BQ_MIN_WAVES") ? atoll(getenv("G4D_BQ_MIN_WAVES")) : 4096;  // measured: SA1 (8192 queries) 55 us at 4 queries per wave, 44 at 2, 58 at 1
     int qw = 4;
-    while (qw > 1 && queries / qw < 2048) qw >>= 1;
+    while (qw > 1 && queries / qw < min_waves) qw >>= 1;
     dim3 grid((m + 4 * qw - 1) / (4 * qw), b);
     if (boxes) {
         const int nblk = (n + 63) / 64;
