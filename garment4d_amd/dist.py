@@ -74,16 +74,22 @@ def clip_max_over_frames(frame_feats_local: torch.Tensor, frame_ids_local: torch
 
 
 def temporal_attention(last_feat_local: torch.Tensor, frame_ids_local: torch.Tensor, n_frames: int, T: int, qkv,
-                       group=None, out=None, col0: int = 0) -> torch.Tensor:
+                       group=None, out=None, col0: int = 0, clip_range=None) -> torch.Tensor:
     """The reference's temporal attention (mesh_encoder.py:467-476) for frame-sharded features: k, v of ALL T frames
     of a clip are needed, so the per-frame features are all-gathered once (RCCL all-gather; skipped with group=False or
     without an initialised process group), q/k/v are computed locally, and each rank keeps the rows of its own frames.
     last_feat_local (f_local, Vg, C); qkv: the per-vertex Linear(C -> 3C) (`temporal_qkv_*`, bias-free), any callable
     mapping (..., C) -> (..., 3C).  On the GPU the two skinny contractions run on the HIP kernels of csrc/attention.hip
     (T <= 32, C % 16 == 0); on CPU tensors (the gloo tests) with torch.matmul.
-    out/col0: optional (f_local, Vg, >= col0 + C) buffer to write the result into (only when nothing is sharded)."""
+    out/col0: optional (f_local, Vg, >= col0 + C) buffer to write the result into.
+    clip_range = (first, last) clip touched by the local frames (host ints): when sharded, q/k/v and the attention are
+    evaluated for those clips only instead of for every clip of the batch on every rank."""
     sharded = dist.is_initialized() and group is not False and dist.get_world_size(group) > 1
     feats = allgather_frames(last_feat_local, n_frames, group) if sharded else last_feat_local
+    if sharded and clip_range is not None:
+        c0, c1 = int(clip_range[0]), int(clip_range[1])
+        feats = feats[c0 * T:(c1 + 1) * T]
+        frame_ids_local = frame_ids_local - c0 * T
     F_, Vg, C = feats.shape
     n_clips = F_ // T
     qkv_all = qkv(feats.reshape(n_clips * T, Vg, C))                              # (F, Vg, 3C)

@@ -240,6 +240,6 @@ class PCALBSGarmentUseSegEncoderSeg(GarmentRefinementHead):
         out["lbs_pred_garment_v"], out["lbs_stage1_pred_garment_v"] = posed, stage1
         out["iter_regressed_lbs_garment_v"] = GarmentRefinementHead.forward(
             self, posed, body_v, body_vn, out["garment_v_list"], out["_garment_f_list_pm"], self._adj_scipy, nbatch, T, group=group,
-            frame_ids=fid_t)
+            frame_ids=fid_t, clip_range=(ids[0] // T, ids[-1] // T))
         return out
 

@@ -171,7 +171,8 @@ class GarmentRefinementHead(nn.Module):
         L = hit[1]
         return lambda x: fused.linear(x.reshape(-1, x.shape[-1]).contiguous(), L).view(*x.shape[:-1], -1)
 
-    def forward(self, cur_garment_v, body_v, body_vn, garment_v_list, garment_f_list, adj, nbatch, T, group=None, frame_ids=None):
+    def forward(self, cur_garment_v, body_v, body_vn, garment_v_list, garment_f_list, adj, nbatch, T, group=None, frame_ids=None,
+                clip_range=None):
         """cur_garment_v (F,Vg,3) LBS-posed garment; body_v / body_vn (F,V,3) body vertices / normals; garment_v_list[i] (F,N_i,3)
         and garment_f_list[i] (F,N_i,C_i) POINT-major encoder levels; adj the normalised garment adjacency; F = local frames
         (= nbatch*T without sharding; with sharding pass the process group and the global ids of the local frames).
@@ -206,7 +207,8 @@ class GarmentRefinementHead(nn.Module):
                                     garment_f_list[i], feat, col, table=tables[i])
                 col += self.feat_num
             if it > 0:                                                               # :467-476
-                gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group, out=feat, col0=col)
+                gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group, out=feat, col0=col,
+                                         clip_range=clip_range)
             h = feat
             for i, m in enumerate(regress[it]):                                      # :477-481
                 h = m(h, adj, False, relu=(i != 3))

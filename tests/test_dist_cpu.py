@@ -42,6 +42,8 @@ def _worker(rank, world, port, n_frames, T, ret):
             q, k, v = [z.reshape(n_frames // T, T, 20) for z in qkv(full.reshape(n_frames // T, T, 5, 4)).chunk(3, -1)]
             want = (torch.softmax(q @ k.transpose(1, 2) / T ** 0.5, -1) @ v).reshape(n_frames, 5, 4)[b:e]
         assert torch.allclose(got, want, atol=1e-6)
+        got2 = gd.temporal_attention(local, ids[b:e], n_frames, T, qkv, clip_range=(b // T, (e - 1) // T))  # touched clips only
+        assert torch.allclose(got2, want, atol=1e-6)
         ret[rank] = True
     finally:
         dist.destroy_process_group()
