@@ -185,3 +185,30 @@ def test_chain_kernel_equals_lds_kernels(widths, S, pool, monkeypatch):
     assert (outs[True][:, :2] == 3.0).all() and (outs[True][:, 2 + widths[-1]:] == 3.0).all()
     scale = float(outs[False].abs().max())
     assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("widths", [(3, 32, 32, 64), (195, 128, 128, 256), (99, 128, 128), (128, 7)])
+@pytest.mark.parametrize("S,pool", [(16, 1), (64, 1), (4, 2), (1, 0)])
+def test_chain_kernel_32_rows_per_wave(widths, S, pool, monkeypatch):
+    """Large launches take the 32-rows-per-wave instantiation of mlp_chain.hip (pool groups span 2 waves at S = 64)."""
+    g = torch.Generator().manual_seed(S + len(widths))
+    S_ = max(S, 1)
+    B, N = 2, 300
+    P = 70000 // (B * S_) + 3                        # > 65536 rows and not a multiple of the 128-row workgroup tile
+    C = widths[0] - 3
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    new_xyz = torch.rand(B, P, 3, generator=g).cuda()
+    feats = torch.randn(B, N, max(C, 1), generator=g).cuda() if C > 0 else None
+    idx = torch.randint(0, N, (B, P, S_), generator=g, dtype=torch.int32).cuda()
+    layers = [fused.PackedLayer(torch.randn(co, ci, generator=g).cuda() * (1.5 / ci ** 0.5), (torch.rand(co, generator=g) + 0.5).cuda(),
+                                torch.randn(co, generator=g).cuda() * 0.1, relu=True) for ci, co in zip(widths[:-1], widths[1:])]
+    rows = B * P * S_
+    assert rows >= 65536 and fused.chain_fits(layers, pool, S_, 1)
+    outs = {}
+    for chain in (True, False):
+        monkeypatch.setattr(fused, "USE_CHAIN", chain)
+        o = torch.empty((rows // S_ if pool else rows, widths[-1]), device="cuda")
+        fused.mlp_stack(1, rows, widths[0], layers, o, pool=pool, S=S_, group=(N, P, max(C, 0), 1, xyz, new_xyz, feats, idx))
+        outs[chain] = o
+    scale = float(outs[False].abs().max())
+    assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * max(scale, 1.0)
