@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libg4d_hip.so")
+LIB_PATH = os.environ.get("G4D_LIB_PATH") or os.path.join(_HERE, "lib", "libg4d_hip.so")
 
 _vp = ctypes.c_void_p
 _I = ctypes.c_int
@@ -51,6 +51,8 @@ SIGNATURES = {
     "g4d_mlp_chain_supported": [_I, _vp],
     "g4d_mlp_chain_f32": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
                           _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
+    "g4d_mlp_chain_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
+                           _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_segment_select_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_segment_take_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_vertex_normals_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -11,10 +11,10 @@ namespace g4d {
 constexpr int kMaxLayersH = 4;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {  // RNE, lo -> bits [15:0]
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef __bf16 bf16x2_s __attribute__((ext_vector_type(2)));
+typedef float f32x2_s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {  // RNE, lo -> bits [15:0]; compiles to v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_s){lo, hi}, bf16x2_s));  // (no inline asm: see mlp_chain_bf16.hip)
 }
 
 struct StackLayerH {

@@ -38,7 +38,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "Wf", "Wf16", "scale", "shift", "K", "Kpad", "Cout", "relu")
+    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -56,7 +56,10 @@ class PackedLayer:
         Wf = W.view(cpad // 16, 16, kpad // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
         # bf16 copy (RNE) in the fragment order of v_mfma_f32_16x16x32_bf16: [tile][k-step of 32][lane = fq*16+fi][8 k]
         Wf16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
-        self.W, self.Wf, self.Wf16, self.scale, self.shift = W, Wf, Wf16, sc, sh
+        # bf16 copy in CHAIN order (csrc/mlp_chain_bf16.hip): lane (fi, g) element e <-> k = 32 s + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)
+        kperm = torch.tensor([[(4 * g + e) if e < 4 else (16 + 4 * g + e - 4) for e in range(8)] for g in range(4)], device=dev)
+        Wc16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 32)[..., kperm].permute(0, 2, 3, 1, 4).contiguous()
+        self.W, self.Wf, self.Wf16, self.Wc16, self.scale, self.shift = W, Wf, Wf16, Wc16, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
 
 
@@ -133,7 +136,7 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
     orow = rows // S if pool else rows
     if out is None:
         out = torch.empty((orow, layer.Cout), dtype=torch.float32, device=x2d.device)
-    if not pool and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
+    if not pool and PRECISION == "fp32" and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
         # ragged K (e.g. the 323- / 195-wide GCN inputs) or a very narrow output: the chain kernel streams the rows with
         # unaligned 16-byte loads and wins (82 vs 60 TFLOP/s at 323 -> 128); results are bit-identical (same k order)
         return mlp_stack(0, rows, layer.K, [layer], out, col0=col0, X=x2d, ldx=ldx)
@@ -179,7 +182,7 @@ _CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8,
 def chain_fits(layers, pool, S, mode):
     """Register-resident chain kernel (csrc/mlp_chain.hip): DIRECT / GROUP loader, 1..3 layers whose 16-channel tile counts
     are one of the instantiated combinations (mirrors g4d_mlp_chain_supported)."""
-    if not USE_CHAIN or mode not in (0, 1, 2) or PRECISION != "fp32" or (pool and S not in _POOL_WINDOWS):
+    if not USE_CHAIN or mode not in (0, 1, 2) or (pool and S not in _POOL_WINDOWS):
         return False
     return tuple((L.Cout + 15) // 16 for L in layers) in _CHAIN_TILES
 
@@ -218,6 +221,13 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
         cV, rowptr, colidx, vals = csr
         cr, cc, cv = rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr()
     tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
+    if PRECISION == "bf16" and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
+        W16 = PA(*[L.Wc16.data_ptr() for L in layers])
+        _lib.call("g4d_mlp_chain_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
+                  n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
+                  ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
+                  out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
+        return out
     if _use_bf16(rows):
         W16 = PA(*[L.Wf16.data_ptr() for L in layers])
         _lib.call("g4d_mlp_stack_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
@@ -225,7 +235,7 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
                   ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
                   ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
         return out
-    if chain_fits(layers, pool, S, mode):
+    if PRECISION == "fp32" and chain_fits(layers, pool, S, mode):
         _lib.call("g4d_mlp_chain_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
                   n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
                   ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),

@@ -180,6 +180,16 @@ int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx,
                       const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
                       float *tap_out, int tap_ld, g4d_stream_t stream);
 
+/* bf16 variant of g4d_mlp_chain_f32 (BASELINE config 3): operands bf16 (RNE), fp32 accumulate / affine / pool / I/O.
+ * W[l]: bf16 in CHAIN order [CoutPad64/16][Kpad/32][64 lanes][8]: lane (fi, g) element e holds
+ * W[16 t + fi][32 s + (e < 4 ? 4 g + e : 16 + 4 g + e - 4)] (garment4d_amd/csrc/mlp_chain_bf16.hip explains the permutation). */
+int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                       const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                       int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int nlayers,
+                       const unsigned short *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
+                       const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
+                       float *tap_out, int tap_ld, g4d_stream_t stream);
+
 /* Batched SpMM of the GCN layer: out (frames,Vg,C) = Ahat (CSR) . S (frames,Vg,C) + bias (C, may be NULL), optional ReLU
  * (the caller's F.relu, modules/mesh_encoder.py:479-480, fused), all point-major (modules/pygcn/layers.py:44-55 without
  * the transposes).  GraphConvolution = g4d_linear_f32 then this. */

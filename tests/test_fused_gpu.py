@@ -212,3 +212,47 @@ def test_chain_kernel_32_rows_per_wave(widths, S, pool, monkeypatch):
         outs[chain] = o
     scale = float(outs[False].abs().max())
     assert float((outs[True] - outs[False]).abs().max()) <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("widths", [(3, 16, 16, 32), (3, 32, 32, 64), (99, 64, 64, 128), (195, 128, 128, 256), (67, 32, 32), (99, 128, 128), (40, 64),
+                                    (128, 7)])
+@pytest.mark.parametrize("S,pool", [(16, 1), (64, 1), (8, 1), (4, 2), (1, 0)])
+def test_chain_bf16_kernel(widths, S, pool, monkeypatch):
+    """csrc/mlp_chain_bf16.hip (cfg3 precision, activations chained through the accumulators as bf16 fragments) against a torch
+    emulation of the same arithmetic: operands rounded to bf16 (RNE), fp32 accumulation, fp32 affine / ReLU / pooling."""
+    monkeypatch.setattr(fused, "PRECISION", "bf16")
+    g = torch.Generator().manual_seed(len(widths) * 10 + S)
+    S_ = max(S, 1)
+    B, N, P = 2, 400, 41 if S > 1 else 1500
+    C = widths[0] - 3
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    new_xyz = torch.rand(B, P, 3, generator=g).cuda()
+    feats = torch.randn(B, N, max(C, 1), generator=g).cuda() if C > 0 else None
+    idx = torch.randint(0, N, (B, P, S_), generator=g, dtype=torch.int32).cuda()
+    Ws, layers = [], []
+    for i, (ci, co) in enumerate(zip(widths[:-1], widths[1:])):
+        W = torch.randn(co, ci, generator=g).cuda() * (1.5 / ci ** 0.5)
+        sc, sh = (torch.rand(co, generator=g) + 0.5).cuda(), torch.randn(co, generator=g).cuda() * 0.1
+        relu = i < len(widths) - 2 or pool != 0
+        Ws.append((W, sc, sh, relu))
+        layers.append(fused.PackedLayer(W, sc, sh, relu=relu))
+    rows = B * P * S_
+    assert fused.chain_fits(layers, pool, S_, 1)
+    out = torch.empty((rows // S_ if pool else rows, widths[-1]), device="cuda")
+    fused.mlp_stack(1, rows, widths[0], layers, out, pool=pool, S=S_, group=(N, P, max(C, 0), 1, xyz, new_xyz, feats, idx))
+    # emulation
+    bi = torch.arange(B, device="cuda")[:, None, None]
+    li = idx.long()
+    x = xyz[bi, li] - new_xyz[:, :, None, :]
+    if C > 0:
+        x = torch.cat([x, feats[bi, li]], -1)
+    h = x.reshape(rows, -1)
+    for W, sc, sh, relu in Ws:
+        h = (h.to(torch.bfloat16).double() @ W.to(torch.bfloat16).double().T).float() * sc + sh
+        h = torch.relu(h) if relu else h
+    if pool:
+        h = h.view(-1, S_, h.shape[-1])
+        h = h.max(1)[0] if pool == 1 else h.mean(1)
+    scale = float(h.abs().max())
+    err = float((out - h).abs().max())
+    assert err <= 1.2e-2 * max(scale, 1.0), (err, scale)   # a bf16 ulp flip of a hidden activation (2^-8 relative) now and then
