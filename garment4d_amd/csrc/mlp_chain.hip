@@ -322,6 +322,7 @@ extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
     switch (chain_key(nlayers, Cout)) {
         case 1010200: case 2020400: case 4040800: case 8081600:     // 16-16-32, 32-32-64, 64-64-128, 128-128-256
         case 2020000: case 4040000: case 8080000: case 8040000:     // 32-32, 64-64, 128-128, 128-64
+        case 16080000:                                              // 256-128 (the middle feature-propagation level)
         case 1000000: case 2000000: case 4000000: case 8000000:     // single layers up to 128
         case 8040201:                                               // 128-64-32-(<=16): last FP level + segmentation head
             return 1;
@@ -378,6 +379,7 @@ extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *
         case 4040000: G4D_CHAIN(4, 4, 0, 0)
         case 8080000: G4D_CHAIN(8, 8, 0, 0)
         case 8040000: G4D_CHAIN(8, 4, 0, 0)
+        case 16080000: G4D_CHAIN(16, 8, 0, 0)
         case 1000000: G4D_CHAIN(1, 0, 0, 0)
         case 2000000: G4D_CHAIN(2, 0, 0, 0)
         case 4000000: G4D_CHAIN(4, 0, 0, 0)

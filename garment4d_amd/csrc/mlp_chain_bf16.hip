@@ -370,6 +370,7 @@ extern "C" int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float 
         case 4040000: G4D_CHAIN(4, 4, 0, 0)
         case 8080000: G4D_CHAIN(8, 8, 0, 0)
         case 8040000: G4D_CHAIN(8, 4, 0, 0)
+        case 16080000: G4D_CHAIN(16, 8, 0, 0)
         case 1000000: G4D_CHAIN(1, 0, 0, 0)
         case 2000000: G4D_CHAIN(2, 0, 0, 0)
         case 4000000: G4D_CHAIN(4, 0, 0, 0)

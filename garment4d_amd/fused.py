@@ -176,7 +176,7 @@ def stack_fits(layers, pool, S, rows=None):
 
 
 USE_CHAIN = os.environ.get("G4D_MLP_CHAIN", "1") != "0"
-_CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (1,), (2,), (4,), (8,), (8, 4, 2, 1)}
+_CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (16, 8), (1,), (2,), (4,), (8,), (8, 4, 2, 1)}
 
 
 def chain_fits(layers, pool, S, mode):
@@ -417,7 +417,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
             mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
                       tap=(len(layers) - 1, out.view(B * n, -1)))
             return out, logits
-    if USE_STACK and stack_fits(layers, 0, 1, rows=B * n):
+    if USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
     elif layers[0].Cout > 64:
         # wide FP level: every 64-channel tile of the first layer would redo the interpolation -> materialise the
