@@ -152,6 +152,24 @@ _MAX_STACK_LDS = 150 * 1024
 PRECISION = "fp32"  # "bf16": MLP operands in bf16 (cfg3), set per call through encoder.forward_fused(precision=...)
 
 
+class precision:
+    """with fused.precision("bf16"): ...  -- shared-MLP operands in bf16 (BASELINE config 3) inside the block."""
+
+    def __init__(self, mode):
+        assert mode in ("fp32", "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        global PRECISION
+        self.prev, PRECISION = PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.prev
+        return False
+
+
 _BF16_MIN_ROWS = 8192  # below 128 workgroups of 64 rows the one-launch bf16 stack leaves the chip idle: stay on the fp32 path
 
 

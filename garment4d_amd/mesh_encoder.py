@@ -119,7 +119,7 @@ class PCAGarmentEncoderSeg(nn.Module):
             frame_ids = torch.arange(F_, device=x.device)
         cm = fused.to_channel_major if self.channel_major_outputs else (lambda t: t)
         out = {"middle_results": {}}
-        feat_global, sem_logits, feats_pm, xyz_list = self.pointnet.forward_fused(x.contiguous())
+        feat_global, sem_logits, feats_pm, xyz_list = self.pointnet.forward_fused(x.contiguous(), precision=fused.PRECISION)
         out["feat_global"] = feat_global
         out["feature_list"] = [None if f is None else cm(f) for f in feats_pm]
         out["xyz_list"] = xyz_list
@@ -169,11 +169,16 @@ class PCALBSGarmentUseSegEncoderSeg(GarmentRefinementHead):
         return lbs_garment_interpolation(pred_template_garment_v, Tpose_vertices, Tpose_root_joints, zeropose_vertices, body_model.parents,
                                          gt_pose, T_J_regressor, T_lbs_weights, self.adj_old, K=K)
 
-    def forward(self, x, body_model, batch, *, group=None, clip_ids=None):
+    def forward(self, x, body_model, batch, *, group=None, clip_ids=None, precision="fp32"):
         """x (nbatch, T, N, 3); body_model needs `.parents`, `.faces`, `.J_regressor`; batch holds the reference's keys
         (`smpl_vertices_torch`, `Tpose_smpl_vertices_torch`, `Tpose_smpl_root_joints_torch`, `zeropose_smpl_vertices_torch`,
         `pose_torch`, `T_J_regressor`, `T_lbs_weights`), each with the same leading (nbatch, T) as x.  Clips shard over ranks
-        without any exchange: every rank calls this on its own clips."""
+        without any exchange: every rank calls this on its own clips.  precision="bf16": the set-abstraction / feature-propagation
+        MLP operands in bf16 (BASELINE config 3); sampling, grouping, skinning, positional encoders, attention and GCN stay fp32."""
+        with fused.precision(precision):
+            return self._forward(x, body_model, batch)
+
+    def _forward(self, x, body_model, batch):
         assert not torch.is_grad_enabled() and not self.training, "inference only: model.eval() under torch.no_grad()"
         import scipy.sparse as sp
         nbatch, T = x.size(0), x.size(1)

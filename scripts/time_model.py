@@ -21,6 +21,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 loader = sys.argv[5] if len(sys.argv) > 5 else "gpu"
+prec = sys.argv[6] if len(sys.argv) > 6 else "fp32"
 
 
 def dev(a):
@@ -61,15 +62,15 @@ with torch.no_grad():
     others = torch.cat([logits[..., :tgt], logits[..., tgt + 1:]], -1).max(-1)[0]
     m.PCA_garment_encoder.pointnet.FC_layer[2].conv.bias[tgt] += torch.quantile((others - logits[..., tgt]).flatten()[:1000000], 0.35)
     for _ in range(2):
-        out = m(x, bm, make_batch())
+        out = m(x, bm, make_batch(), precision=prec)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        out = m(x, bm, make_batch())
+        out = m(x, bm, make_batch(), precision=prec)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
 offs = [float((b - a).norm(dim=-1).mean()) for a, b in zip([out["lbs_pred_garment_v"].reshape(-1, out["lbs_pred_garment_v"].shape[-2], 3)] + out["iter_regressed_lbs_garment_v"][:-1],
                                                            out["iter_regressed_lbs_garment_v"])]
 print("mean per-round vertex offset (m):", [round(o, 4) for o in offs])
-print(f"loader={loader} nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
+print(f"precision={prec} loader={loader} nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
       f"{nbatch*T/dt:.1f} frames/s; finite={bool(torch.isfinite(out['iter_regressed_lbs_garment_v'][-1]).all())}")
