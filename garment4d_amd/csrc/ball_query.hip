@@ -31,7 +31,8 @@ struct BqArgs {
     int *idx[4];
 };
 
-constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered; a multiple of 128 (two points per lane and step)
 
 // boxes: per (frame, 64-point block) axis-aligned bounds [lo.xyz, hi.xyz], written by ball_boxes_kernel
 __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long long total, const float *__restrict__ xyz_all,
@@ -166,27 +167,38 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 }
             }
         } else
-        for (int c = 0; c < cn && open > 0; c += 64) {
-            const int k = base + c + lane;
-            // lanes past the end of the cloud hold +inf coordinates (stage loader) -> never a hit, no `valid` predicate
-            const float x = sp[buf][0][c + lane], y = sp[buf][1][c + lane], z = sp[buf][2][c + lane];
+        for (int c = 0; c < cn && open > 0; c += 128) {
+            // two points per lane and step (c + lane, c + 64 + lane): the distance arithmetic runs on the packed fp32 pipe
+            // (v_pk_add / v_pk_mul: same IEEE results per component, half the instructions); lanes past the end of the cloud
+            // hold +inf coordinates (stage loader) -> never a hit, no `valid` predicate
+            const f32x2 x = {sp[buf][0][c + lane], sp[buf][0][c + 64 + lane]};
+            const f32x2 y = {sp[buf][1][c + lane], sp[buf][1][c + 64 + lane]};
+            const f32x2 z = {sp[buf][2][c + lane], sp[buf][2][c + 64 + lane]};
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
-                const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                // common case: nobody within the LARGEST radius -> one compare, one branch for all NS scales
-                if (__builtin_amdgcn_ballot_w64(d2 < a.radius2_max) == 0ull) continue;
+                const f32x2 dx = f32x2{qx[i], qx[i]} - x, dy = f32x2{qy[i], qy[i]} - y, dz = f32x2{qz[i], qz[i]} - z;
+                const f32x2 d2v = dx * dx + dy * dy + dz * dz;
+                // common case: nobody within the LARGEST radius -> two compares, one branch for all NS scales
+                const unsigned long long any0 = __builtin_amdgcn_ballot_w64(d2v[0] < a.radius2_max);
+                const unsigned long long any1 = __builtin_amdgcn_ballot_w64(d2v[1] < a.radius2_max);
+                if ((any0 | any1) == 0ull) continue;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
-                        const bool hit = d2 < a.radius2[s];
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                        if (mask != 0ull) {
-                            if (cnt[i][s] == 0) first[i][s] = base + c + __builtin_ctzll(mask);
-                            const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
-                            cnt[i][s] += __builtin_popcountll(mask);
-                            if (cnt[i][s] >= a.nsample[s]) --open;
+                for (int h = 0; h < 2; ++h) {  // ascending index order: first the low half, then the high half
+                    if ((h ? any1 : any0) == 0ull) continue;
+                    const float d2 = h ? d2v[1] : d2v[0];
+                    const int k = base + c + h * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
+                            const bool hit = d2 < a.radius2[s];
+                            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                            if (mask != 0ull) {
+                                if (cnt[i][s] == 0) first[i][s] = base + c + h * 64 + __builtin_ctzll(mask);
+                                const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
+                                cnt[i][s] += __builtin_popcountll(mask);
+                                if (cnt[i][s] >= a.nsample[s]) --open;
+                            }
                         }
                     }
                 }
