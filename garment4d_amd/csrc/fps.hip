@@ -248,10 +248,7 @@ static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz,
 }
 
 int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s);  // fps_bucket.hip
-int fps_bucket_indexed(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float4 *sorted, float *boxes,
-                       int *npad_out, hipStream_t s);
 
-int ref_block_size_pub(int n) { return ref_block_size(n); }  // neighbors.hip
 
 static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|8|16|0(generic); unset = automatic (bucketed kernel for 2048 < n <= 8192)
 

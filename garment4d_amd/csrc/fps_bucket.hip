@@ -97,8 +97,7 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
 template <int W, int P>
 __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
-                                                           float *__restrict__ temp_all, int *__restrict__ idx_all,
-                                                           float4 *__restrict__ sorted_all, float *__restrict__ boxes_all) {
+                                                           float *__restrict__ temp_all, int *__restrict__ idx_all) {
     constexpr int T = 64 * W, NPAD = T * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);         // [2][16] candidate keys
@@ -191,21 +190,6 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
         const float a0 = wave_min_f32(ok ? px[i] : INF), a1 = wave_min_f32(ok ? py[i] : INF), a2 = wave_min_f32(ok ? pz[i] : INF);
         const float a3 = wave_max_f32(ok ? px[i] : -INF), a4 = wave_max_f32(ok ? py[i] : -INF), a5 = wave_max_f32(ok ? pz[i] : -INF);
         if (lane == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }
-    }
-    if (sorted_all) {
-        // export the spatial index this kernel builds anyway (g4d_fps_indexed_f32): the cloud in Morton order -- (x, y, z, original
-        // index), padding = +inf / -1 -- and the bounds of its 64-point blocks, for the neighbour searches of the same level
-        float4 *so = sorted_all + (size_t)blockIdx.x * NPAD;
-        float *bo = boxes_all + (size_t)blockIdx.x * (NPAD / 64) * 6;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const bool ok = pk[i] >= 0;
-            so[(i * W + wave) * 64 + lane] = make_float4(ok ? px[i] : INF, ok ? py[i] : INF, ok ? pz[i] : INF, __int_as_float(pk[i]));
-        }
-        if (lane < P) {
-            float *o = bo + (size_t)(lane * W + wave) * 6;
-            o[0] = blx; o[1] = bly; o[2] = blz; o[3] = bhx; o[4] = bhy; o[5] = bhz;
-        }
     }
     if (t == 0) { idx[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
     __syncthreads();
@@ -306,8 +290,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
 }
 
 template <int W, int P>
-static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s,
-                         float4 *sorted = nullptr, float *boxes = nullptr) {
+static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
     const size_t lds = 1024 + body;
@@ -317,7 +300,7 @@ static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *x
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx, sorted, boxes);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
     return check_launch("g4d_fps_f32(bucketed)");
 }
 
@@ -330,14 +313,6 @@ int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xy
         return launch_bucket<16, 8>(b, n, m, bs, log2bs, xyz, temp, idx, s);
     }
     if (n > 2048 && n <= 4096) return launch_bucket<16, 4>(b, n, m, bs, log2bs, xyz, temp, idx, s);
-    return -1;
-}
-
-// FPS that also exports its Morton-sorted cloud and block bounds; npad_out = padded point count (8192 or 4096).
-int fps_bucket_indexed(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float4 *sorted, float *boxes,
-                       int *npad_out, hipStream_t s) {
-    if (n > 4096 && n <= 8192) { *npad_out = 8192; return launch_bucket<16, 8>(b, n, m, bs, log2bs, xyz, temp, idx, s, sorted, boxes); }
-    if (n > 2048 && n <= 4096) { *npad_out = 4096; return launch_bucket<16, 4>(b, n, m, bs, log2bs, xyz, temp, idx, s, sorted, boxes); }
     return -1;
 }
 

@@ -330,49 +330,6 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False):
     return outs
 
 
-# ---- bucketed neighbour search on the FPS kernel's spatial index (csrc/neighbors.hip) -------------------------------------------
-USE_INDEX = os.environ.get("G4D_SPATIAL_INDEX", "1") != "0"
-
-
-def fps_indexed(xyz, npoint):
-    """FPS of a (B,N,3) cloud, 2048 < N <= 8192, that also returns the Morton index the kernel builds:
-    (sample idx (B,npoint) int32, index = dict(n, npad, sorted (B,npad,4), boxes (B,npad/64,6)))."""
-    B, N, _ = xyz.shape
-    npad = 8192 if N > 4096 else 4096
-    sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-    srt = torch.empty((B, npad, 4), dtype=torch.float32, device=xyz.device)
-    boxes = torch.empty((B, npad // 64, 6), dtype=torch.float32, device=xyz.device)
-    _lib.call("g4d_fps_indexed_f32", B, N, npoint, xyz.data_ptr(), 0, sidx.data_ptr(), srt.data_ptr(), boxes.data_ptr(), _lib.stream_ptr())
-    return sidx, {"n": N, "npad": npad, "sorted": srt, "boxes": boxes}
-
-
-def subset_index(index, sample_idx):
-    """The sampled points in the cloud's Morton order (+ block bounds): dict(m, sorted (B,mpad,4), boxes (B,mpad/64,6))."""
-    B, m = sample_idx.shape
-    mpad = 64
-    while mpad < m:
-        mpad *= 2
-    dev = sample_idx.device
-    sub = torch.empty((B, mpad, 4), dtype=torch.float32, device=dev)
-    boxes = torch.empty((B, mpad // 64, 6), dtype=torch.float32, device=dev)
-    _lib.call("g4d_subset_index_f32", B, index["npad"], m, index["sorted"].data_ptr(), sample_idx.data_ptr(), sub.data_ptr(), boxes.data_ptr(),
-              _lib.stream_ptr())
-    return {"m": m, "sorted": sub, "boxes": boxes}
-
-
-def three_nn_indexed(index, sub):
-    """three_nn(unknown = the indexed cloud, known = the indexed samples): (dist2 (B,n,3), idx (B,n,3) int32), bit-identical to
-    g4d_three_nn_f32."""
-    B = index["sorted"].shape[0]
-    n = index["n"]
-    dev = index["sorted"].device
-    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
-    nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=dev)
-    _lib.call("g4d_three_nn_indexed_f32", B, n, index["npad"], sub["m"], index["sorted"].data_ptr(), sub["sorted"].data_ptr(),
-              sub["boxes"].data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), _lib.stream_ptr())
-    return dist2, nn_idx
-
-
 def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
     """Fused PointnetSAModule(MSG).forward (pointnet2_modules.py:19-55), eval mode.
     xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major)."""

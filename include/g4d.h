@@ -190,25 +190,6 @@ int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float *X, int ldx
                        const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
                        float *tap_out, int tap_ld, g4d_stream_t stream);
 
-/* ---- bucketed neighbour search on the FPS kernel's spatial index (garment4d_amd/csrc/neighbors.hip) -------------------------- */
-
-/* g4d_fps_f32 for 2048 < n <= 8192 that also writes the index it builds internally: sorted_pts (b, npad, 4) = the cloud in
- * Morton order as (x, y, z, original index as int bits), padding = (+inf, +inf, +inf, -1), npad = 8192 (n > 4096) or 4096;
- * boxes (b, npad/64, 6) = [lo.xyz, hi.xyz] of every 64-point block.  Sampling result identical to g4d_fps_f32. */
-int g4d_fps_indexed_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, float *sorted_pts, float *boxes,
-                        g4d_stream_t stream);
-
-/* The m <= 2048 sampled points (sample_idx (b,m) = FPS output, indices into the ORIGINAL cloud) in the same Morton order:
- * sub_sorted (b, mpad, 4) = (x, y, z, sample number), sub_boxes (b, mpad/64, 6); mpad = m rounded up to a power of two >= 64. */
-int g4d_subset_index_f32(int b, int npad, int m, const float *sorted_pts, const int *sample_idx, float *sub_sorted,
-                         float *sub_boxes, g4d_stream_t stream);
-
-/* three_nn (interpolate_gpu.cu:9-74) of every point of the sorted cloud against the indexed sample set: same dist2 (b,n,3) /
- * idx (b,n,3) as g4d_three_nn_f32(unknown = the cloud, known = the samples) -- bit-identical, ties to the lower index --
- * visiting only the 64-sample blocks whose bounds are within the current third-nearest distance of some point of a wave. */
-int g4d_three_nn_indexed_f32(int b, int n, int npad, int m, const float *sorted_pts, const float *known_sorted,
-                             const float *known_boxes, float *dist2, int *idx, g4d_stream_t stream);
-
 /* Batched SpMM of the GCN layer: out (frames,Vg,C) = Ahat (CSR) . S (frames,Vg,C) + bias (C, may be NULL), optional ReLU
  * (the caller's F.relu, modules/mesh_encoder.py:479-480, fused), all point-major (modules/pygcn/layers.py:44-55 without
  * the transposes).  GraphConvolution = g4d_linear_f32 then this. */
