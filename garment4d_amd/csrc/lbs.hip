@@ -99,7 +99,11 @@ __global__ void __launch_bounds__(64) lbs_rigid_kernel(int J, int pose2rot, cons
                                                       const int *__restrict__ parents, float *__restrict__ rot_out /* (B,J,9)|null */,
                                                       float *__restrict__ posed_joints /* (B,J,3)|null */,
                                                       float *__restrict__ rel_transforms /* (B,J,16) */,
-                                                      float *__restrict__ pose_feature /* (B,(J-1)*9)|null */) {
+                                                      float *__restrict__ pose_feature /* (B,pf_ld)|null, written at column pf_col0 */,
+                                                      int pf_ld, int pf_col0,
+                                                      const float *__restrict__ Jt /* (J,3)|null: joints of the template */,
+                                                      const float *__restrict__ Js /* (J,3,NB): d joints / d betas */,
+                                                      const float *__restrict__ betas, int nb, int betas_bstride) {
     __shared__ float sR[64][9], sJ[64][3], sL[64][12], sG[64][12];
     __shared__ int sP[64];
     const int b = blockIdx.x, l = threadIdx.x;
@@ -115,8 +119,20 @@ __global__ void __launch_bounds__(64) lbs_rigid_kernel(int J, int pose2rot, cons
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) sR[l][k] = R[k];
-        const float *jp = joints + ((size_t)b * J + l) * 3;
-        sJ[l][0] = jp[0]; sJ[l][1] = jp[1]; sJ[l][2] = jp[2];
+        if (Jt) {
+            // fused front end: J_regressor (v_template + shapedirs beta) == (J_regressor v_template) + (J_regressor shapedirs) beta;
+            // the two products are constants of the model, so the joints cost 3 * NB FMAs here instead of a V-long reduction
+            const float *be = betas + (size_t)b * betas_bstride;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float acc = Jt[l * 3 + r];
+                for (int k = 0; k < nb; ++k) acc = fmaf(Js[(l * 3 + r) * nb + k], be[k], acc);
+                sJ[l][r] = acc;
+            }
+        } else {
+            const float *jp = joints + ((size_t)b * J + l) * 3;
+            sJ[l][0] = jp[0]; sJ[l][1] = jp[1]; sJ[l][2] = jp[2];
+        }
         sP[l] = parents[l];
         if (rot_out) {
 #pragma unroll
@@ -125,9 +141,10 @@ __global__ void __launch_bounds__(64) lbs_rigid_kernel(int J, int pose2rot, cons
         if (pose_feature && l > 0) {  // lbs.py:217 / :222  (R[1:] - I).view(B, -1)
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                pose_feature[(size_t)b * (J - 1) * 9 + (l - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
+                pose_feature[(size_t)b * pf_ld + pf_col0 + (l - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
         }
     }
+    if (Jt && pose_feature && l < nb) pose_feature[(size_t)b * pf_ld + l] = betas[(size_t)b * betas_bstride + l];  // [betas | R - I]
     __syncthreads();
     if (l < J) {  // local transform [R | J - J_parent]  (lbs.py:390-396)
         const int p = sP[l];
@@ -171,7 +188,7 @@ __global__ void __launch_bounds__(64) lbs_rigid_kernel(int J, int pose2rot, cons
 // 256 threads = 64 columns x 4 k-slices: posedirs (17 MB) streams once per <= 8 frames with 256-byte coalesced row
 // segments and ~1300 waves in flight (a thread-per-vertex layout leaves the chip at 27 workgroups and is latency
 // bound); the four k-slices meet in LDS.
-__global__ void __launch_bounds__(256) lbs_pose_blend_kernel(int B, int E, int PF, const float *__restrict__ v_shaped,
+__global__ void __launch_bounds__(256) lbs_pose_blend_kernel(int B, int E, int PF, const float *__restrict__ v_shaped, long long v_bstride,
                                                             const float *__restrict__ pose_feature,
                                                             const float *__restrict__ posedirs, float *__restrict__ v_posed) {
     extern __shared__ float smem[];
@@ -207,7 +224,7 @@ __global__ void __launch_bounds__(256) lbs_pose_blend_kernel(int B, int E, int P
         for (int f = 0; f < kFB; ++f) {
             if (f < nf) {
                 const float o = ((acc[f] + sRed[(0 * 64 + col) * kFB + f]) + sRed[(1 * 64 + col) * kFB + f]) + sRed[(2 * 64 + col) * kFB + f];
-                v_posed[(size_t)(b0 + f) * E + e] = o + v_shaped[(size_t)(b0 + f) * E + e];
+                v_posed[(size_t)(b0 + f) * E + e] = o + v_shaped[(size_t)(b0 + f) * v_bstride + e];
             }
         }
     }
@@ -288,7 +305,8 @@ extern "C" int g4d_rigid_transform_f32(int b, int j, int pose2rot, const float *
     if (b == 0) return G4D_OK;
     G4D_REQUIRE(pose && joints && parents && rel_transforms, "g4d_rigid_transform_f32: null pointer");
     hipLaunchKernelGGL(lbs_rigid_kernel, dim3(b), dim3(64), 0, G4D_S(stream), j, pose2rot, pose, joints, parents, rot_out,
-                       posed_joints, rel_transforms, pose_feature);
+                       posed_joints, rel_transforms, pose_feature, (j - 1) * 9, 0, (const float *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, 0, 0);
     return check_launch("g4d_rigid_transform_f32");
 }
 
@@ -304,8 +322,8 @@ extern "C" int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v
         const size_t lds = sizeof(float) * ((size_t)kFB * pf + 3 * 64 * kFB);
         G4D_REQUIRE(lds <= 64 * 1024, "g4d_lbs_pose_skin_f32: pose feature too long for LDS staging");
         dim3 grid((v * 3 + 63) / 64, (b + kFB - 1) / kFB);
-        hipLaunchKernelGGL(lbs_pose_blend_kernel, grid, dim3(256), lds, G4D_S(stream), b, v * 3, pf, v_in, pose_feature, posedirs,
-                           v_posed_scratch);
+        hipLaunchKernelGGL(lbs_pose_blend_kernel, grid, dim3(256), lds, G4D_S(stream), b, v * 3, pf, v_in, (long long)v * 3, pose_feature,
+                           posedirs, v_posed_scratch);
         skin_in = v_posed_scratch;
     }
     G4D_REQUIRE((size_t)j * 12 * sizeof(float) <= 64 * 1024, "g4d_lbs_pose_skin_f32: too many joints");
@@ -313,3 +331,30 @@ extern "C" int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v
                        weights, weights_batched ? (long long)v * j : 0ll, weights_batched > 0 ? weights_batched : 1, A, verts);
     return check_launch("g4d_lbs_pose_skin_f32");
 }
+
+// lbs() in three launches: [rigid transform with the joints from betas, writes the blend coefficients [betas | R - I]] ->
+// [v_posed = v_template + [betas | R - I] . [shapedirs ; posedirs]] -> [skin].  The shape blend, the V-long joint regression and
+// their (B,V,3) intermediate are gone; see garment4d_amd/lbs.py for the constants.
+extern "C" int g4d_lbs_fused_f32(int b, int v, int j, int nb, int pose2rot, const float *betas, int betas_bstride, const float *pose,
+                                 const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
+                                 const int *parents, const float *lbs_weights, float *coeff_scratch, float *A_out, float *posed_joints,
+                                 float *v_posed_scratch, float *verts, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && b <= 65535 && v >= 0 && j > 0 && j <= 64 && nb >= 0 && nb <= 64, "g4d_lbs_fused_f32: bad sizes (J <= 64, NB <= 64)");
+    if (b == 0) return G4D_OK;
+    G4D_REQUIRE(betas && pose && v_template && blend_dirs && J_template && J_shapedirs && parents && lbs_weights && coeff_scratch && A_out &&
+                    v_posed_scratch && verts, "g4d_lbs_fused_f32: null pointer");
+    const int pf = (j - 1) * 9, nc = nb + pf;
+    hipLaunchKernelGGL(lbs_rigid_kernel, dim3(b), dim3(64), 0, G4D_S(stream), j, pose2rot, pose, (const float *)nullptr, parents,
+                       (float *)nullptr, posed_joints, A_out, coeff_scratch, nc, nb, J_template, J_shapedirs, betas, nb, betas_bstride);
+    if (v > 0) {
+        const size_t lds = sizeof(float) * ((size_t)kFB * nc + 3 * 64 * kFB);
+        G4D_REQUIRE(lds <= 64 * 1024, "g4d_lbs_fused_f32: too many blend coefficients for LDS staging");
+        dim3 grid((v * 3 + 63) / 64, (b + kFB - 1) / kFB);
+        hipLaunchKernelGGL(lbs_pose_blend_kernel, grid, dim3(256), lds, G4D_S(stream), b, v * 3, nc, v_template, 0ll, coeff_scratch, blend_dirs,
+                           v_posed_scratch);
+        hipLaunchKernelGGL(lbs_skin_kernel, dim3((v + 255) / 256, b), dim3(256), sizeof(float) * j * 12, G4D_S(stream), v, j, v_posed_scratch,
+                           lbs_weights, 0ll, 1, A_out, verts);
+    }
+    return check_launch("g4d_lbs_fused_f32");
+}
+

@@ -32,6 +32,32 @@ def _parents_i32(parents, device):
     return p
 
 
+USE_FUSED_LBS = True   # three-launch lbs() (g4d_lbs_fused_f32); False: the five-step path that follows lbs.py line by line
+_const_cache = {}
+
+
+def _model_constants(v_template, shapedirs, posedirs, J_regressor):
+    """[shapedirs^T ; posedirs] ((NB+PF), V*3), J_regressor v_template (J,3), J_regressor shapedirs (J,3,NB): constants of a body
+    model, computed once (the two regressor products in float64) and cached on the tensors' identities."""
+    src = (v_template, shapedirs, posedirs, J_regressor)
+    key = tuple((id(t), t._version) for t in src)
+    hit = _const_cache.get(key)
+    if hit is not None and not all(a is b for a, b in zip(hit[3], src)):
+        hit = None                       # an id recycled by a new tensor: the entry keeps its sources alive, so this cannot happen while cached
+    if hit is None:
+        V, _, NB = shapedirs.shape
+        with torch.no_grad():
+            blend_dirs = torch.cat([shapedirs.reshape(V * 3, NB).t(), posedirs], 0).contiguous()
+            Jr = J_regressor.double()
+            Jt = (Jr @ v_template.double()).float().contiguous()
+            Js = torch.einsum("jv,vrk->jrk", Jr, shapedirs.double()).float().contiguous()
+        if len(_const_cache) > 8:
+            _const_cache.clear()
+        hit = (blend_dirs, Jt, Js, src)     # holding `src` pins the ids the key is made of
+        _const_cache[key] = hit
+    return hit[:3]
+
+
 def blend_shapes(betas, shape_disps):
     """betas (B,NB), shape_disps (V,3,NB) -> per-vertex displacement (B,V,3)."""
     betas, shape_disps = _f32(betas, "betas"), _f32(shape_disps, "shape_disps")
@@ -121,20 +147,29 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     J = J_regressor.shape[0]
     dev = betas.device
     stream = _lib.stream_ptr()
+    PF = (J - 1) * 9
+    assert posedirs.shape[0] == PF and posedirs.shape[1] == V * 3, "posedirs must be ((J-1)*9, V*3)"
+    posed = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
+    A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=dev)
+    verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+    v_posed = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+    if USE_FUSED_LBS and NB <= 64:
+        # three launches: the joints follow from betas through two model constants (J_regressor is linear), the shape blend rides
+        # in the pose-blend kernel as NB extra coefficients
+        blend_dirs, Jt, Js = _model_constants(v_template, shapedirs, posedirs, J_regressor)
+        coeff = torch.empty((B, NB + PF), dtype=torch.float32, device=dev)
+        _lib.call("g4d_lbs_fused_f32", B, V, J, NB, int(bool(pose2rot)), betas.data_ptr(), NB if betas.shape[0] == B else 0, pose.data_ptr(),
+                  v_template.data_ptr(), blend_dirs.data_ptr(), Jt.data_ptr(), Js.data_ptr(), _parents_i32(parents, dev).data_ptr(),
+                  lbs_weights.data_ptr(), coeff.data_ptr(), A.data_ptr(), posed.data_ptr(), v_posed.data_ptr(), verts.data_ptr(), stream)
+        return verts, posed
     v_shaped = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
     _lib.call("g4d_lbs_shape_f32", B, V, NB, betas.data_ptr(), NB if betas.shape[0] == B else 0, v_template.data_ptr(),
               shapedirs.data_ptr(), v_shaped.data_ptr(), stream)
     joints = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
     _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor.data_ptr(), 0, v_shaped.data_ptr(), joints.data_ptr(), stream)
-    PF = (J - 1) * 9
-    assert posedirs.shape[0] == PF and posedirs.shape[1] == V * 3, "posedirs must be ((J-1)*9, V*3)"
-    posed = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
-    A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=dev)
     pf = torch.empty((B, PF), dtype=torch.float32, device=dev)
     _lib.call("g4d_rigid_transform_f32", B, J, int(bool(pose2rot)), pose.data_ptr(), joints.data_ptr(),
               _parents_i32(parents, dev).data_ptr(), 0, posed.data_ptr(), A.data_ptr(), pf.data_ptr(), stream)
-    verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
-    v_posed = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
     _lib.call("g4d_lbs_pose_skin_f32", B, V, J, PF, v_shaped.data_ptr(), pf.data_ptr(), posedirs.data_ptr(),
               lbs_weights.data_ptr(), 0, A.data_ptr(), v_posed.data_ptr(), verts.data_ptr(), stream)
     return verts, posed

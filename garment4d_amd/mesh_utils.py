@@ -62,19 +62,21 @@ _csr_cache = {}
 
 
 def _vf_csr(vertex_index, face_index, nv):
-    key = (vertex_index.data_ptr(), face_index.data_ptr(), vertex_index._version, face_index._version, nv, str(vertex_index.device))
+    key = (id(vertex_index), id(face_index), vertex_index._version, face_index._version, nv)
     hit = _csr_cache.get(key)
+    if hit is not None and not (hit[2] is vertex_index and hit[3] is face_index):
+        hit = None
     if hit is None:
         vi = vertex_index.long()
         order = torch.argsort(vi, stable=True)  # scatter-sum is order-free up to rounding; CSR needs rows together
         counts = torch.bincount(vi, minlength=nv)
         rowptr = torch.zeros(nv + 1, dtype=torch.int32, device=vi.device)
         rowptr[1:] = torch.cumsum(counts, 0).int()
-        hit = (rowptr.contiguous(), face_index.long()[order].int().contiguous())
+        hit = (rowptr.contiguous(), face_index.long()[order].int().contiguous(), vertex_index, face_index)  # sources pinned: ids stay unique
         if len(_csr_cache) > 16:
             _csr_cache.clear()
         _csr_cache[key] = hit
-    return hit
+    return hit[0], hit[1]
 
 
 def compute_vnorms(verts, tri_fs, vertex_index, face_index):

@@ -246,6 +246,16 @@ int g4d_lbs_pose_skin_f32(int b, int v, int j, int pf, const float *v_in, const 
                           const float *posedirs, const float *weights, int weights_batched, const float *A,
                           float *v_posed_scratch, float *verts, g4d_stream_t stream);
 
+/* The whole lbs() (smplx/smplx/lbs.py:152-248) in three launches.  Model constants prepared once by the caller:
+ * blend_dirs ((NB + (J-1)*9), V*3) = [shapedirs^T ; posedirs], J_template (J,3) = J_regressor v_template, J_shapedirs (J,3,NB) =
+ * J_regressor shapedirs.  J_regressor (v_template + shapedirs beta) = J_template + J_shapedirs beta, so the joints need no
+ * V-long reduction and v_shaped is never materialised.  coeff_scratch (B, NB + (J-1)*9); A_out (B,J,4,4); posed_joints (B,J,3) or
+ * NULL; v_posed_scratch, verts (B,V,3).  pose: (B,J,3) axis-angle (pose2rot != 0) or (B,J,3,3). */
+int g4d_lbs_fused_f32(int b, int v, int j, int nb, int pose2rot, const float *betas, int betas_bstride, const float *pose,
+                      const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
+                      const int *parents, const float *lbs_weights, float *coeff_scratch, float *A_out, float *posed_joints,
+                      float *v_posed_scratch, float *verts, g4d_stream_t stream);
+
 /* ---- callers around the hot path ---------------------------------------------- */
 
 /* K nearest neighbours, K <= 256: for every query (B,P1,3) the K points of (B,P2,3) that are smallest under

@@ -135,3 +135,20 @@ def test_gcn_fused_csr_linear_entry_point():
     _lib.call("g4d_gcn_linear_f32", 2, Vg, 40, xd.data_ptr(), 40, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), L.Kpad, L.Cout,
               L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), 0, out.data_ptr(), 24, 0, _lib.stream_ptr())
     np.testing.assert_allclose(host(out), want, **TOL)
+
+
+@pytest.mark.parametrize("fused_path", [True, False])
+def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, monkeypatch):
+    """Both lbs() routes -- the three-launch one (joints from betas via J_regressor's linearity, shape blend folded into the pose
+    blend) and the five-step one that follows lbs.py line by line -- against the reference's outputs at full SMPL size."""
+    monkeypatch.setattr(L, "USE_FUSED_LBS", fused_path)
+    g = golden_lbs
+    P = syn.smpl_like_params(V=6890, J=24, num_betas=10, seed=40)
+    betas, pose = syn.smpl_like_pose(2, seed=41)
+    args = [dev(P[k]) for k in ("v_template", "shapedirs", "posedirs", "J_regressor")] + [torch.from_numpy(P["parents"]), dev(P["lbs_weights"])]
+    v, j = L.lbs(dev(betas), dev(pose), *args, pose2rot=True)
+    np.testing.assert_allclose(host(v), g["full_verts"], **TOL)
+    np.testing.assert_allclose(host(j), g["full_joints"], **TOL)
+    v1, j1 = L.lbs(dev(betas[:1]), dev(pose), *args, pose2rot=True)      # one betas row broadcast over the batch
+    v2, j2 = L.lbs(dev(np.repeat(betas[:1], 2, 0)), dev(pose), *args, pose2rot=True)
+    assert torch.equal(v1, v2) and torch.equal(j1, j2)
