@@ -22,6 +22,7 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 loader = sys.argv[5] if len(sys.argv) > 5 else "gpu"
 prec = sys.argv[6] if len(sys.argv) > 6 else "fp32"
+use_graph = len(sys.argv) > 7 and sys.argv[7] == "graph"   # replay the whole forward as one captured hipGraph
 
 
 def dev(a):
@@ -64,13 +65,27 @@ with torch.no_grad():
     for _ in range(2):
         out = m(x, bm, make_batch(), precision=prec)
     torch.cuda.synchronize()
+    if use_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out = m(x, bm, make_batch(), precision=prec)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(x, bm, make_batch(), precision=prec)
+        g.replay()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        out = m(x, bm, make_batch(), precision=prec)
+        if use_graph:
+            g.replay()
+        else:
+            out = m(x, bm, make_batch(), precision=prec)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
 offs = [float((b - a).norm(dim=-1).mean()) for a, b in zip([out["lbs_pred_garment_v"].reshape(-1, out["lbs_pred_garment_v"].shape[-2], 3)] + out["iter_regressed_lbs_garment_v"][:-1],
                                                            out["iter_regressed_lbs_garment_v"])]
 print("mean per-round vertex offset (m):", [round(o, 4) for o in offs])
-print(f"precision={prec} loader={loader} nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
+print(f"graph={use_graph} precision={prec} loader={loader} nbatch={nbatch} T={T} N={N} V={body['v_template'].shape[0]} Vg={scene['template'][0].shape[0]}: {dt*1e3:.2f} ms / forward, "
       f"{nbatch*T/dt:.1f} frames/s; finite={bool(torch.isfinite(out['iter_regressed_lbs_garment_v'][-1]).all())}")
