@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) att_scores_partial_kernel(int T, int vg, 
     const int lane = threadIdx.x & 63, fi = lane & 15, fq = lane >> 4;
     const int slice = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int c = blockIdx.y;
-    if (slice >= slices) return;
+    const bool active = slice < slices;   // inactive waves keep zero tiles and still join the reduction
     const long long total_ksteps = (long long)vg * C / 16;
     const long long s0 = (long long)slice * kAttKsteps;
     const int t0 = min(fi, T - 1), t1 = min(16 + fi, T - 1);
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) att_scores_partial_kernel(int T, int vg, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int s = 0; s < kAttKsteps; ++s) {
+    for (int s = 0; s < kAttKsteps && active; ++s) {
         const long long ks = s0 + s;
         if (ks >= total_ksteps) break;
         const long long d = ks * 16;
@@ -53,13 +53,18 @@ __global__ void __launch_bounds__(256) att_scores_partial_kernel(int T, int vg, 
             acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
         }
     }
-    float *p = partial + ((size_t)c * slices + slice) * (kAttMaxT * kAttMaxT);
+    // the 4 waves of the workgroup meet in LDS: one partial tile per WORKGROUP (4x fewer to reduce in the softmax kernel)
+    __shared__ float red[4][kAttMaxT * kAttMaxT];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[(rt * 16 + fq * 4 + r) * kAttMaxT + ct * 16 + fi] = acc[rt][ct][r];
+            for (int r = 0; r < 4; ++r) red[wave][(rt * 16 + fq * 4 + r) * kAttMaxT + ct * 16 + fi] = acc[rt][ct][r];
+    __syncthreads();
+    float *p = partial + ((size_t)c * gridDim.x + blockIdx.x) * (kAttMaxT * kAttMaxT);
+    for (int i = threadIdx.x; i < kAttMaxT * kAttMaxT; i += 256) p[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
 }
 
 __global__ void __launch_bounds__(1024) att_scores_softmax_kernel(int T, int slices, const float *__restrict__ partial, float *__restrict__ att) {
@@ -67,8 +72,16 @@ __global__ void __launch_bounds__(1024) att_scores_softmax_kernel(int T, int sli
     const int t = threadIdx.x >> 5, u = threadIdx.x & 31;
     const int c = blockIdx.x;
     const float *p = partial + (size_t)c * slices * (kAttMaxT * kAttMaxT) + threadIdx.x;
-    float s = 0.f;
-    for (int w = 0; w < slices; ++w) s += p[(size_t)w * (kAttMaxT * kAttMaxT)];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains: the loads of 4 partials are in flight together
+    int w = 0;
+    for (; w + 3 < slices; w += 4) {
+        s0 += p[(size_t)w * (kAttMaxT * kAttMaxT)];
+        s1 += p[(size_t)(w + 1) * (kAttMaxT * kAttMaxT)];
+        s2 += p[(size_t)(w + 2) * (kAttMaxT * kAttMaxT)];
+        s3 += p[(size_t)(w + 3) * (kAttMaxT * kAttMaxT)];
+    }
+    for (; w < slices; ++w) s0 += p[(size_t)w * (kAttMaxT * kAttMaxT)];
+    const float s = (s0 + s1) + (s2 + s3);
     sc[t][u] = s / (float)sqrt((double)T);  // qk / np.sqrt(T)
     __syncthreads();
     if (t < T && u < T) {
@@ -121,7 +134,7 @@ extern "C" int g4d_temporal_attention_f32(int nclips, int t, int vg, int c, cons
     const long long ksteps = (long long)vg * c / 16;
     const int slices = (int)((ksteps + kAttKsteps - 1) / kAttKsteps);
     hipLaunchKernelGGL(att_scores_partial_kernel, dim3((slices + 3) / 4, nclips), dim3(256), 0, st, t, vg, c, qkv, scratch, slices);
-    hipLaunchKernelGGL(att_scores_softmax_kernel, dim3(nclips), dim3(1024), 0, st, t, slices, scratch, att);
+    hipLaunchKernelGGL(att_scores_softmax_kernel, dim3(nclips), dim3(1024), 0, st, t, (slices + 3) / 4, scratch, att);
     hipLaunchKernelGGL(att_mix_kernel, dim3((unsigned)(((long long)vg * c + 255) / 256), nclips), dim3(256), 0, st, t, vg, c, qkv, att, out, ldo,
                        col0);
     return check_launch("g4d_temporal_attention_f32");
