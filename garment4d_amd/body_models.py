@@ -136,7 +136,8 @@ class SMPL(nn.Module):
         self.register_buffer("v_template", v_template.float() if torch.is_tensor(v_template) else torch.from_numpy(to_np(v_template)))
         self.register_buffer("J_regressor", torch.from_numpy(to_np(data_struct.J_regressor)))
         num_pose_basis = data_struct.posedirs.shape[-1]
-        self.register_buffer("posedirs", torch.from_numpy(to_np(np.reshape(to_np(data_struct.posedirs), [-1, num_pose_basis]).T)))
+        # (.T of a numpy array is a strided view: make it contiguous HERE, or every lbs() call would copy 17 MB and miss its cache)
+        self.register_buffer("posedirs", torch.from_numpy(np.ascontiguousarray(to_np(np.reshape(to_np(data_struct.posedirs), [-1, num_pose_basis]).T))))
         parents = torch.from_numpy(to_np(data_struct.kintree_table[0], dtype=np.int64)).long()
         parents[0] = -1
         self.register_buffer("parents", parents)
