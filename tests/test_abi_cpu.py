@@ -75,3 +75,35 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
                 assert "g4d_oracle" not in src, f"{f} references the oracle library"
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point validates its arguments before touching the device and reports through the status code +
+    g4d_last_error() (the reference prints to stderr and calls exit(-1)): checked here without a GPU."""
+    from garment4d_amd import _lib
+    L = _lib.lib()
+    EINVAL = 10001
+    bad = [
+        ("g4d_fps_f32", (-1, 8, 4, 0, 0, 0, 0), "negative"),
+        ("g4d_ball_query_f32", (1, 8, 4, 0.1, 4, 0, 0, 0, 0), "null"),
+        ("g4d_knn_f32", (1, 4, 100, 300, 1, 1, 1, 1, 0), "K <= 256"),
+        ("g4d_knn_f32", (1, 4, 3, 8, 1, 1, 1, 1, 0), "K (8) > number of points (3)"),
+        ("g4d_pos_encode_f32", (1, 8, 4, 5, 0, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 64, 0, 0), "nsample must be"),
+        ("g4d_temporal_attention_f32", (1, 33, 8, 16, 1, 1, 1, 1, 16, 0, 0), "T <= 32"),
+        ("g4d_temporal_attention_f32", (1, 4, 8, 20, 1, 1, 1, 1, 20, 0, 0), "C % 16"),
+        ("g4d_knn_blend_weights_f32", (1, 1, 4, 8, 300, 24, 1, 1, 1, 1, 0), "K <= 256"),
+        ("g4d_lbs_fused_f32", (1, 8, 65, 10, 1, 1, 10, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 0), "J <= 64"),
+    ]
+    for name, args, needle in bad:
+        rc = getattr(L, name)(*args)
+        assert rc == EINVAL, (name, rc)
+        msg = L.g4d_last_error().decode()
+        assert name.split("_f32")[0] in msg and needle.lower() in msg.lower(), (name, msg)
+    # unsupported widths for the register-chain kernel are reported, not mis-launched
+    import ctypes
+    cout = (ctypes.c_int * 2)(48, 48)
+    assert L.g4d_mlp_chain_supported(2, ctypes.cast(cout, ctypes.c_void_p)) == 0
+    cout = (ctypes.c_int * 3)(128, 128, 256)
+    assert L.g4d_mlp_chain_supported(3, ctypes.cast(cout, ctypes.c_void_p)) == 1
+    # empty problems are fine everywhere (the reference's kernels are simply not launched)
+    assert L.g4d_fps_f32(0, 8, 4, 0, 0, 0, 0) == 0 and L.g4d_knn_f32(0, 4, 8, 3, 0, 0, 0, 0, 0) == 0
