@@ -111,9 +111,9 @@ def kernel_rooflines(model, cloud):
     fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024)
     res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8)", "bound": "hbm", "achieved": fps_bytes / t / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS,
-                  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch: 545.1 KB + 154.4 KB
-                  # (profiles/r01_pmc_hbm_traffic.csv; calibration factor 1.02 measured on linear_kernel in the same run)
-                  "traffic": (545.1 + 154.4) * 1024, "traffic_unit": "bytes/launch", "algorithmic_bytes": fps_bytes,
+                  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch: 483.0 KB + 32.0 KB (profiles/r01_pmc_hbm_traffic.csv);
+                  # below the algorithmic bytes because part of the cloud is still in L2 / MALL from the previous step
+                  "traffic": (483.0 + 32.0) * 1024, "traffic_unit": "bytes/launch", "algorithmic_bytes": fps_bytes,
                   "avg_launch_us": t * 1e6, "rounds_per_s_per_cloud": 1023 / t,
                   "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
                           "neither HBM nor MFMA limits it -- see DESIGN.md section 5"}
@@ -133,7 +133,10 @@ def kernel_rooflines(model, cloud):
     flops = 2.0 * rows * sum(L.K * L.Cout for L in layers)
     res["mlp"] = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", "bound": "mfma",
                   "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_us": t * 1e6}
+                  "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                  # PMC per launch: 6434.9 KB fetched + 512.0 KB written (profiles/r01_pmc_hbm_traffic.csv) against 2.0 MB algorithmic
+                  # (indices + gathered features + weights): the weights are fetched once per XCD
+                  "traffic": (6434.9 + 512.0) * 1024, "traffic_unit": "bytes/launch", "avg_launch_us": t * 1e6}
     return res
 
 
