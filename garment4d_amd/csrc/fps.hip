@@ -238,11 +238,8 @@ template <int W, int U, int Q>
 static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
     const size_t lds = 2 * 16 * 16 + (size_t)n * 12;
     auto kern = fps_reg_kernel<W, U, Q>;
-    static bool attr_done = false;  // benign race: idempotent
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;  // one bit per device
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32")) return rc;
     hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
     return check_launch("g4d_fps_f32");
 }

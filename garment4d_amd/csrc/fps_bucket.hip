@@ -295,11 +295,8 @@ static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *x
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
     const size_t lds = 1024 + body;
     auto kern = fps_bucket_kernel<W, P>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;  // one bit per device
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32(bucketed)")) return rc;
     hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
     return check_launch("g4d_fps_f32(bucketed)");
 }

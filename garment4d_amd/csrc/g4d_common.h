@@ -30,6 +30,22 @@ inline int check_launch(const char *what) {
 
 constexpr int kWave = 64;
 
+// Raise a kernel's dynamic-LDS limit above the 64 KB default.  The attribute is PER DEVICE: `done` holds one bit per device
+// ordinal so that a process driving several GPUs sets it on each of them (idempotent, so a race between host threads is benign).
+inline int ensure_dynamic_lds(const void *kernel, int bytes, unsigned long long &done, const char *what) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (__atomic_load_n(&done, __ATOMIC_RELAXED) & bit)) return G4D_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+        return (int)e;
+    }
+    if (dev < 64) __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+    return G4D_OK;
+}
+
 // ---- wave-level primitives (DPP, no LDS) ------------------------------------------------------
 // dpp_ctrl encodings: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
 template <int CTRL, int ROW_MASK>

@@ -152,11 +152,8 @@ extern "C" int g4d_knn_f32(int b, int p1, int p2, int k, const float *queries, c
     G4D_REQUIRE(queries && points && dists && idx, "g4d_knn_f32: null pointer");
     G4D_REQUIRE(b <= 65535 && p2 <= 32768, "g4d_knn_f32: b <= 65535, p2 <= 32768 (LDS-resident distance keys)");
     const size_t lds = sizeof(unsigned) * (((size_t)p2 + 3) / 4 * 4 + 256 + 8) + sizeof(unsigned long long) * kKnnMaxK;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr = true;
-    }
+    static unsigned long long attr = 0;  // one bit per device
+    if (const int rc = g4d::ensure_dynamic_lds(reinterpret_cast<const void *>(knn_kernel), 150 * 1024, attr, "g4d_knn_f32")) return rc;
     hipLaunchKernelGGL(knn_kernel, dim3(p1, b), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p1, p2, k, queries, points, dists,
                        idx);
     return check_launch("g4d_knn_f32");

@@ -284,14 +284,11 @@ extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
     dim3 grid((unsigned)((rows + rows_per_wg - 1) / rows_per_wg)), block(512);
 #define G4D_LAUNCH_STACK(M)                                                                                        \
     {                                                                                                              \
-        static bool attr = false;                                                                                  \
-        if (!attr) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_kernel<M, 2>),                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_kernel<M, 1>),                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
-            attr = true;                                                                                           \
-        }                                                                                                          \
+        static unsigned long long attr2 = 0, attr1 = 0; /* one bit per device */                                   \
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_stack_kernel<M, 2>), 150 * 1024, attr2,   \
+                                              "g4d_mlp_stack_f32")) return rc;                                     \
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_stack_kernel<M, 1>), 150 * 1024, attr1,   \
+                                              "g4d_mlp_stack_f32")) return rc;                                     \
         if (mt == 2) hipLaunchKernelGGL((mlp_stack_kernel<M, 2>), grid, block, lds, st, s);                        \
         else hipLaunchKernelGGL((mlp_stack_kernel<M, 1>), grid, block, lds, st, s);                                \
     }

@@ -263,12 +263,9 @@ extern "C" int g4d_mlp_stack_bf16(int mode, long long rows, int K0,
     dim3 grid((unsigned)((rows + 63) / 64)), block(512);
 #define G4D_LAUNCH_STACKH(M)                                                                                        \
     {                                                                                                              \
-        static bool attr = false;                                                                                  \
-        if (!attr) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_stack_bf16_kernel<M>),                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
-            attr = true;                                                                                           \
-        }                                                                                                          \
+        static unsigned long long attr = 0; /* one bit per device */                                               \
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(mlp_stack_bf16_kernel<M>), 150 * 1024, attr,  \
+                                              "g4d_mlp_stack_bf16")) return rc;                                    \
         hipLaunchKernelGGL(mlp_stack_bf16_kernel<M>, grid, block, lds, st, s);                                          \
     }
     switch (mode) {

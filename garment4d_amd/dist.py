@@ -32,60 +32,117 @@ def shard_frames(x: torch.Tensor, rank: int = None, world: int = None) -> torch.
     return x[b:e]
 
 
+WORLD = "world"   # pass as `group` to shard over the default process group
+
+
+def resolve_group(group):
+    """Which process group, if any, a sharded helper exchanges over.  Collectives run ONLY on an explicit request:
+    None / False -> no exchange (the caller holds whole clips), WORLD -> the default group, a ProcessGroup -> itself.
+    A process group that merely happens to be initialised (clip-sharded bench ranks) never triggers a collective."""
+    if group is None or group is False or not dist.is_initialized():
+        return None
+    pg = dist.group.WORLD if isinstance(group, str) else group
+    return pg if dist.get_world_size(pg) > 1 else None
+
+
 def _stage(t: torch.Tensor, group=None) -> torch.Tensor:
     """gloo has no device collectives: with that backend (CPU tests, or a 1-GPU box shared by two test ranks) CUDA tensors are
     staged through the host.  With nccl (= RCCL) tensors stay on the device."""
     return t.cpu() if (t.is_cuda and dist.get_backend(group) == "gloo") else t
 
 
-def allgather_frames(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """Inverse of shard_frames: every rank gets the (n_total, ...) tensor.  Ragged blocks (n_total % world != 0) are
-    padded to the largest block for the collective and trimmed afterwards."""
-    world = dist.get_world_size(group)
-    if world == 1:
-        return local
+class GatherHandle:
+    """An all-gather in flight.  RCCL runs it on the process group's own stream (ordered after the work already queued on
+    the caller's stream), so kernels launched between `allgather_frames_async` and `wait()` overlap the transfer; `wait()`
+    orders the caller's stream behind the collective and returns the (n_total, ...) tensor."""
+
+    def __init__(self, out, works=(), finish=None):
+        self._out, self._works, self._finish = out, list(works), finish
+
+    def wait(self) -> torch.Tensor:
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._finish is not None:
+            self._out, self._finish = self._finish(self._out), None
+        return self._out
+
+
+def allgather_frames_async(local: torch.Tensor, n_total: int, group=WORLD) -> GatherHandle:
+    """Inverse of shard_frames, asynchronous: every rank gets the (n_total, ...) tensor from `handle.wait()`.
+    RCCL: the blocks land directly in their place of ONE output tensor -- `all_gather_into_tensor` when every rank holds the
+    same number of frames, otherwise a list all-gather on exact, un-padded views of it (no pad, no torch.cat).
+    gloo (CPU tests) needs equal sizes: ragged blocks are padded for the collective and trimmed afterwards."""
+    pg = resolve_group(group)
+    if pg is None:
+        return GatherHandle(local)
+    world = dist.get_world_size(pg)
     sizes = [shard_range(n_total, r, world) for r in range(world)]
+    assert local.shape[0] == sizes[dist.get_rank(pg)][1] - sizes[dist.get_rank(pg)][0], "local block does not match shard_range"
+    even = all(e - b == sizes[0][1] - sizes[0][0] for b, e in sizes)
+    tail = tuple(local.shape[1:])
+    if dist.get_backend(pg) != "gloo":
+        src = local.contiguous()
+        out = src.new_empty((n_total,) + tail)
+        if even:
+            w = dist.all_gather_into_tensor(out, src, group=pg, async_op=True)
+        else:
+            w = dist.all_gather([out[b:e] for b, e in sizes], src, group=pg, async_op=True)
+        return GatherHandle(out, [w])
     mx = max(e - b for b, e in sizes)
     pad = local
     if local.shape[0] < mx:
-        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
-    src = _stage(pad.contiguous(), group)
-    out = src.new_empty((world * mx,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, src, group=group)
-    out = out.to(local.device)
-    if all(e - b == mx for b, e in sizes):
-        return out
-    return torch.cat([out[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], dim=0)
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tail)], dim=0)
+    src = _stage(pad.contiguous(), pg)
+    out = src.new_empty((world * mx,) + tail)
+    w = dist.all_gather_into_tensor(out, src, group=pg, async_op=True)
+    dev = local.device
+
+    def finish(o):
+        o = o.to(dev)
+        return o if even else torch.cat([o[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], dim=0)
+
+    return GatherHandle(out, [w], finish)
+
+
+def allgather_frames(local: torch.Tensor, n_total: int, group=WORLD) -> torch.Tensor:
+    """Blocking form of `allgather_frames_async`."""
+    return allgather_frames_async(local, n_total, group).wait()
 
 
 def clip_max_over_frames(frame_feats_local: torch.Tensor, frame_ids_local: torch.Tensor, n_clips: int, T: int,
                          group=None) -> torch.Tensor:
-    """max over the T frames of each clip when a clip's frames live on several ranks.
+    """max over the T frames of each clip; when a clip's frames live on several ranks (`group` given, see resolve_group) the
+    per-rank partial maxima are combined by all_reduce(MAX).
     frame_feats_local (f_local, C); frame_ids_local (f_local,) global frame ids (clip = id // T) -> (n_clips, C)."""
     C = frame_feats_local.shape[1]
     out = frame_feats_local.new_full((n_clips, C), float("-inf"))
     clip = (frame_ids_local // T).long()
     out.scatter_reduce_(0, clip[:, None].expand(-1, C), frame_feats_local, reduce="amax", include_self=True)
-    if dist.is_initialized() and group is not False and dist.get_world_size(group) > 1:
-        red = _stage(out, group)
-        dist.all_reduce(red, op=dist.ReduceOp.MAX, group=group)
+    pg = resolve_group(group)
+    if pg is not None:
+        red = _stage(out, pg)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX, group=pg)
         out = red.to(out.device)
     return out
 
 
 def temporal_attention(last_feat_local: torch.Tensor, frame_ids_local: torch.Tensor, n_frames: int, T: int, qkv,
-                       group=None, out=None, col0: int = 0, clip_range=None) -> torch.Tensor:
+                       group=None, out=None, col0: int = 0, clip_range=None, gathered: "GatherHandle" = None) -> torch.Tensor:
     """The reference's temporal attention (mesh_encoder.py:467-476) for frame-sharded features: k, v of ALL T frames
-    of a clip are needed, so the per-frame features are all-gathered once (RCCL all-gather; skipped with group=False or
-    without an initialised process group), q/k/v are computed locally, and each rank keeps the rows of its own frames.
+    of a clip are needed, so the per-frame features are all-gathered once (RCCL all-gather; only when `group` names a process
+    group, see resolve_group), q/k/v are computed locally, and each rank keeps the rows of its own frames.
     last_feat_local (f_local, Vg, C); qkv: the per-vertex Linear(C -> 3C) (`temporal_qkv_*`, bias-free), any callable
     mapping (..., C) -> (..., 3C).  On the GPU the two skinny contractions run on the HIP kernels of csrc/attention.hip
     (T <= 32, C % 16 == 0); on CPU tensors (the gloo tests) with torch.matmul.
     out/col0: optional (f_local, Vg, >= col0 + C) buffer to write the result into.
     clip_range = (first, last) clip touched by the local frames (host ints): when sharded, q/k/v and the attention are
     evaluated for those clips only instead of for every clip of the batch on every rank."""
-    sharded = dist.is_initialized() and group is not False and dist.get_world_size(group) > 1
-    feats = allgather_frames(last_feat_local, n_frames, group) if sharded else last_feat_local
+    sharded = resolve_group(group) is not None
+    if sharded:  # `gathered`: the caller started the all-gather earlier so that it overlaps independent work (SURVEY.md 8e)
+        feats = gathered.wait() if gathered is not None else allgather_frames(last_feat_local, n_frames, group)
+    else:
+        feats = last_feat_local
     if sharded and clip_range is not None:
         c0, c1 = int(clip_range[0]), int(clip_range[1])
         feats = feats[c0 * T:(c1 + 1) * T]

@@ -110,6 +110,23 @@ def pack_conv_stack(stack):
     return layers
 
 
+_CACHE_ATTRS = ("_g4d_packed", "_g4d_split", "_g4d_pe", "_g4d_table")
+
+
+def invalidate(module):
+    """Drop every packed-weight cache below `module`.  The caches are keyed on (data_ptr, tensor._version); an in-place
+    update THROUGH `.data` (p.data.copy_, p.data.mul_, EMA swaps, GraphConvolution.reset_parameters) does not bump the
+    version counter, so after such an update call this once -- `load_state_dict` / optimiser steps / plain in-place ops
+    bump the counter and need nothing."""
+    n = 0
+    for m in module.modules():
+        for a in _CACHE_ATTRS:
+            if hasattr(m, a):
+                delattr(m, a)
+                n += 1
+    return n
+
+
 def to_point_major(x):
     """(B, C, N) -> (B, N, C) on the HIP transpose kernel."""
     _chk(x)

@@ -109,7 +109,7 @@ class GraphConvolution(torch.nn.Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def _packed(self):
-        key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else self.bias._version)
+        key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
         hit = getattr(self, "_g4d_packed", None)
         if hit is None or hit[0] != key:
             with torch.no_grad():

@@ -58,6 +58,11 @@ def _model_constants(v_template, shapedirs, posedirs, J_regressor):
     return hit[:3]
 
 
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
 def blend_shapes(betas, shape_disps):
     """betas (B,NB), shape_disps (V,3,NB) -> per-vertex displacement (B,V,3)."""
     betas, shape_disps = _f32(betas, "betas"), _f32(shape_disps, "shape_disps")
@@ -75,6 +80,8 @@ def vertices2joints(J_regressor, vertices):
     J_regressor, vertices = _f32(J_regressor, "J_regressor"), _f32(vertices, "vertices")
     B, V, _ = vertices.shape
     J = J_regressor.shape[0]
+    _require(J_regressor.dim() == 2 and J_regressor.shape[1] == V and vertices.shape[2] == 3,
+             f"vertices2joints: J_regressor {tuple(J_regressor.shape)} does not match vertices {tuple(vertices.shape)}")
     out = torch.empty((B, J, 3), dtype=torch.float32, device=vertices.device)
     _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor.data_ptr(), 0, vertices.data_ptr(), out.data_ptr(), _lib.stream_ptr())
     return out
@@ -86,7 +93,9 @@ def vertices2jointsB(J_regressor_B, vertices, group=1):
     J_regressor_B, vertices = _f32(J_regressor_B, "J_regressor_B"), _f32(vertices, "vertices")
     B, V, _ = vertices.shape
     J = J_regressor_B.shape[1]
-    assert J_regressor_B.shape[0] * group == B
+    _require(J_regressor_B.dim() == 3 and J_regressor_B.shape[2] == V and vertices.shape[2] == 3,
+             f"vertices2jointsB: regressor {tuple(J_regressor_B.shape)} does not match vertices {tuple(vertices.shape)}")
+    _require(J_regressor_B.shape[0] * group == B, "vertices2jointsB: regressor batch x group must equal the vertex batch")
     out = torch.empty((B, J, 3), dtype=torch.float32, device=vertices.device)
     _lib.call("g4d_joint_regress_f32", B, J, V, J_regressor_B.data_ptr(), int(group), vertices.data_ptr(), out.data_ptr(), _lib.stream_ptr())
     return out
@@ -120,9 +129,11 @@ def skin(weights, A, verts, group=1):
     weights, A, verts = _f32(weights, "weights"), _f32(A, "A"), _f32(verts, "verts")
     B, V, _ = verts.shape
     J = A.shape[1]
+    _require(verts.shape[2] == 3 and tuple(A.shape) == (B, J, 4, 4), f"skin: A {tuple(A.shape)} does not match verts {tuple(verts.shape)}")
+    _require(tuple(weights.shape[-2:]) == (V, J), f"skin: weights {tuple(weights.shape)} must end in (V={V}, J={J})")
     out = torch.empty_like(verts)
     if weights.dim() == 3:
-        assert weights.shape[0] * group == B
+        _require(weights.shape[0] * group == B, "skin: weights batch x group must equal the vertex batch")
     _lib.call("g4d_lbs_pose_skin_f32", B, V, J, 0, verts.data_ptr(), 0, 0, weights.data_ptr(), int(group) if weights.dim() == 3 else 0,
               A.data_ptr(), 0, out.data_ptr(), _lib.stream_ptr())
     return out
@@ -148,7 +159,15 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     dev = betas.device
     stream = _lib.stream_ptr()
     PF = (J - 1) * 9
-    assert posedirs.shape[0] == PF and posedirs.shape[1] == V * 3, "posedirs must be ((J-1)*9, V*3)"
+    # the C ABI reads raw pointers: every extent it will touch is checked here (the reference raises a shape error from torch)
+    _require(pose.numel() == B * J * (3 if pose2rot else 9),
+             f"lbs: pose has {pose.numel()} elements, expected B*J*{3 if pose2rot else 9} = {B * J * (3 if pose2rot else 9)} "
+             f"(B={B}, J={J}, pose2rot={bool(pose2rot)}); pass the full pose incl. global_orient")
+    _require(posedirs.dim() == 2 and posedirs.shape[0] == PF and posedirs.shape[1] == V * 3, "lbs: posedirs must be ((J-1)*9, V*3)")
+    _require(tuple(shapedirs.shape) == (V, 3, NB), f"lbs: shapedirs {tuple(shapedirs.shape)} must be (V={V}, 3, NB={NB})")
+    _require(tuple(J_regressor.shape) == (J, V), f"lbs: J_regressor {tuple(J_regressor.shape)} must be (J, V={V})")
+    _require(tuple(lbs_weights.shape) == (V, J), f"lbs: lbs_weights {tuple(lbs_weights.shape)} must be (V={V}, J={J})")
+    _require(len(parents) == J, f"lbs: parents has {len(parents)} entries, expected J={J}")
     posed = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
     A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=dev)
     verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)

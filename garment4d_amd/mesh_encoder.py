@@ -183,7 +183,7 @@ class PCALBSGarmentUseSegEncoderSeg(GarmentRefinementHead):
         import scipy.sparse as sp
         nbatch, T = x.size(0), x.size(1)
         dev = x.device
-        out = self.PCA_garment_encoder(x, body_model)
+        out = self.PCA_garment_encoder(x, body_model, group=False)    # whole clips on this rank: no exchange, whatever is initialised
         if getattr(self, "_lap_adj", None) is None or self._lap_adj.device != dev:     # constant of the mesh: built once
             lap_adj = sp.eye(self.adj_old.shape[0]) - gcn.normalize(self.adj_old)
             self._lap_adj = gcn.sparse_mx_to_torch_sparse_tensor(lap_adj).to(dev)
@@ -204,7 +204,7 @@ class PCALBSGarmentUseSegEncoderSeg(GarmentRefinementHead):
             self, cur, body_v, body_vn, out["garment_v_list"], out["_garment_f_list_pm"], self._adj_scipy, nbatch, T, group=False)
         return out
 
-    def forward_frames(self, x, body_model, batch, *, nbatch, T, frame_ids, group=None):
+    def forward_frames(self, x, body_model, batch, *, nbatch, T, frame_ids, group=gdist.WORLD):
         """Frame-sharded forward: this rank holds the frames `frame_ids` (ascending global ids, clip =
         id // T) of the nbatch x T frames.  x (F_local, N, 3); batch: per-FRAME tensors for the local frames only
         (`smpl_vertices_torch`, `zeropose_smpl_vertices_torch` (F_local,V,3), `pose_torch` (F_local,72), `T_J_regressor`

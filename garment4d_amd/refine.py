@@ -189,6 +189,7 @@ class GarmentRefinementHead(nn.Module):
         n_frames = nbatch * T
         cur = cur_garment_v.contiguous()
         outs, lbs_iter_feat = [], []
+        pending = None   # all-gather of the previous round's attention features, in flight (frame-sharded runs only)
         # per-source-point first-layer tables of the garment encoders: the garment levels do not change over the rounds
         tables = [feature_table(garm_pe[i], garment_f_list[i].contiguous()) if garment_f_list[i].shape[2] > self.feat_num else None
                   for i in range(3)]
@@ -208,11 +209,16 @@ class GarmentRefinementHead(nn.Module):
                 col += self.feat_num
             if it > 0:                                                               # :467-476
                 gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group, out=feat, col0=col,
-                                         clip_range=clip_range)
+                                         clip_range=clip_range, gathered=pending)
+                pending = None
             h = feat
             for i, m in enumerate(regress[it]):                                      # :477-481
                 h = m(h, adj, False, relu=(i != 3))
                 lbs_iter_feat.append(h)
+                if i == 2 and it + 1 < self.iteration and gdist.resolve_group(group) is not None:
+                    # the next round's attention needs this tensor from every rank: start the all-gather now, it overlaps the last
+                    # GCN layer and the next round's six ball queries + positional encoders, which do not depend on it
+                    pending = gdist.allgather_frames_async(h, n_frames, group)
             cur = (cur + h).contiguous()                                             # :482-483
             outs.append(cur)
         return outs

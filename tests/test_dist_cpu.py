@@ -31,18 +31,24 @@ def _worker(rank, world, port, n_frames, T, ret):
         assert torch.equal(local, full[b:e])
         back = gd.allgather_frames(local, n_frames)
         assert torch.equal(back, full)
-        mx = gd.clip_max_over_frames(frame_feat[b:e], ids[b:e], n_frames // T, T)
+        mx = gd.clip_max_over_frames(frame_feat[b:e], ids[b:e], n_frames // T, T, group=gd.WORLD)
+        # no group named -> no exchange, even though a process group is initialised (clip-sharded ranks must not mix their clips)
+        loc = gd.clip_max_over_frames(frame_feat[b:e], ids[b:e], n_frames // T, T)
+        part = torch.full((n_frames // T, 6), float('-inf'))
+        part.scatter_reduce_(0, (ids[b:e] // T)[:, None].expand(-1, 6), frame_feat[b:e], reduce='amax')
+        assert torch.equal(loc, part)
         assert torch.equal(mx, frame_feat.view(n_frames // T, T, 6).max(1)[0])
         qkv = torch.nn.Linear(4, 12, bias=False)  # per-vertex Linear(C, 3C) like temporal_qkv_*
         torch.manual_seed(1)
         for p in qkv.parameters():
             p.data.normal_()
         with torch.no_grad():
-            got = gd.temporal_attention(local, ids[b:e], n_frames, T, qkv)
+            got = gd.temporal_attention(local, ids[b:e], n_frames, T, qkv, group=gd.WORLD)
             q, k, v = [z.reshape(n_frames // T, T, 20) for z in qkv(full.reshape(n_frames // T, T, 5, 4)).chunk(3, -1)]
             want = (torch.softmax(q @ k.transpose(1, 2) / T ** 0.5, -1) @ v).reshape(n_frames, 5, 4)[b:e]
         assert torch.allclose(got, want, atol=1e-6)
-        got2 = gd.temporal_attention(local, ids[b:e], n_frames, T, qkv, clip_range=(b // T, (e - 1) // T))  # touched clips only
+        got2 = gd.temporal_attention(local, ids[b:e], n_frames, T, qkv, group=gd.WORLD, clip_range=(b // T, (e - 1) // T),
+                                      gathered=gd.allgather_frames_async(local, n_frames))  # pre-started gather  # touched clips only
         assert torch.allclose(got2, want, atol=1e-6)
         ret[rank] = True
     finally:

@@ -152,3 +152,35 @@ def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, monkeypatch
     v1, j1 = L.lbs(dev(betas[:1]), dev(pose), *args, pose2rot=True)      # one betas row broadcast over the batch
     v2, j2 = L.lbs(dev(np.repeat(betas[:1], 2, 0)), dev(pose), *args, pose2rot=True)
     assert torch.equal(v1, v2) and torch.equal(j1, j2)
+
+
+def test_lbs_rejects_mismatched_shapes_before_touching_the_device():
+    """the C ABI reads raw pointers, so every extent is validated in the host mirror -- a (B,69) body pose
+    without global_orient, rotation matrices passed with pose2rot=True, or tables of another body raise RuntimeError (the
+    reference raises a shape error from torch) instead of reading out of bounds."""
+    from garment4d_amd import lbs as L
+    from garment4d_amd import synthetic as syn
+    P = syn.smpl_like_params(V=200, J=24, num_betas=10, seed=1)
+    betas, pose = syn.smpl_like_pose(2, seed=2)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = lambda **kw: [d(kw.get("betas", betas)), d(kw.get("pose", pose)), d(kw.get("v_template", P["v_template"])),
+                         d(kw.get("shapedirs", P["shapedirs"])), d(kw.get("posedirs", P["posedirs"])),
+                         d(kw.get("J_regressor", P["J_regressor"])), torch.from_numpy(P["parents"]), d(kw.get("lbs_weights", P["lbs_weights"]))]
+    L.lbs(*args())                                                           # the well-formed call passes
+    with pytest.raises(RuntimeError, match="pose has"):
+        L.lbs(*args(pose=pose[:, 3:]))                                       # body_pose only: 69 instead of 72 values
+    rot = np.tile(np.eye(3, dtype=np.float32), (2, 24, 1, 1))
+    with pytest.raises(RuntimeError, match="pose has"):
+        L.lbs(*args(pose=rot), pose2rot=True)                                # rotation matrices misdeclared as axis-angle
+    L.lbs(*args(pose=rot), pose2rot=False)
+    with pytest.raises(RuntimeError, match="lbs_weights"):
+        L.lbs(*args(lbs_weights=P["lbs_weights"][:, :23]))
+    with pytest.raises(RuntimeError, match="J_regressor"):
+        L.lbs(*args(J_regressor=P["J_regressor"][:, :199]))
+    with pytest.raises(RuntimeError, match="shapedirs"):
+        L.lbs(*args(shapedirs=P["shapedirs"][:199]))
+    A = torch.zeros((2, 24, 4, 4), device="cuda")
+    with pytest.raises(RuntimeError, match="weights"):
+        L.skin(d(P["lbs_weights"][:, :23]), A, torch.zeros((2, 200, 3), device="cuda"))
+    with pytest.raises(RuntimeError, match="regressor"):
+        L.vertices2jointsB(torch.zeros((2, 24, 199), device="cuda"), torch.zeros((2, 200, 3), device="cuda"))

@@ -203,3 +203,49 @@ def test_forward_frames_two_ranks_equals_unsharded():
     want = ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy()
     err = np.abs(final - want).reshape(nbatch * T, -1).max(1)
     np.testing.assert_allclose(final, want, rtol=1e-4, atol=1e-5, err_msg=f"final; per-frame max err {err}")
+
+
+def _clip_rank_worker(rank, world, port, nbatch, T, N, ret):
+    """One rank of the CLIP-sharded forward: an initialised process group, whole clips per rank, forward() must not exchange."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        scene = syn.garment_scene(nbatch, T, N, seed=23)
+        m = _model(scene, "Tshirt", 16)
+        mine = slice(0, 1) if rank == 0 else slice(1, nbatch)          # different clip counts per rank: a hidden collective would hang
+        with torch.no_grad():
+            out = m(dev(scene["x"][mine]), _body_model(scene["body"]), {k: dev(v[mine]) for k, v in scene["batch"].items()})
+        ret[rank] = dict(coeff=out["garment_PCA_coeff"].cpu().numpy(), final=out["iter_regressed_lbs_garment_v"][-1].cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forward_clip_sharded_ranks_do_not_exchange():
+    """with a process group initialised (scripts/bench_model.py --shard clips) forward() used to all-reduce the
+    garment summaries of DIFFERENT clips.  Each rank runs forward() on its own clips; the union must equal the single-process run."""
+    import socket
+    import torch.multiprocessing as mp
+    nbatch, T, N = 3, 2, 2048
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_clip_rank_worker, args=(r, 2, port, nbatch, T, N, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    scene = syn.garment_scene(nbatch, T, N, seed=23)
+    m = _model(scene, "Tshirt", 16)
+    with torch.no_grad():
+        ref = m(dev(scene["x"]), _body_model(scene["body"]), {k: dev(v) for k, v in scene["batch"].items()})
+    coeff = np.concatenate([ret[0]["coeff"], ret[1]["coeff"]], 0)
+    final = np.concatenate([ret[0]["final"], ret[1]["final"]], 0)
+    np.testing.assert_allclose(coeff, ref["garment_PCA_coeff"].cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(final, ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy(), rtol=1e-4, atol=1e-5)

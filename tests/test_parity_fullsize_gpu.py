@@ -1,0 +1,120 @@
+"""Parity at the BENCHED sizes: the cfg2 / cfg3 encoder at N = 8192 against the oracle for every level,
+QueryAndGroup / GroupAll directly on the GPU against the reference-generated goldens, with elementwise gates and the error
+statistics printed per tensor."""
+import numpy as np
+import pytest
+import torch
+
+from garment4d_amd import pointnet2_utils as PU
+from garment4d_amd import synthetic as syn
+from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
+from oracle import modules_oracle as MO
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def stats(name, got, want):
+    """max-abs, max-rel (|err| / max(|want|, 1e-3 * scale)) and the share of elements outside rtol = atol = 1e-5."""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    scale = float(np.abs(want).max())
+    rel = err / np.maximum(np.abs(want), 1e-3 * max(scale, 1e-30))
+    bad = float((err > 1e-5 + 1e-5 * np.abs(want)).mean())
+    print(f"[parity] {name}: shape {want.shape} scale {scale:.3g} max_abs {err.max():.3g} max_rel {rel.max():.3g} "
+          f"outside_elementwise_1e-5 {bad:.3g}")
+    return err.max(), rel.max(), bad, scale
+
+
+def check(name, got, want, rtol=1e-5, atol=1e-5, scaled=False):
+    """Elementwise |got - want| <= atol + rtol |want|.  scaled=True: atol is relative to the tensor's max-abs (deep MLP stacks:
+    the MFMA contraction sums K in fragment order, numpy's einsum in BLAS order -- the rounding error of an element is
+    proportional to the magnitude of its partial sums, not to its own, possibly cancelled, value)."""
+    mx, _, _, scale = stats(name, got, want)
+    g = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    np.testing.assert_allclose(g, want, rtol=rtol, atol=atol * (max(scale, 1.0) if scaled else 1.0), err_msg=name)
+
+
+@pytest.mark.parametrize("kind", ["unit", "ties"])
+def test_cfg2_encoder_full_size_vs_oracle(kind):
+    """BASELINE config 2 at its real size: B x 8192 points through Pointnet2MSGSEG on the fused HIP path (the kernels and
+    instantiations bench.py times: bucketed FPS, MSG ball query, mlp_chain at 32 rows per wave, FP1 INTERP at n = 8192)."""
+    B, N = 2, 8192
+    xyz = syn.unit_cloud(B, N, seed=21) if kind == "unit" else syn.body_like_cloud(B, N, seed=21)
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=5).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    want_logits, want_f, want_xyz = MO.encoder_forward(xyz, sd)
+    model = model.cuda()
+    with torch.no_grad():
+        _, logits, l_f, l_xyz = model.forward_fused(dev(xyz), channel_major=True)
+    for lvl in range(1, 4):
+        assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl]), f"FPS-selected centroids of level {lvl}: not bit-exact"
+    for lvl in range(0, 4):
+        check(f"cfg2/{kind} l_features[{lvl}]", l_f[lvl], want_f[lvl], scaled=True)
+    check(f"cfg2/{kind} sem_logits", logits, want_logits, scaled=True)
+
+
+def test_cfg3_encoder_bf16_full_size_vs_bf16_oracle(monkeypatch):
+    """BASELINE config 3 precision at N = 8192: bf16 MLP operands, fp32 accumulate; sampling stays bit-exact."""
+    B, N = 1, 8192
+    xyz = syn.unit_cloud(B, N, seed=22)
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=6).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    monkeypatch.setattr(MO, "BF16", True)
+    want_logits, want_f, want_xyz = MO.encoder_forward(xyz, sd)
+    model = model.cuda()
+    with torch.no_grad():
+        _, logits, l_f, l_xyz = model.forward_fused(dev(xyz), channel_major=True, precision="bf16")
+    for lvl in range(1, 4):
+        assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl])
+    for lvl in range(0, 4):
+        mx, _, _, scale = stats(f"cfg3 l_features[{lvl}] (bf16 vs bf16-emulating oracle)", l_f[lvl], want_f[lvl])
+        assert mx <= 2e-2 * max(scale, 1.0)
+    mx, _, _, scale = stats("cfg3 sem_logits", logits, want_logits)
+    assert mx <= 2e-2 * max(scale, 1.0)
+
+
+# ---- a5: QueryAndGroup / GroupAll directly on the GPU (pointnet2_utils.py:232-291) ------------------------------------
+def test_query_and_group_gpu_vs_reference_golden(golden_modules):
+    g = golden_modules
+    xyz, feats, q = dev(g["xyz"]), dev(g["feats"]), dev(g["qg_new_xyz"])
+    check("QueryAndGroup(xyz, new_xyz, feats)", PU.QueryAndGroup(0.25, 8)(xyz, q, feats), g["qg_out"])
+    check("QueryAndGroup(xyz, new_xyz, None)", PU.QueryAndGroup(0.25, 8)(xyz, q, None), g["qg_out_nofeat"])
+    got = PU.QueryAndGroup(0.25, 8, use_xyz=False)(xyz, q, feats)
+    assert got.shape == (xyz.shape[0], feats.shape[1], q.shape[1], 8)          # :258-263: features only, no xyz channels
+    want = MO.query_and_group(0.25, 8, g["xyz"], g["qg_new_xyz"], g["feats"], use_xyz=False)
+    assert np.array_equal(got.cpu().numpy(), want)                             # a pure gather: bit-exact
+    assert np.array_equal(got.cpu().numpy(), g["qg_out"][:, 3:])               # = the feature channels of the golden
+    if "qg_out_noxyz" in g:
+        assert np.array_equal(got.cpu().numpy(), g["qg_out_noxyz"])
+    with pytest.raises(AssertionError):
+        PU.QueryAndGroup(0.25, 8, use_xyz=False)(xyz, q, None)                 # :264: "Cannot have not features and not use xyz"
+
+
+def test_group_all_gpu_vs_reference_golden(golden_modules):
+    g = golden_modules
+    xyz, feats = dev(g["xyz"]), dev(g["feats"])
+    got = PU.GroupAll()(xyz, None, feats)
+    assert np.array_equal(got.cpu().numpy(), g["ga_out"])
+    assert np.array_equal(PU.GroupAll(use_xyz=False)(xyz, None, feats).cpu().numpy(), g["ga_out"][:, 3:])
+    assert np.array_equal(PU.GroupAll()(xyz, None, None).cpu().numpy(), g["ga_out"][:, :3])
+
+
+def test_fused_group_loader_equals_query_and_group(golden_modules):
+    """The fused path never materialises the grouped tensor; its GROUP loader must feed the MLP the same rows.  An identity
+    'MLP' (one linear layer with W = I, no BN, no ReLU, no pooling) exposes the loader's rows."""
+    from garment4d_amd import fused
+    g = golden_modules
+    xyz, feats, q = dev(g["xyz"]), dev(g["feats"]), dev(g["qg_new_xyz"])
+    B, N, _ = xyz.shape
+    C, P, S = feats.shape[1], q.shape[1], 8
+    idx = PU.ball_query(0.25, S, xyz, q)
+    K = 3 + C
+    L = fused.PackedLayer(torch.eye(K, device="cuda"), torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), relu=False)
+    out = torch.empty((B * P * S, K), device="cuda")
+    fused.mlp_stack(1, B * P * S, K, [L], out, group=(N, P, C, 1, xyz, q, fused.to_point_major(feats), idx), S=S)
+    got = out.view(B, P, S, K).permute(0, 3, 1, 2).contiguous()
+    check("GROUP loader rows vs golden QueryAndGroup", got, g["qg_out"])
