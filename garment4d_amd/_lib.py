@@ -90,6 +90,9 @@ def lib():
             fn.argtypes = args
             fn.restype = RESTYPES.get(name, _I)
         L.g4d_version.restype = _I
+        L.g4d_get_distance_contraction.restype = _I
+        L.g4d_set_distance_contraction.argtypes = [_I]
+        L.g4d_set_distance_contraction.restype = _I
         L.g4d_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib

@@ -1,8 +1,8 @@
 // Ball query for gfx950 -- replaces ball_query_kernel_fast / ball_query_kernel_launcher_fast
 // (/root/reference/modules/pointnet2/pointnet2/src/ball_query_gpu.cu:9-67), single- and multi-scale.
 //
-// Semantics kept: for query q, hits = ascending k with d2 = (qx-x)^2 + (qy-y)^2 + (qz-z)^2 < r*r
-// (fp32, left-to-right, no fma; r*r rounded once in fp32); out = first `nsample` hits, remaining slots
+// Semantics kept: for query q, hits = ascending k with d2 = dist2<FM>(qx-x, qy-y, qz-z) < r*r
+// (fp32 under the process-wide contraction contract of g4d.h -- nvcc's fused shape by default; r*r rounded once in fp32); out = first `nsample` hits, remaining slots
 // = first hit, all 0 when there is no hit.
 //
 // Layout for the hardware (the reference runs one THREAD per query, each scanning N points serially with
@@ -31,7 +31,7 @@ struct BqArgs {
     int *idx[4];
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef g4d_f32x2 f32x2;
 constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered; a multiple of 128 (two points per lane and step)
 
 // boxes: per (frame, 64-point block) axis-aligned bounds [lo.xyz, hi.xyz], written by ball_boxes_kernel
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long l
     }
 }
 
-template <int QW, int NS, bool BOXES>
+template <int QW, int NS, bool BOXES, int FM>
 __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
                                                         const float *__restrict__ xyz_all, const float *__restrict__ boxes_all) {
     __shared__ float sp[2][3][kStage];
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
         if (BOXES) {
             // Mesh-ordered clouds: consecutive indices are neighbours in space, so most 64-point blocks lie wholly outside
             // a query's largest still-open ball.  Lane l < 16 tests block l of the stage against the query with the SAME
-            // un-fused fp32 expression as the point test: rounding is monotone, so box d2 <= d2 of every point inside
+            // fp32 expression (same contraction shape FM) as the point test: rounding is monotone, so box d2 <= d2 of every point inside
             // the box and a block holding a hit is never skipped.  Blocks are then visited in ascending order, so the
             // "first nsample hits by index" semantics is untouched.
             const int nblk = (n + 63) >> 6;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 if (r2open < 0.f) continue;
                 const float ex = fmaxf(fmaxf(lox - qx[i], qx[i] - hix), 0.f), ey = fmaxf(fmaxf(loy - qy[i], qy[i] - hiy), 0.f),
                             ez = fmaxf(fmaxf(loz - qz[i], qz[i] - hiz), 0.f);
-                const float bd2 = ex * ex + ey * ey + ez * ez;
+                const float bd2 = dist2<FM>(ex, ey, ez);
                 unsigned cand = (unsigned)__builtin_amdgcn_ballot_w64(lane < nb_stage && bd2 < r2open);
                 while (cand) {
                     const int c = __builtin_ctz(cand) << 6;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                     const int k = base + c + lane;
                     const float x = sp[buf][0][c + lane], y = sp[buf][1][c + lane], z = sp[buf][2][c + lane];
                     const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
-                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    const float d2 = dist2<FM>(dx, dy, dz);
                     if (__builtin_amdgcn_ballot_w64(d2 < r2open) == 0ull) continue;
                     bool any_open = false;
 #pragma unroll
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
                 const f32x2 dx = f32x2{qx[i], qx[i]} - x, dy = f32x2{qy[i], qy[i]} - y, dz = f32x2{qz[i], qz[i]} - z;
-                const f32x2 d2v = dx * dx + dy * dy + dz * dz;
+                const f32x2 d2v = dist2<FM>(dx, dy, dz);
                 // common case: nobody within the LARGEST radius -> two compares, one branch for all NS scales
                 const unsigned long long any0 = __builtin_amdgcn_ballot_w64(d2v[0] < a.radius2_max);
                 const unsigned long long any1 = __builtin_amdgcn_ballot_w64(d2v[1] < a.radius2_max);
@@ -219,12 +219,18 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
 }
 
+template <int NS, bool BOXES, int FM>
+static void launch_bq_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
+                         const float *boxes) {
+    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS, BOXES, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS, BOXES, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+    else hipLaunchKernelGGL((ball_query_kernel<1, NS, BOXES, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+}
+
 template <int NS, bool BOXES>
 static void launch_bq(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
                       const float *boxes) {
-    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS, BOXES>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
-    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS, BOXES>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
-    else hipLaunchKernelGGL((ball_query_kernel<1, NS, BOXES>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+    G4D_WITH_FM(distance_contraction(), (launch_bq_fm<NS, BOXES, FM>(qw, grid, st, n, m, a, new_xyz, xyz, boxes)))
 }
 
 }  // namespace g4d

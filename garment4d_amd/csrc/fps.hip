@@ -2,8 +2,8 @@
 // (/root/reference/modules/pointnet2/pointnet2/src/sampling_gpu.cu:93-253).
 //
 // Semantics kept bit-for-bit: idx[0]=0; round j: mind[k] = min(d(k,old), mind[k])
-// with d = dx*dx + dy*dy + dz*dz evaluated left-to-right in fp32 WITHOUT fma (this file is built with
-// -ffp-contract=off); next = arg-max mind[k], ties resolved like the reference's strided scan +
+// with d = dist2<FM>(dx, dy, dz) -- the squared distance under the process-wide contraction contract (g4d.h
+// G4D_CONTRACT_*: nvcc's fused shape by default, or every operation rounded; g4d_common.h); next = arg-max mind[k], ties resolved like the reference's strided scan +
 // shared-memory tree: let bs = min(1024, 2^floor(log2 N)); smallest bit-reversed (k mod bs) wins, then
 // smallest k.  That total order lets the work be laid out for the hardware instead of copying the
 // reference's thread/tree shape:
@@ -91,7 +91,7 @@ __device__ __forceinline__ void wave_argmax(float best, int k, int bs, int log2b
 
 // Register-resident FPS: T = 64*W threads; thread t owns classes t + u*T (u < U = bs/T) and, per class,
 // points c + q*bs (q < Q).  Slot i = v*Q + q visits u = bitrev(v) so that tie-rank ascends with i.
-template <int W, int U, int Q>
+template <int W, int U, int Q, int FM>
 __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
                                                         float *__restrict__ temp_all, int *__restrict__ idx_all) {
     constexpr int T = 64 * W, P = U * Q;
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-            const float d = dx * dx + dy * dy + dz * dz;
+            const float d = dist2<FM>(dx, dy, dz);
             const float d2 = min_f32(d, md[i]);
             md[i] = d2;
             const bool gt = d2 > best;
@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
 
 // Any-N fallback: the reference's thread shape (class c = tid, strided scan from L2-resident global
 // memory), the same DPP + one-barrier reduction.  1024 threads; threads >= bs idle.
+template <int FM>
 __global__ void __launch_bounds__(1024) fps_generic_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
                                                           float *__restrict__ temp_all, int *__restrict__ idx_all) {
     constexpr int W = 16;
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(1024) fps_generic_kernel(int n, int m, int bs,
         if (t < bs) {
             for (int k = t; k < n; k += bs) {
                 const float dx = xyz[k * 3 + 0] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
-                const float d = dx * dx + dy * dy + dz * dz;
+                const float d = dist2<FM>(dx, dy, dz);
                 const float d2 = fminf(d, temp[k]);
                 temp[k] = d2;
                 const bool gt = d2 > best;
@@ -234,14 +235,20 @@ static int ref_block_size(int work_size) {
     return v;
 }
 
-template <int W, int U, int Q>
-static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+template <int W, int U, int Q, int FM>
+static int launch_reg_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
     const size_t lds = 2 * 16 * 16 + (size_t)n * 12;
-    auto kern = fps_reg_kernel<W, U, Q>;
+    auto kern = fps_reg_kernel<W, U, Q, FM>;
     static unsigned long long attr_done = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32")) return rc;
     hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
     return check_launch("g4d_fps_f32");
+}
+
+template <int W, int U, int Q>
+static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+    G4D_WITH_FM(distance_contraction(), return (launch_reg_fm<W, U, Q, FM>(b, n, m, bs, log2bs, xyz, temp, idx, s)))
+    return G4D_OK;
 }
 
 int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s);  // fps_bucket.hip
@@ -330,6 +337,6 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
     }
 #undef G4D_FPS_CASE
     G4D_REQUIRE(temp, "g4d_fps_f32: temp scratch (B,N) is required for this N (register-resident path covers 64 <= N <= 12800)");
-    hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx);
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(fps_generic_kernel<FM>, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx))
     return check_launch("g4d_fps_f32(generic)");
 }

@@ -7,10 +7,12 @@
 // wave, buckets dealt round-robin to the 16 waves so that the buckets near a sample sit in different waves.  Each
 // wave keeps the bounding boxes of its buckets lane-distributed.  A round is then
 //
-//   1. lane i tests box i against the new sample: d_box = gx*gx + gy*gy + gz*gz with gx = the gap between the sample
-//      and the box along x, ... evaluated with the SAME fp32 operation order as the point distance.  Every fp32
-//      operation involved is monotone, so d(p) >= d_box holds for the ROUNDED values of every point p in the box,
-//      exactly, without any epsilon: if d_box >= g_j the sweep could not lower a single min-distance and the bucket
+//   1. lane i tests box i against the new sample: d_box = dist2<FM>(gx, gy, gz) with gx = the gap between the sample
+//      and the box along x, ... evaluated with the SAME fp32 operations (same contraction shape FM) as the point distance.
+//      gx = max(lo - x1, x1 - hi, 0) <= |px - x1| holds for the ROUNDED differences (rounding a difference is monotone),
+//      and dist2<FM> is monotone non-decreasing in each |argument| whether its products are rounded separately or fused
+//      (fma(a, a, c) = round(a*a + c) is monotone in |a| and in c), so d(p) >= d_box holds for the ROUNDED values of every
+//      point p in the box, exactly, without any epsilon, under every contraction mode: if d_box >= g_j the sweep could not lower a single min-distance and the bucket
 //      is skipped -- pruning is bit-exact (measured: 14 of 128 buckets swept per round at N=8192, M=1024);
 //   2. a wave with no active bucket (about half of them in a typical round) republishes its cached candidate; the
 //      others sweep their active buckets and redo ONE arg-max: balanced max / rank-select trees over the lane's 8
@@ -95,7 +97,7 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 }
 
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
-template <int W, int P>
+template <int W, int P, int FM>
 __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all, int *__restrict__ idx_all) {
     constexpr int T = 64 * W, NPAD = T * P;
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
         const float gx = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
         const float gy = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
         const float gz = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
-        const float dbox = gx * gx + gy * gy + gz * gz;
+        const float dbox = dist2<FM>(gx, gy, gz);
         const unsigned active = (unsigned)__builtin_amdgcn_ballot_w64(lane < P && dbox < gval);
 #ifdef G4D_FPS_DEBUG
         dbg_active += __builtin_popcount(active);
@@ -226,8 +228,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
             for (int i = 0; i < P; ++i) {
                 if ((active >> i) & 1u) {
                     const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-                    const float d = dx * dx + dy * dy + dz * dz;
-                    md[i] = fpsb_min(d, md[i]);
+                    md[i] = fpsb_min(dist2<FM>(dx, dy, dz), md[i]);
                 }
             }
             // 3. lane candidate: max value over its P points, smallest rank among the points holding it; then the wave's
@@ -289,16 +290,22 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
 #endif
 }
 
-template <int W, int P>
-static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+template <int W, int P, int FM>
+static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
     const size_t lds = 1024 + body;
-    auto kern = fps_bucket_kernel<W, P>;
+    auto kern = fps_bucket_kernel<W, P, FM>;
     static unsigned long long attr_done = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32(bucketed)")) return rc;
     hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
     return check_launch("g4d_fps_f32(bucketed)");
+}
+
+template <int W, int P>
+static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+    G4D_WITH_FM(distance_contraction(), return (launch_bucket_fm<W, P, FM>(b, n, m, bs, log2bs, xyz, temp, idx, s)))
+    return G4D_OK;
 }
 
 // Called by g4d_fps_f32 (fps.hip) for 2048 < n <= 8192.  Returns -1 when the shape is not covered.

@@ -30,6 +30,41 @@ inline int check_launch(const char *what) {
 
 constexpr int kWave = 64;
 
+// ---- squared distance under the three contraction contracts (include/g4d.h: G4D_CONTRACT_*) ---------------------------
+// Every .hip file is built with -ffp-contract=off, so the only fused operations are the ones written here.
+//   FM = 0  (x*x + y*y) + z*z, every product and sum rounded              (nvcc -fmad=false; the CPU-portable contract)
+//   FM = 1  fma(z, z, fma(x, x, y*y))   the contraction of `x*x + y*y + z*z` by the LLVM / NVVM DAG combiner: of the two
+//           products feeding the first add the LEFT one is fused (fold (fadd (fmul a, b), c) -> fma a, b, c), then the
+//           third product is fused into the second add -- the reference's kernels as nvcc -O2 (fmad on) compiles them
+//   FM = 2  fma(z, z, fma(y, y, x*x))   the accumulate-loop shape `d = 0; d += x*x; d += y*y; d += z*z` (pytorch3d /
+//           chamferdist knn) -- also the alternative pairing for the expression above
+// All three are monotone non-decreasing in |x|, |y|, |z| (each fp32 rounding is monotone), which is what the exact box
+// pruning of fps_bucket.hip / ball_query.hip relies on: a box gap evaluated with the SAME FM bounds every point inside.
+template <int FM>
+__device__ __forceinline__ float dist2(float x, float y, float z) {
+    if constexpr (FM == 0) return x * x + y * y + z * z;
+    else if constexpr (FM == 1) return __builtin_fmaf(z, z, __builtin_fmaf(x, x, y * y));
+    else return __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+}
+typedef float g4d_f32x2 __attribute__((ext_vector_type(2)));
+template <int FM>
+__device__ __forceinline__ g4d_f32x2 dist2(g4d_f32x2 x, g4d_f32x2 y, g4d_f32x2 z) {  // two points on the packed fp32 pipe
+    if constexpr (FM == 0) return x * x + y * y + z * z;
+    else if constexpr (FM == 1) return __builtin_elementwise_fma(z, z, __builtin_elementwise_fma(x, x, y * y));
+    else return __builtin_elementwise_fma(z, z, __builtin_elementwise_fma(y, y, x * x));
+}
+
+int distance_contraction();  // api.hip: the process-wide G4D_CONTRACT_* mode (0, 1 or 2)
+inline int knn_shape(int mode) { return mode == 0 ? 0 : 2; }  // the accumulate loop contracts to the chain shape
+
+// run `body` with a compile-time FM equal to the run-time `fm`
+#define G4D_WITH_FM(fm, ...)                                   \
+    switch (fm) {                                              \
+        case 0: { constexpr int FM = 0; __VA_ARGS__; } break;  \
+        case 1: { constexpr int FM = 1; __VA_ARGS__; } break;  \
+        default: { constexpr int FM = 2; __VA_ARGS__; } break; \
+    }
+
 // Raise a kernel's dynamic-LDS limit above the 64 KB default.  The attribute is PER DEVICE: `done` holds one bit per device
 // ordinal so that a process driving several GPUs sets it on each of them (idempotent, so a race between host threads is benign).
 inline int ensure_dynamic_lds(const void *kernel, int bytes, unsigned long long &done, const char *what) {

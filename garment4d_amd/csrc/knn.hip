@@ -41,6 +41,7 @@ __device__ __forceinline__ void knn_find_bin(const unsigned *hist, unsigned kth,
     }
 }
 
+template <int FM>
 __global__ void __launch_bounds__(256) knn_kernel(int p1, int p2, int K, const float *__restrict__ q_all, const float *__restrict__ x_all,
                                                  float *__restrict__ dist_all, int *__restrict__ idx_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
@@ -57,7 +58,8 @@ __global__ void __launch_bounds__(256) knn_kernel(int p1, int p2, int K, const f
 
     for (int k = t; k < p2; k += 256) {
         const float dx = qx - x[k * 3 + 0], dy = qy - x[k * 3 + 1], dz = qz - x[k * 3 + 2];
-        const float d = dx * dx + dy * dy + dz * dz;  // >= +0: the bit pattern orders like the value
+        const float d = dist2<FM>(dx, dy, dz);  // >= +0: the bit pattern orders like the value.  chamferdist / pytorch3d accumulate
+                                                // `dist += diff * diff` over the 3 axes: nvcc contracts that loop to the chain shape (FM = 2)
         dk[k] = __float_as_uint(d);
     }
     // ---- radix select: value of the (K-1)-th smallest key (0-based), 8 bits per pass, MSB first
@@ -152,9 +154,14 @@ extern "C" int g4d_knn_f32(int b, int p1, int p2, int k, const float *queries, c
     G4D_REQUIRE(queries && points && dists && idx, "g4d_knn_f32: null pointer");
     G4D_REQUIRE(b <= 65535 && p2 <= 32768, "g4d_knn_f32: b <= 65535, p2 <= 32768 (LDS-resident distance keys)");
     const size_t lds = sizeof(unsigned) * (((size_t)p2 + 3) / 4 * 4 + 256 + 8) + sizeof(unsigned long long) * kKnnMaxK;
-    static unsigned long long attr = 0;  // one bit per device
-    if (const int rc = g4d::ensure_dynamic_lds(reinterpret_cast<const void *>(knn_kernel), 150 * 1024, attr, "g4d_knn_f32")) return rc;
-    hipLaunchKernelGGL(knn_kernel, dim3(p1, b), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p1, p2, k, queries, points, dists,
-                       idx);
+    if (knn_shape(distance_contraction()) == 0) {
+        static unsigned long long attr = 0;  // one bit per device
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(knn_kernel<0>), 150 * 1024, attr, "g4d_knn_f32")) return rc;
+        hipLaunchKernelGGL(knn_kernel<0>, dim3(p1, b), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p1, p2, k, queries, points, dists, idx);
+    } else {
+        static unsigned long long attr = 0;
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(knn_kernel<2>), 150 * 1024, attr, "g4d_knn_f32")) return rc;
+        hipLaunchKernelGGL(knn_kernel<2>, dim3(p1, b), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p1, p2, k, queries, points, dists, idx);
+    }
     return check_launch("g4d_knn_f32");
 }

@@ -72,6 +72,7 @@ __device__ __forceinline__ void nn_insert_lex(float d, int k, float &b1, float &
     b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
 }
 
+template <int FM>
 __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                       const float *__restrict__ known_all, float *__restrict__ dist2_all,
                                                       int *__restrict__ idx_all) {
@@ -105,14 +106,10 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
         for (int j = j0; j < j1; j += 4) {
             const float4 kx = *reinterpret_cast<const float4 *>(&skx[j]), ky = *reinterpret_cast<const float4 *>(&sky[j]),
                          kz = *reinterpret_cast<const float4 *>(&skz[j]);
-            float dx = ux - kx.x, dy = uy - ky.x, dz = uz - kz.x;
-            const float d0 = dx * dx + dy * dy + dz * dz;
-            dx = ux - kx.y; dy = uy - ky.y; dz = uz - kz.y;
-            const float d1 = dx * dx + dy * dy + dz * dz;
-            dx = ux - kx.z; dy = uy - ky.z; dz = uz - kz.z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            dx = ux - kx.w; dy = uy - ky.w; dz = uz - kz.w;
-            const float d3 = dx * dx + dy * dy + dz * dz;
+            const float d0 = dist2<FM>(ux - kx.x, uy - ky.x, uz - kz.x);   // interpolate_gpu.cu:33 under the contraction contract
+            const float d1 = dist2<FM>(ux - kx.y, uy - ky.y, uz - kz.y);
+            const float d2 = dist2<FM>(ux - kx.z, uy - ky.z, uz - kz.z);
+            const float d3 = dist2<FM>(ux - kx.w, uy - ky.w, uz - kz.w);
             if (__builtin_amdgcn_ballot_w64(fminf(fminf(d0, d1), fminf(d2, d3)) < b3) != 0ull) {  // wave-uniform skip
                 nn_insert(d0, base + j, b1, b2, b3, i1, i2, i3);
                 nn_insert(d1, base + j + 1, b1, b2, b3, i1, i2, i3);
@@ -338,7 +335,7 @@ extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const
     if ((long long)b * n == 0) return G4D_OK;
     G4D_REQUIRE(unknown && dist2 && idx && (known || m == 0), "g4d_three_nn_f32: null pointer");
     dim3 grid((n + 63) / 64, b);
-    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx);
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_kernel<FM>, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx))
     return check_launch("g4d_three_nn_f32");
 }
 

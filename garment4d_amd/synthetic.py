@@ -39,6 +39,19 @@ def body_like_cloud(B, N, seed=0, dup_frac=0.2, zero_frac=0.1):
     return np.ascontiguousarray(v)
 
 
+def shell_cloud(B, N, seed=0, R=0.5, centre=0.0):
+    """Rounding-adversarial cloud: point 0 sits at `centre`, every other point at distance R from it up to fp32 rounding
+    (random directions on a sphere).  The squared distances to point 0 then agree to within a few ulps, so WHICH point FPS
+    picks, which points a radius-R ball holds and the order of a 3-NN are decided by how the distance expression is rounded --
+    the inputs on which the contraction modes of include/g4d.h (fused vs un-fused multiply-adds) give different indices."""
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((B, N, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    v = (d * R + centre).astype(F32)
+    v[:, 0] = centre
+    return np.ascontiguousarray(v)
+
+
 def smpl_like_params(V=6890, J=24, num_betas=10, seed=0):
     """SMPL-shaped random model parameters:
     v_template (V,3), shapedirs (V,3,nb), posedirs ((J-1)*9, V*3), J_regressor (J,V) row-normalised

@@ -33,6 +33,27 @@ typedef struct ihipStream_t *g4d_stream_t; /* == hipStream_t */
 int g4d_version(void);
 const char *g4d_last_error(void);
 
+/* ---- numerics: how the squared distance of FPS / ball query / three_nn / knn is rounded ---------------------------------
+ * The reference writes  d = (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)  (sampling_gpu.cu:136,
+ * ball_query_gpu.cu:30, interpolate_gpu.cu:33) and builds with `nvcc -O2` (setup.py:19-20), i.e. with -fmad=true: the
+ * compiler contracts the expression into fused multiply-adds.  Which indices come out of FPS (arg-max), ball query (d < r^2)
+ * and three_nn (ordering) depends on that rounding wherever two candidates are within an ulp, and one flipped FPS pick
+ * changes every later pick.  The mode is process-wide, read when a kernel is launched:
+ *   G4D_CONTRACT_NVCC  (default)  fma(dz,dz, fma(dx,dx, dy*dy)) -- the contraction the LLVM/NVVM DAG combiner performs on
+ *                                 that expression (left product of the first sum fused, then the third product): matches
+ *                                 the reference as built by its own setup.py; knn (chamferdist's accumulate loop) uses
+ *                                 fma(dz,dz, fma(dy,dy, dx*dx));
+ *   G4D_CONTRACT_OFF              every product and sum rounded separately (a reference built with -fmad=false, and the
+ *                                 contract a plain C compiler without contraction reproduces);
+ *   G4D_CONTRACT_CHAIN            fma(dz,dz, fma(dy,dy, dx*dx)) for every kernel (the other possible pairing).
+ * Environment: G4D_DIST_CONTRACT=nvcc|off|chain sets the initial mode.  The setter returns the previous mode (-1 and an
+ * error text for an unknown mode).  Box pruning inside the kernels is exact under every mode (monotone rounding). */
+#define G4D_CONTRACT_OFF 0
+#define G4D_CONTRACT_NVCC 1
+#define G4D_CONTRACT_CHAIN 2
+int g4d_get_distance_contraction(void);
+int g4d_set_distance_contraction(int mode);
+
 /* ---- the reference's nine kernels ------------------------------------------------------- */
 
 /* furthest_point_sampling_kernel_launcher (sampling_gpu.h:24-27, sampling_gpu.cu:93-253).

@@ -43,6 +43,11 @@ def lib():
         L.g4d_oracle_block_size.argtypes = [_I]
         L.g4d_oracle_block_size.restype = _I
         L.g4d_oracle_num_threads.restype = _I
+        L.g4d_oracle_set_contraction.argtypes = [_I]
+        L.g4d_oracle_set_contraction.restype = None
+        L.g4d_oracle_get_contraction.restype = _I
+        L.g4d_oracle_pairwise_d2.argtypes = [_I, _I, _I, _I, _f32p, _f32p, _f32p]
+        L.g4d_oracle_pairwise_d2.restype = None
         L.g4d_oracle_fps.argtypes = [_I, _I, _I, _f32p, _f32p, _i32p]
         L.g4d_oracle_fps_keyed.argtypes = [_I, _I, _I, _f32p, _f32p, _i32p]
         L.g4d_oracle_gather.argtypes = [_I, _I, _I, _I, _f32p, _i32p, _f32p]
@@ -65,6 +70,35 @@ def _f(a):
 def _i(a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     return a, a.ctypes.data_as(_i32p)
+
+
+CONTRACT = {"off": 0, "nvcc": 1, "chain": 2}   # include/g4d.h G4D_CONTRACT_*
+
+
+def set_contraction(mode):
+    """Contraction mode of the squared distance in fps / ball_query / three_nn (see g4d_oracle.c header); returns the
+    previous mode.  mode: 0|1|2 or "off"|"nvcc"|"chain"."""
+    prev = lib().g4d_oracle_get_contraction()
+    lib().g4d_oracle_set_contraction(CONTRACT.get(mode, mode))
+    return prev
+
+
+def get_contraction():
+    return lib().g4d_oracle_get_contraction()
+
+
+def pairwise_d2(q, x, shape=None):
+    """(B,P1,3),(B,P2,3) -> (B,P1,P2) fp32 squared distances in the arithmetic of chamferdist's knn under the current
+    contraction mode (accumulate loop: shape 2 when contraction is on, 0 when off) or an explicit shape."""
+    q, pq = _f(q)
+    x, px = _f(x)
+    B, P1, _ = q.shape
+    P2 = x.shape[1]
+    if shape is None:
+        shape = 0 if get_contraction() == 0 else 2
+    out = np.empty((B, P1, P2), dtype=np.float32)
+    lib().g4d_oracle_pairwise_d2(int(shape), B, P1, P2, pq, px, out.ctypes.data_as(_f32p))
+    return out
 
 
 def block_size(n):

@@ -46,3 +46,17 @@ def golden_gcn():
 
 def sub_state_dict(g, prefix):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+@pytest.fixture(params=["nvcc", "off"])
+def contraction_mode(request):
+    """Runs an index-parity test once per distance-contraction mode (include/g4d.h): the HIP library and the oracle are switched
+    together, so each run compares the kernels with the MATCHING oracle.  Modules opt in with
+    `pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("contraction_mode")]`."""
+    from garment4d_amd import numerics
+    from oracle import pointnet2_oracle as K
+    prev_o = K.set_contraction(request.param)
+    prev_l = numerics.set_distance_contraction(request.param)
+    yield request.param
+    numerics.set_distance_contraction(prev_l)
+    K.set_contraction(prev_o)

@@ -133,6 +133,21 @@ def gen_ops(p2u):
                     f"{name}_ball": N(bq), f"{name}_grouped": N(grouped), f"{name}_nn_dist": N(dist),
                     f"{name}_nn_idx": N(nn_idx), f"{name}_feats": N(feats), f"{name}_weight": N(w),
                     f"{name}_interp": N(interp)})
+    # rounding-adversarial case, once per contraction mode of the squared distance (g4d_oracle.c header): a shell of points
+    # at (almost) equal distance from point 0 -- which one FPS picks, which ones a ball of that radius holds and the 3-NN order
+    # are decided by whether nvcc's fused multiply-adds are emulated.  The cases above come out identical in every mode
+    # (tests/test_contraction.py checks that), these do not.
+    shell = syn.shell_cloud(2, 1500, seed=8)
+    out["shell_xyz"] = shell
+    for mode in ("off", "nvcc", "chain"):
+        prev = K.set_contraction(mode)
+        x = T(shell)
+        idx = p2u.furthest_point_sample(x, 96)
+        q = x[:, :16].contiguous()
+        out[f"shell_fps_{mode}"] = N(idx)
+        out[f"shell_ball_{mode}"] = N(p2u.ball_query(0.5, 48, x, q))
+        out[f"shell_nn_idx_{mode}"] = N(p2u.three_nn(q, x[:, 1:].contiguous())[1])
+        K.set_contraction(prev)
     # far-away query: no neighbour at all -> row stays zeros (ball_query_gpu.cu:27-44)
     xyz = syn.unit_cloud(1, 64, seed=5)
     q = np.array([[[5.0, 5.0, 5.0], [0.5, 0.5, 0.5]]], dtype=np.float32)
@@ -180,6 +195,7 @@ def gen_modules(p2u, p2m):
     out["qg_new_xyz"] = N(nx)
     out["qg_out"] = N(qg(T(xyz), nx, T(feats)))
     out["qg_out_nofeat"] = N(qg(T(xyz), nx, None))
+    out["qg_out_noxyz"] = N(p2u.QueryAndGroup(0.25, 8, use_xyz=False)(T(xyz), nx, T(feats)))      # pointnet2_utils.py:258-263
     out["ga_out"] = N(p2u.GroupAll(True)(T(xyz), None, T(feats)))
 
     # MSG, 2 scales, with features
@@ -311,6 +327,7 @@ def gen_gcn(gl, gu):
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    K.set_contraction("nvcc")   # the default mode: the reference as its own setup.py builds it (nvcc -O2, fmad on)
     p2u, p2m, ptu, lbs, gl, gu = load_reference()
     with torch.no_grad():
         pass

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_signatures_cover_header():
     from garment4d_amd import _lib
-    declared = set(declared_symbols()) - {"g4d_version", "g4d_last_error"}
+    declared = set(declared_symbols()) - {"g4d_version", "g4d_last_error", "g4d_get_distance_contraction", "g4d_set_distance_contraction"}
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
 
 
@@ -107,3 +107,20 @@ def test_argument_validation_needs_no_gpu():
     assert L.g4d_mlp_chain_supported(3, ctypes.cast(cout, ctypes.c_void_p)) == 1
     # empty problems are fine everywhere (the reference's kernels are simply not launched)
     assert L.g4d_fps_f32(0, 8, 4, 0, 0, 0, 0) == 0 and L.g4d_knn_f32(0, 4, 8, 3, 0, 0, 0, 0, 0) == 0
+
+
+def test_distance_contraction_switch_without_a_gpu():
+    """The numerics mode (include/g4d.h G4D_CONTRACT_*) is host state: default nvcc, round trip, bad mode rejected."""
+    from garment4d_amd import _lib, numerics
+    start = numerics.get_distance_contraction()
+    assert start == os.environ.get("G4D_DIST_CONTRACT", "nvcc")
+    try:
+        assert numerics.set_distance_contraction("off") == start
+        assert numerics.get_distance_contraction() == "off"
+        with numerics.distance_contraction("chain"):
+            assert numerics.get_distance_contraction() == "chain"
+        assert numerics.get_distance_contraction() == "off"
+        with pytest.raises(_lib.G4DError):
+            numerics.set_distance_contraction(3)
+    finally:
+        numerics.set_distance_contraction(start)

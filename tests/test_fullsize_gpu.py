@@ -7,7 +7,7 @@ import torch
 from garment4d_amd import fused, pointnet2_modules as PM, pointnet2_utils as PU, synthetic as syn
 from oracle import pointnet2_oracle as K
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("contraction_mode")]   # every test runs in both numerics modes
 
 
 def dev(a):

@@ -7,7 +7,7 @@ from garment4d_amd import synthetic as syn
 from garment4d_amd.knn import knn_points
 from oracle import refine_oracle as RO
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("contraction_mode")]   # every test runs in both numerics modes
 
 
 def dev(a):

@@ -8,7 +8,7 @@ from garment4d_amd import pointnet2_utils as PU
 from garment4d_amd import synthetic as syn
 from oracle import pointnet2_oracle as K
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("contraction_mode")]   # every test runs in both numerics modes
 TOL = dict(rtol=1e-5, atol=1e-5)
 
 
