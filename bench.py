@@ -15,8 +15,15 @@ the timed region (barrier + synchronize on both sides, max over ranks).
 Multi-GPU: frames are independent -> each rank processes its own batches, no data-path
 collective, weak scaling; value = frames of all ranks / max-over-ranks time.
 
-Output: ONE JSON line (rank 0) with the contract fields + `roofline` (dominant kernel, measured with HIP
-events in an instrumented eager pass inside this script) + `cpu_baseline` (the CPU oracle timed on this box).
+Timed region: the K steps are repeated R times back to back (`repeats` in the output; R chosen so that the region lasts
+>= 0.5 s whatever --steps is, so a short driver run is not a single wave of 16 batches); ms_per_step = time / (K * R).
+Inputs: every step first copies a fresh batch from a rotating pool of distinct clouds (> 256 MB, i.e. larger than the MALL)
+into the stream's input buffer, so the path reads inputs that are cold in every cache -- the copy is inside the timed region.
+
+Output: ONE JSON line (rank 0) with the contract fields + `roofline` (dominant kernel by GPU time = FPS level 1, a LATENCY-
+bound kernel, measured with HIP events in an instrumented eager pass inside this script) + `roofline_mfma` (heaviest MFMA
+launch) + `whole_path` (the SURVEY 8(d) fractions of the step as a whole) + `latency_ms_single_stream` + `cpu_baseline`
+(the CPU oracle timed on this box per BASELINE.md section 3: 1 thread and all cores, warm-up, medians, CPU model).
 """
 import argparse
 import json
@@ -47,7 +54,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=16, help="independent batches in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the workload the CPU oracle is timed on")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames per sample the CPU oracle is timed on with all cores")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of the timed region (the K steps are repeated)")
+    ap.add_argument("--input-pool-mb", type=float, default=320.0, help="distinct input clouds rotated through, in MB (0 = replay the "
+                                                                       "same resident batches: MALL-warm inputs)")
     ap.add_argument("--no-lbs", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE config 3: shared-MLP operands in bf16 (fp32 accumulate); default fp32 = config 2")
@@ -56,11 +66,16 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(device, streams, with_lbs):
+def build_workload(device, streams, with_lbs, pool_mb=0.0):
     from garment4d_amd import synthetic as syn
     from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=0).to(device).eval()
     clouds = [torch.from_numpy(syn.unit_cloud(B_CLOUDS, N_POINTS, seed=1 + s)).to(device) for s in range(streams)]
+    pool = None
+    if pool_mb > 0:  # distinct batches the steps rotate through: generated on the device (uniform clouds, as syn.unit_cloud)
+        nb = int(np.ceil(pool_mb * 1e6 / (B_CLOUDS * N_POINTS * 12)))
+        g = torch.Generator(device=device).manual_seed(12345)
+        pool = torch.rand((nb, B_CLOUDS, N_POINTS, 3), generator=g, device=device, dtype=torch.float32)
     lbs_in = None
     if with_lbs:
         from garment4d_amd import lbs as G
@@ -71,7 +86,7 @@ def build_workload(device, streams, with_lbs):
             betas, pose = syn.smpl_like_pose(B_CLOUDS, seed=100 + s)
             poses.append((torch.from_numpy(betas).to(device), torch.from_numpy(pose).to(device)))
         lbs_in = (G, smpl, poses)
-    return model, clouds, lbs_in
+    return model, clouds, lbs_in, pool
 
 
 def one_step(model, cloud, lbs_in, slot, precision="fp32"):
@@ -85,10 +100,30 @@ def one_step(model, cloud, lbs_in, slot, precision="fp32"):
     return out[1], None
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950
+    correction for wide coalesced reads is NOT applied to these gather-heavy kernels; WRITE_SIZE as reported), read from
+    profiles/ at run time -- newest round first; None when no profile holds the kernel."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.csv")), reverse=True):
+        tot, seen = 0.0, set()
+        try:
+            for row in csv.DictReader(open(path)):
+                if kernel_substr in row["kernel"] and row["counter"] not in seen:
+                    tot += float(row["avg_per_launch_KB"]) * 1024.0
+                    seen.add(row["counter"])
+        except (OSError, KeyError, ValueError):
+            continue
+        if {"FETCH_SIZE", "WRITE_SIZE"} <= seen:
+            return {"bytes": tot, "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def kernel_rooflines(model, cloud):
     """Instrumented eager pass: HIP events (on the stream the kernels are launched on = torch's current
     stream) around the two heaviest kernels.  Algorithmic bytes/flops per launch: DESIGN.md §Kernels."""
-    from garment4d_amd import fused, pointnet2_utils as PU
+    from garment4d_amd import fused
     res = {}
 
     def timed(fn, iters=10):
@@ -102,21 +137,24 @@ def kernel_rooflines(model, cloud):
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3  # seconds
 
-    # 1. FPS level 1 (8192 -> 1024), the dominant kernel by GPU time (56 % in profiles/r01_kernel_stats_bench_default.csv).
-    #    One launch = B clouds.  Algorithmic bytes = xyz in + idx out (the fused path passes temp=NULL: no scratch traffic).
+    # 1. FPS level 1 (8192 -> 1024): the dominant kernel by summed GPU time.  One launch = B clouds, one workgroup per cloud,
+    #    1023 strictly dependent rounds: LATENCY-bound (SURVEY 8d regime 1).  Algorithmic bytes = xyz in + idx out (the fused
+    #    path passes temp=NULL: no scratch traffic); the HBM fraction is reported because the contract asks for it -- the
+    #    meaningful figure is us_per_round.
     xyz_dev = cloud
     idx_dev = torch.empty((B_CLOUDS, 1024), dtype=torch.int32, device=cloud.device)
     from garment4d_amd import _lib
     t = timed(lambda: _lib.call("g4d_fps_f32", B_CLOUDS, N_POINTS, 1024, xyz_dev.data_ptr(), 0, idx_dev.data_ptr(), _lib.stream_ptr()))
     fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024)
-    res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8)", "bound": "hbm", "achieved": fps_bytes / t / 1e9,
+    tr = pmc_traffic("fps_bucket_kernel")
+    res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8)", "bound": "latency", "achieved": fps_bytes / t / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS,
-                  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per launch: 483.0 KB + 32.0 KB (profiles/r01_pmc_hbm_traffic.csv);
-                  # below the algorithmic bytes because part of the cloud is still in L2 / MALL from the previous step
-                  "traffic": (483.0 + 32.0) * 1024, "traffic_unit": "bytes/launch", "algorithmic_bytes": fps_bytes,
-                  "avg_launch_us": t * 1e6, "rounds_per_s_per_cloud": 1023 / t,
+                  "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
+                  "traffic_source": None if tr is None else tr["source"], "algorithmic_bytes": fps_bytes,
+                  "avg_launch_us": t * 1e6, "rounds_per_launch": 1023, "us_per_round": t * 1e6 / 1023,
+                  "rounds_per_s_per_cloud": 1023 / t,
                   "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
-                          "neither HBM nor MFMA limits it -- see DESIGN.md section 5"}
+                          "neither HBM nor MFMA limits it (frac is against HBM only because the contract wants a number) -- DESIGN.md section 5"}
     # 2. heaviest MFMA launch of a step: SA3 scale 1, [195 -> 128 -> 128 -> 256] over B*64*64 grouped rows + max pool, one
     #    register-chain launch (csrc/mlp_chain.hip).  Algorithmic flops = 2 * rows * sum(K_l * C_l), un-padded.
     sa3 = model.SA_modules[2]
@@ -131,35 +169,84 @@ def kernel_rooflines(model, cloud):
     rows = Bc * P * S
     t = timed(lambda: fused.mlp_stack(1, rows, 3 + C, layers, out3, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
     flops = 2.0 * rows * sum(L.K * L.Cout for L in layers)
+    tr = pmc_traffic("mlp_chain_kernel<1, 8, 8, 16")
     res["mlp"] = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", "bound": "mfma",
                   "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                  # PMC per launch: 6434.9 KB fetched + 512.0 KB written (profiles/r01_pmc_hbm_traffic.csv) against 2.0 MB algorithmic
-                  # (indices + gathered features + weights): the weights are fetched once per XCD
-                  "traffic": (6434.9 + 512.0) * 1024, "traffic_unit": "bytes/launch", "avg_launch_us": t * 1e6}
+                  "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
+                  "traffic_source": None if tr is None else tr["source"], "avg_launch_us": t * 1e6,
+                  "note": "isolated launch on an idle chip; inside the 16-batch bench the same launch runs concurrently with others"}
     return res
 
 
-def cpu_baseline(frames, with_lbs):
-    """The CPU oracle (C kernels + numpy MLP/LBS) on `frames` frames of the same workload."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(frames_all, with_lbs):
+    """The CPU oracle on this box's host cores, per BASELINE.md section 3 / SURVEY 8(d): the C restatement of the reference's
+    CUDA kernels (OpenMP) + the numpy restatement of SharedMLP (channel contraction through the multi-threaded BLAS) and lbs(),
+    with 1 thread and with all cores, one warm-up run and the MEDIAN of the timed runs; LBS timed batched and the way the
+    reference's dataloader calls it (batch 1, three calls per frame: utils/dataloader.py:199-212).  Bounded to ~30 s."""
+    import threadpoolctl
     from garment4d_amd import synthetic as syn
     from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
     from oracle import lbs_oracle, modules_oracle as MO, pointnet2_oracle as K
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=0).eval()
     sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    ncores = os.cpu_count() or 1
+    P = syn.smpl_like_params(seed=40)
 
-    xyz = syn.unit_cloud(frames, N_POINTS, seed=1)
-    t0 = time.perf_counter()
-    MO.encoder_forward(xyz, sd)
-    if with_lbs:
-        P = syn.smpl_like_params(seed=40)
+    def lbs_call(betas, pose):
+        return lbs_oracle.lbs(betas, pose, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"])
+
+    def run(threads, frames, reps):
+        """median seconds of (encoder on `frames` clouds, batched lbs on `frames`, dataloader-style lbs per frame)"""
+        xyz = syn.unit_cloud(frames, N_POINTS, seed=1)
         betas, pose = syn.smpl_like_pose(frames, seed=100)
-        lbs_oracle.lbs(betas, pose, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"],
-                       P["lbs_weights"])
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": K.num_threads(), "kind": "port",
-            "sample": f"{frames} frame(s) of the same workload (N={N_POINTS} encoder{' + lbs' if with_lbs else ''}), "
-                      f"C oracle kernels (OpenMP) + numpy fp32 MLP; {dt:.1f} s"}
+        prev = K.set_threads(threads)
+        MO.BLAS = True
+        te, tb, td = [], [], []
+        try:
+            with threadpoolctl.threadpool_limits(limits=threads):
+                for rep in range(reps + 1):                      # rep 0 = warm-up
+                    t0 = time.perf_counter()
+                    MO.encoder_forward(xyz, sd)
+                    t1 = time.perf_counter()
+                    if with_lbs:
+                        lbs_call(betas, pose)
+                    t2 = time.perf_counter()
+                    if with_lbs:
+                        for f in range(min(frames, 4)):          # the dataloader evaluates SMPL 3x per frame, batch 1
+                            for _ in range(3):
+                                lbs_call(betas[f:f + 1], pose[f:f + 1])
+                    t3 = time.perf_counter()
+                    if rep:
+                        te.append(t1 - t0); tb.append(t2 - t1); td.append((t3 - t2) / max(1, min(frames, 4)))
+        finally:
+            MO.BLAS = False
+            K.set_threads(prev)
+        return float(np.median(te)), float(np.median(tb)), float(np.median(td))
+
+    e_all, b_all, d_all = run(ncores, frames_all, 3)
+    e_1, b_1, d_1 = run(1, 1, 2)
+    fps_all = frames_all / (e_all + b_all)
+    return {"value": fps_all, "unit": "frames/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model_name(),
+            "value_1_thread": 1.0 / (e_1 + b_1),
+            "encoder_s_per_frame": {"all_cores": e_all / frames_all, "1_thread": e_1},
+            "lbs_ms_per_frame": {"batched_all_cores": b_all / frames_all * 1e3, "batched_1_thread": b_1 * 1e3,
+                                 "dataloader_style_3_calls_batch1_all_cores": d_all * 1e3, "dataloader_style_3_calls_batch1_1_thread": d_1 * 1e3},
+            "value_with_dataloader_style_lbs": frames_all / (e_all + d_all * frames_all),
+            "sample": f"all cores: {frames_all} frames of the same workload (N={N_POINTS} encoder"
+                      f"{' + lbs' if with_lbs else ''}) per run, 1 warm-up + median of 3 runs; 1 thread: 1 frame, 1 warm-up + median of 2; "
+                      f"C oracle kernels (OpenMP; FPS parallel over clouds only) + numpy MLP on the BLAS; "
+                      f"{e_all + b_all:.1f} s per all-core run"}
 
 
 def main():
@@ -189,8 +276,9 @@ def main():
     except ImportError:
         with_lbs = False
     ns = max(1, args.streams)
-    model, clouds, lbs_in = build_workload(dev, ns, with_lbs)
+    model, clouds, lbs_in, pool = build_workload(dev, ns, with_lbs, args.input_pool_mb)
     streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    npool = 0 if pool is None else pool.shape[0]
 
     with torch.no_grad():
         # eager warm-up (also packs weights, sets kernel attributes)
@@ -218,15 +306,36 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        def run_steps(first, count):
+            """`count` steps, round-robin over the streams; each takes the next batch of the input pool (a device-to-device copy
+            on the step's own stream, inside the timed region) and runs the whole hot path on it."""
+            for k in range(first, first + count):
+                s = k % ns
+                with torch.cuda.stream(streams[s]):
+                    if pool is not None:
+                        clouds[s].copy_(pool[k % npool], non_blocking=True)
+                    if graphs is not None:
+                        graphs[s].replay()
+                    else:
+                        one_step(model, clouds[s], lbs_in, s, args.precision)
+
+        # how many times the K-step block is repeated: a short probe (untimed, also the post-capture warm-up) sizes the timed
+        # region to >= --min-seconds; every rank uses the max so that all ranks do the same work
         barrier()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            s = k % ns
-            with torch.cuda.stream(streams[s]):
-                if graphs is not None:
-                    graphs[s].replay()
-                else:
-                    one_step(model, clouds[s], lbs_in, s, args.precision)
+        run_steps(0, args.steps)
+        torch.cuda.synchronize()
+        probe = time.perf_counter() - t0
+        repeats = max(1, int(np.ceil(args.min_seconds / max(probe, 1e-6))))
+        if dist is not None:
+            rr = torch.tensor([repeats], device=dev if args.backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+            repeats = int(rr.item())
+
+        barrier()
+        t0 = time.perf_counter()
+        for r in range(repeats):
+            run_steps(r * args.steps, args.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -235,21 +344,53 @@ def main():
             dt = float(tt.item())
         barrier()
 
+        # single-batch latency: one graph alone on an otherwise idle chip (what a caller that cannot batch sees)
+        lat = None
+        if rank == 0:
+            ts = []
+            with torch.cuda.stream(streams[0]):
+                for i in range(12):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    if graphs is not None:
+                        graphs[0].replay()
+                    else:
+                        one_step(model, clouds[0], lbs_in, 0, args.precision)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t1)
+            lat = float(np.median(ts[2:])) * 1e3
         roof = kernel_rooflines(model, clouds[0]) if rank == 0 else None
 
     if rank == 0:
-        frames = args.steps * B_CLOUDS * world
+        total_steps = args.steps * repeats
+        frames = total_steps * B_CLOUDS * world
+        fps = frames / dt
+        per_gpu = fps / world
         line = {
             "metric": "point-cloud frames/s (FPS+ball_query+SA-MLP+LBS), B=8 N=8192",
-            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
+            "timed_seconds": dt, "ms_per_step": dt / total_steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 MLP operands / f32 accumulate, sampling, LBS", "data": "synthetic",
+            "latency_ms_single_stream": lat,
             "config": {"workload": "cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32"
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),
                        "frames_per_step": B_CLOUDS, "batches_in_flight": ns, "hipgraph": graphs is not None,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "inputs": (f"rotating pool of {npool} distinct batches = {npool * B_CLOUDS * N_POINTS * 12 / 1e6:.0f} MB (> 256 MB MALL), "
+                                  "copied in on the step's stream inside the timed region") if pool is not None
+                                 else f"{ns} resident batches replayed (MALL-warm inputs)",
+                       "note": f"a step lasts longer than ms_per_step: {ns} batches overlap (single-batch latency: latency_ms_single_stream)",
+                       "device": torch.cuda.get_device_name(dev),
+                       "collective_backend": None if dist is None else f"{args.backend} world_size={world} (barrier + max-reduce of the time only)",
+                       "distance_contraction": __import__("garment4d_amd.numerics", fromlist=["x"]).get_distance_contraction(),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roof["fps"], "roofline_mfma": roof["mlp"],
+            # SURVEY 8(d) whole-path fractions, per GPU: frames/s x per-frame algorithmic cost / peak
+            "whole_path": {"mfma_frac": per_gpu * 2.22e9 / (MFMA_F32_PEAK_TFLOPS * 1e12 if args.precision == "fp32" else 2.5e15),
+                           "mfma_peak": "157.3 TFLOP/s fp32" if args.precision == "fp32" else "2.5 PFLOP/s bf16 dense",
+                           "hbm_frac_of_unfused_op_traffic": per_gpu * 42.5e6 / (HBM_PEAK_GBS * 1e9),
+                           "hbm_frac_of_fused_lower_bound": per_gpu * 8.0e6 / (HBM_PEAK_GBS * 1e9),
+                           "per_frame": "2.22 GFLOP, 42.5 MB op-by-op traffic, ~8 MB fused lower bound (BASELINE.md section 2)"},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (same host cores at every N)
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames, with_lbs)

@@ -85,10 +85,25 @@ class Pointnet2MSGSEG(nn.Module):
         xyz = pointcloud[..., 0:3].contiguous()
         feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None  # already point-major
         l_xyz, l_feats = [xyz], [feats]
-        for sa in self.SA_modules:
-            nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1])
-            l_xyz.append(nx)
-            l_feats.append(nf)
+        if fused.OVERLAP_SAMPLING:
+            # sampling depends on coordinates only: the three FPS -> gather steps run as one chain on a side stream, overlapping
+            # the ball-grid build of level 1 and the ball queries + MLPs of the levels before them
+            cur = torch.cuda.current_stream(xyz.device)
+            chain = fused.sampling_chain(xyz, [sa.npoint for sa in self.SA_modules])
+            grid = None
+            if xyz.shape[1] >= fused.GRID_MIN_N:
+                grid = fused.build_ball_grid(xyz, max(g.radius for g in self.SA_modules[0].groupers))
+            for sa, (nx, ready) in zip(self.SA_modules, chain):
+                cur.wait_event(ready)
+                _, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1], new_xyz=nx, grid=grid)
+                grid = None
+                l_xyz.append(nx)
+                l_feats.append(nf)
+        else:
+            for sa in self.SA_modules:
+                nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1])
+                l_xyz.append(nx)
+                l_feats.append(nf)
         middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None
         nfp = len(self.FP_modules)
         for i in range(-1, -nfp, -1):

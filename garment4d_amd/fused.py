@@ -323,20 +323,43 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
     _pool_rows(h, rows // S, S, out, col0, pool == 1)
 
 
-def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False):
+OVERLAP_SAMPLING = os.environ.get("G4D_OVERLAP_SAMPLING", "1") != "0"  # encoder: FPS chain on a side stream (sampling_chain)
+GRID_MIN_N = int(os.environ.get("G4D_BQ_GRID_MIN_N", "4096"))  # clouds at least this large go through the cell grid (csrc/ball_grid.hip)
+
+
+def build_ball_grid(xyz, rmax):
+    """Per-cloud uniform grid (cell edge 1.01 * rmax) + the cloud counting-sorted into cell order: (workspace, rmax).  Depends on
+    (xyz, rmax) only -- reusable by every ball query on this cloud with radii <= rmax."""
+    _chk(xyz)
+    B, N, _ = xyz.shape
+    ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B, N), 16), dtype=torch.uint8, device=xyz.device)
+    _lib.call("g4d_ball_grid_build_f32", B, N, float(rmax), xyz.data_ptr(), ws.data_ptr(), _lib.stream_ptr())
+    return ws, float(rmax)
+
+
+def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     """All scales of an MSG layer in one pass over the cloud; returns one (B,P,nsample) int32 tensor per scale.
-    coherent=True: the cloud's index order is spatially coherent (mesh vertices) -> block-bounds skipping (same results)."""
+    coherent=True: the cloud's index order is spatially coherent (mesh vertices) -> block-bounds skipping (same results).
+    grid: None = automatic (cell grid for clouds of >= GRID_MIN_N points), False = scan, True = build a grid, or a
+    (workspace, rmax) pair from build_ball_grid.  Every route returns the same indices, bit for bit."""
     import ctypes
     B, N, _ = xyz.shape
     P = new_xyz.shape[1]
     outs = [torch.empty((B, P, ns), dtype=torch.int32, device=xyz.device) for ns in nsamples]
+    if grid is None:
+        grid = (not coherent) and N >= GRID_MIN_N
+    if grid is True:
+        grid = build_ball_grid(xyz, max(float(r) for r in radii)) if (B and N and P) else False
     done = 0
-    while done < len(radii):  # the kernel takes up to 4 scales per launch
+    while done < len(radii):  # the kernels take up to 4 scales per launch
         n = min(4, len(radii) - done)
         R = (ctypes.c_float * n)(*[float(r) for r in radii[done:done + n]])
         NS = (ctypes.c_int * n)(*[int(v) for v in nsamples[done:done + n]])
         IP = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs[done:done + n]])
-        if coherent and N >= 256:
+        if grid:
+            _lib.call("g4d_ball_grid_query_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
+                      new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), grid[0].data_ptr(), grid[1], _lib.stream_ptr())
+        elif coherent and N >= 256:
             boxes = torch.empty((B, (N + 63) // 64, 6), dtype=torch.float32, device=xyz.device)
             _lib.call("g4d_ball_query_boxes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
                       new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), boxes.data_ptr(), _lib.stream_ptr())
@@ -347,9 +370,67 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False):
     return outs
 
 
-def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
+def fps_gather(xyz, npoint, sidx=None, new_xyz=None):
+    """new_xyz = xyz[furthest_point_sample(xyz, npoint)] (pointnet2_modules.py:32-35) -> (B,npoint,3).  `sidx` / `new_xyz`:
+    optional pre-allocated outputs (the sampling chain of the encoder runs on a side stream into buffers owned by the main one)."""
+    B, N, _ = xyz.shape
+    stream = _lib.stream_ptr()
+    if sidx is None:
+        sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    if 64 <= N <= 12800:  # register-resident FPS: no scratch tensor, no fill kernel
+        _lib.call("g4d_fps_f32", B, N, npoint, xyz.data_ptr(), 0, sidx.data_ptr(), stream)
+    else:
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        _lib.call("g4d_fps_f32", B, N, npoint, xyz.data_ptr(), temp.data_ptr(), sidx.data_ptr(), stream)
+    # gather of the 3 coordinates = GROUP loader with S=1 would do; the legacy kernel wants (B,3,N)
+    if new_xyz is None:
+        new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
+    _lib.call("g4d_gather_rows_f32", B, N, npoint, 3, xyz.data_ptr(), sidx.data_ptr(), new_xyz.data_ptr(), stream)
+    return new_xyz
+
+
+_side_streams = {}
+
+
+def side_stream(device=None):
+    """The side stream paired with the current stream (one per main stream, so that batches in flight on different streams
+    do not serialise on a shared one)."""
+    cur = torch.cuda.current_stream(device)
+    key = (cur.device.index, cur.cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=cur.device)
+    return st
+
+
+def sampling_chain(xyz, npoints):
+    """The FPS -> gather chain of every set-abstraction level, which depends on coordinates only (pointnet2_modules.py:32-35:
+    level l samples the centroids of level l-1), issued on a SIDE stream: level l+1's sampling overlaps level l's ball query
+    and MLPs, and the first level's overlaps the ball-grid build.  Returns [(new_xyz_l, ready_event_l)]; the caller makes its
+    stream wait for event l before using new_xyz_l.  Works eagerly and under hipGraph capture (the side stream forks from and
+    joins back into the capturing stream through the events); buffers are allocated by the CALLING stream, which outlives the use."""
+    cur = torch.cuda.current_stream(xyz.device)
+    B = xyz.shape[0]
+    bufs = [(torch.empty((B, m), dtype=torch.int32, device=xyz.device), torch.empty((B, m, 3), dtype=torch.float32, device=xyz.device))
+            for m in npoints]
+    side = side_stream(xyz.device)
+    side.wait_stream(cur)
+    out = []
+    with torch.cuda.stream(side):
+        src = xyz
+        for (sidx, nx), m in zip(bufs, npoints):
+            fps_gather(src, m, sidx, nx)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            out.append((nx, ev))
+            src = nx
+    return out
+
+
+def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
     """Fused PointnetSAModule(MSG).forward (pointnet2_modules.py:19-55), eval mode.
-    xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major)."""
+    xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major).
+    grid: passed to ball_query_msg (None = automatic, or a pre-built (workspace, rmax) pair)."""
     assert not sa.training, "fused path is eval-mode only (train-mode BN needs batch statistics)"
     _chk(xyz)
     B, N, _ = xyz.shape
@@ -360,18 +441,11 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None):
     stream = _lib.stream_ptr()
     if sa.npoint is not None:
         if new_xyz is None:
-            if 64 <= N <= 12800:  # register-resident FPS: no scratch tensor, no fill kernel
-                sidx = torch.empty((B, sa.npoint), dtype=torch.int32, device=xyz.device)
-                _lib.call("g4d_fps_f32", B, N, sa.npoint, xyz.data_ptr(), 0, sidx.data_ptr(), stream)
-            else:
-                sidx = PU.furthest_point_sample(xyz, sa.npoint)
-            # gather of the 3 coordinates = GROUP loader with S=1 would do; the legacy kernel wants (B,3,N)
-            new_xyz = torch.empty((B, sa.npoint, 3), dtype=torch.float32, device=xyz.device)
-            _lib.call("g4d_gather_rows_f32", B, N, sa.npoint, 3, xyz.data_ptr(), sidx.data_ptr(), new_xyz.data_ptr(), stream)
+            new_xyz = fps_gather(xyz, sa.npoint)
         P = new_xyz.shape[1]
         out = torch.empty((B, P, ctot), dtype=torch.float32, device=xyz.device)
         col0 = 0
-        idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz)
+        idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, grid=grid)
         for grouper, layers, idx in zip(sa.groupers, packed, idxs):
             S = grouper.nsample
             use_xyz = int(grouper.use_xyz)

@@ -37,9 +37,20 @@ def _i(t, name):
     return _chk(t, torch.int32, name)
 
 
+_GRID_MIN_N = 4096  # same threshold as fused.GRID_MIN_N
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
-    _lib.call("g4d_ball_query_f32", b, n, m, float(radius), nsample, _f(new_xyz, "new_xyz"), _f(xyz, "xyz"),
-              _i(idx, "idx"), _lib.stream_ptr())
+    pq, px, pi = _f(new_xyz, "new_xyz"), _f(xyz, "xyz"), _i(idx, "idx")
+    if n >= _GRID_MIN_N and b > 0 and m > 0 and nsample > 0:
+        # large cloud: cell-bucketed search (csrc/ball_grid.hip), bit-identical output; the scratch comes from torch's allocator
+        import ctypes
+        ws = torch.empty(_lib.lib().g4d_ball_grid_bytes(b, n), dtype=torch.uint8, device=xyz.device)
+        R, NS, IP = (ctypes.c_float * 1)(float(radius)), (ctypes.c_int * 1)(int(nsample)), (ctypes.c_void_p * 1)(pi)
+        _lib.call("g4d_ball_query_grid_f32", b, n, m, 1, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p), pq, px,
+                  ctypes.cast(IP, ctypes.c_void_p), ws.data_ptr(), _lib.stream_ptr())
+        return 1
+    _lib.call("g4d_ball_query_f32", b, n, m, float(radius), nsample, pq, px, pi, _lib.stream_ptr())
     return 1
 
 

@@ -6,7 +6,8 @@
  *   - plain C, raw DEVICE pointers + sizes + a HIP stream; no torch / ATen types;
  *   - the caller allocates every output and pre-initialises what the reference's callers
  *     pre-initialise (noted per function); kernels are enqueued on `stream`, never synchronise,
- *     never allocate, keep no global state -> safe from several host threads on different streams;
+ *     never allocate, keep no global state (except the process-wide numerics mode below) -> safe from several host threads
+ *     on different streams;
  *   - every entry point returns 0 on success or a non-zero hipError_t / G4D_E* code; it NEVER
  *     calls exit() (the reference's launchers do: e.g. sampling_gpu.cu:248-252).
  *     g4d_last_error() returns a thread-local message for the last failure.
@@ -95,6 +96,19 @@ int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii,
  * coherent ones (a few % slower for random order). */
 int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
                              const float *xyz, int *const *idx, float *boxes, g4d_stream_t stream);
+
+/* Cell-bucketed ball query (csrc/ball_grid.hip): the same results as g4d_ball_query_msg_f32, bit for bit, for ANY input, with
+ * work proportional to the points NEAR each query instead of to N -- for large clouds with small balls (BASELINE configs 2, 5).
+ * `grid` is caller-provided device scratch of g4d_ball_grid_bytes(b, n) bytes: a per-cloud uniform grid (cell edge 1.01 * rmax)
+ * with the cloud counting-sorted into cell order.  A grid depends on (xyz, rmax) only: build it once, query it with any
+ * radii <= rmax as often as needed (e.g. on a side stream while FPS is still choosing the queries).
+ *   g4d_ball_query_grid_f32 = build (rmax = the largest radius) + query in one call. */
+size_t g4d_ball_grid_bytes(int b, int n);
+int g4d_ball_grid_build_f32(int b, int n, float rmax, const float *xyz, void *grid, g4d_stream_t stream);
+int g4d_ball_grid_query_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                            const float *xyz, int *const *idx, const void *grid, float grid_rmax, g4d_stream_t stream);
+int g4d_ball_query_grid_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                            const float *xyz, int *const *idx, void *grid, g4d_stream_t stream);
 
 /* group_points_kernel_launcher_fast (group_points_gpu.h:13-15): out[b,c,p,s] = points[b,c,idx[b,p,s]].
  * 64-bit offsets (the reference's int32 offsets wrap at 2^31 elements). */

@@ -82,6 +82,18 @@ int g4d_oracle_num_threads(void) {
 #endif
 }
 
+/* bench.py cpu_baseline: run the kernels on `n` OpenMP threads (n <= 0: leave unchanged); returns the previous setting */
+int g4d_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    const int prev = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return prev;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* sampling_gpu.cu:86-91  __update(): max of values, ties keep the lower slot's index. */
 static inline void fps_update(float *dists, int *dists_i, int idx1, int idx2) {
     const float v1 = dists[idx1], v2 = dists[idx2];

@@ -25,6 +25,8 @@ def bf16_round(a):
 
 
 BF16 = False  # set True (tests) to emulate the cfg3 bf16 path: conv operands rounded to bf16, everything else fp32
+BLAS = False  # set True (bench.py cpu_baseline) to contract the channels with a multi-threaded BLAS sgemm instead of einsum's
+              # single-threaded loop: same values to ~1e-6 (different summation order), the fair CPU timing of the 1x1 convolutions
 
 
 def shared_mlp(x, sd, prefix="", training=False, relu=None):
@@ -37,7 +39,11 @@ def shared_mlp(x, sd, prefix="", training=False, relu=None):
         w = w.reshape(w.shape[0], w.shape[1])
         if BF16:
             w, x = bf16_round(w), bf16_round(x)
-        y = np.einsum("oc,bcps->bops", w, x, dtype=F32).astype(F32)
+        if BLAS:
+            b_, c_, p_, s_ = x.shape
+            y = np.matmul(w, x.reshape(b_, c_, p_ * s_)).reshape(b_, w.shape[0], p_, s_)
+        else:
+            y = np.einsum("oc,bcps->bops", w, x, dtype=F32).astype(F32)
         bkey = f"{prefix}layer{i}.conv.bias"
         if bkey in sd:
             y = y + sd[bkey].astype(F32)[None, :, None, None]

@@ -109,6 +109,13 @@ def num_threads():
     return lib().g4d_oracle_num_threads()
 
 
+def set_threads(n):
+    """OpenMP threads of the C kernels (bench.py's cpu_baseline times 1 and all cores); returns the previous count."""
+    lib().g4d_oracle_set_threads.argtypes = [_I]
+    lib().g4d_oracle_set_threads.restype = _I
+    return lib().g4d_oracle_set_threads(int(n))
+
+
 def fps(xyz, npoint, keyed=False, return_temp=False):
     """furthest_point_sample (pointnet2_utils.py:10-36): xyz (B,N,3) -> idx (B,npoint) int32."""
     xyz, px = _f(xyz)
