@@ -93,7 +93,7 @@ class Pointnet2MSGSEG(nn.Module):
             grid = None
             if xyz.shape[1] >= fused.GRID_MIN_N:
                 grid = fused.build_ball_grid(xyz, max(g.radius for g in self.SA_modules[0].groupers))
-            for sa, (nx, ready) in zip(self.SA_modules, chain):
+            for sa, (nx, ready, _sidx) in zip(self.SA_modules, chain):   # `chain` (and the index buffers in it) lives until the loop ends
                 cur.wait_event(ready)
                 _, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1], new_xyz=nx, grid=grid)
                 grid = None

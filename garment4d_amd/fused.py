@@ -323,7 +323,10 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
     _pool_rows(h, rows // S, S, out, col0, pool == 1)
 
 
-OVERLAP_SAMPLING = os.environ.get("G4D_OVERLAP_SAMPLING", "1") != "0"  # encoder: FPS chain on a side stream (sampling_chain)
+# encoder: FPS chain on a side stream (sampling_chain).  OFF by default -- measured on MI355X / ROCm 7.2 (bench.py, cfg2): inside a
+# captured hipGraph the fork / join costs more than the overlap gains (single-batch latency 1.46 -> 1.57 ms, 16-batch throughput
+# 23.3k -> 10.8k frames/s: the runtime serialises graph branches through extra cross-stream dependencies); DESIGN.md section 5
+OVERLAP_SAMPLING = os.environ.get("G4D_OVERLAP_SAMPLING", "0") != "0"
 GRID_MIN_N = int(os.environ.get("G4D_BQ_GRID_MIN_N", "4096"))  # clouds at least this large go through the cell grid (csrc/ball_grid.hip)
 
 
@@ -406,8 +409,9 @@ def side_stream(device=None):
 def sampling_chain(xyz, npoints):
     """The FPS -> gather chain of every set-abstraction level, which depends on coordinates only (pointnet2_modules.py:32-35:
     level l samples the centroids of level l-1), issued on a SIDE stream: level l+1's sampling overlaps level l's ball query
-    and MLPs, and the first level's overlaps the ball-grid build.  Returns [(new_xyz_l, ready_event_l)]; the caller makes its
-    stream wait for event l before using new_xyz_l.  Works eagerly and under hipGraph capture (the side stream forks from and
+    and MLPs, and the first level's overlaps the ball-grid build.  Returns [(new_xyz_l, ready_event_l, idx_l)]; the caller makes
+    its stream wait for event l before using new_xyz_l and drops the tuples only after that (the buffers belong to the caller's
+    stream: freed earlier, the allocator could hand them out again while the side stream still writes them).  Works eagerly and under hipGraph capture (the side stream forks from and
     joins back into the capturing stream through the events); buffers are allocated by the CALLING stream, which outlives the use."""
     cur = torch.cuda.current_stream(xyz.device)
     B = xyz.shape[0]
@@ -422,7 +426,7 @@ def sampling_chain(xyz, npoints):
             fps_gather(src, m, sidx, nx)
             ev = torch.cuda.Event()
             ev.record(side)
-            out.append((nx, ev))
+            out.append((nx, ev, sidx))   # sidx rides along: the caller must keep it alive until its stream has waited for `ev`
             src = nx
     return out
 
