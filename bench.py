@@ -266,8 +266,11 @@ def cpu_worker(weights_npz, frames, start_at, with_lbs):
     xyz = syn.unit_cloud(frames, N_POINTS, seed=seed)
     betas, pose = syn.smpl_like_pose(frames, seed=seed)
     MO.encoder_forward(xyz[:1], sd)                                     # warm-up: page in, build nothing
-    while time.time() < start_at:
-        time.sleep(0.001)
+    open(os.path.join(os.path.dirname(weights_npz), f"ready.{os.getpid()}"), "w").close()
+    go = os.path.join(os.path.dirname(weights_npz), "go")
+    while not os.path.exists(go):                                       # common start: the parent releases everybody at once
+        time.sleep(0.002)
+    start_at = os.path.getmtime(go)
     t0 = time.time()
     for f in range(frames):
         MO.encoder_forward(xyz[f:f + 1], sd)
@@ -285,9 +288,12 @@ def cpu_frame_parallel(sd, workers, frames_each, with_lbs):
         wpath = os.path.join(td, "w.npz")
         np.savez(wpath, **sd)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-        start_at = time.time() + 4.0 + workers * 0.01                    # everybody has imported numpy and warmed up by then
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", wpath, str(frames_each), repr(start_at), str(int(with_lbs))],
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", wpath, str(frames_each), "0", str(int(with_lbs))],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(workers)]
+        deadline = time.time() + 120.0
+        while time.time() < deadline and sum(f.startswith("ready.") for f in os.listdir(td)) < workers:
+            time.sleep(0.05)                                             # every worker has imported numpy and run its warm-up frame
+        open(os.path.join(td, "go"), "w").close()
         res = []
         for p in procs:
             out, _ = p.communicate(timeout=300)
