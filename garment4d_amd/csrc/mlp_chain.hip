@@ -55,7 +55,7 @@ __device__ __forceinline__ void affine_t(const ChainLayer &L, int fq, f32x4 (&ac
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float y = acc[ct][mt][r] * sc[r] + sh[r];
+                float y = __builtin_fmaf(acc[ct][mt][r], sc[r], sh[r]);  // one v_fma_f32: packed mul + add pairs beside MFMAs stall the matrix pipe
                 if (L.relu) y = fmaxf(y, 0.f);
                 acc[ct][mt][r] = y;
             }
@@ -72,7 +72,7 @@ __device__ __forceinline__ void affine_r(const ChainLayer &L, int fi, f32x4 (&ac
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float y = acc[ct][mt][r] * sc + sh;
+                float y = __builtin_fmaf(acc[ct][mt][r], sc, sh);
                 if (L.relu) y = fmaxf(y, 0.f);
                 acc[ct][mt][r] = y;
             }
@@ -87,7 +87,27 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TOUT][MT]) {
         for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// first layer: the input is streamed from the loader, 16 columns per step
+// Weight fragments are streamed from L2 with explicit software prefetch.  A wave of the wide stacks runs alone on its SIMD
+// (173 VGPRs + 200 AGPRs), so nothing else hides an L2 round trip (500+ cycles under load): left to the compiler, a fragment
+// load was issued ~1 fragment (8 MFMAs = 256 cycles) ahead of its use -- `s_waitcnt vmcnt(1)` before almost every MFMA group.
+// Here fragment f + kWDepth is requested before the MFMAs of fragment f are issued (the empty asm with a memory clobber keeps
+// the compiler from sinking the load back down), i.e. kWDepth KB per wave stay in flight.
+constexpr int kWDepth = 6;
+
+__device__ __forceinline__ f32x4 load_wfrag(const ChainLayer &L, int ct, int ks, int lane) {
+    return *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
+}
+
+// the first kWDepth fragments of a chained layer (fragment f = ks * TOUT + ct), requested before the previous layer's epilogue
+template <int TIN, int TOUT>
+__device__ __forceinline__ void preload_ring(const ChainLayer &L, int lane, f32x4 (&ring)[kWDepth]) {
+#pragma unroll
+    for (int f = 0; f < kWDepth; ++f)
+        if (f < TIN * TOUT) ring[f] = load_wfrag(L, f % TOUT, f / TOUT, lane);
+}
+
+// first layer: the input is streamed from the loader, 16 columns per step; the weights AND the input fragment of step
+// ks + 1 are requested before the MFMAs of step ks
 template <int MODE, int TOUT, int MT, bool LAST>
 __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLayer &L, int lane, int row0, f32x4 (&acc)[TOUT][MT]) {
     const int fi = lane & 15, fq = lane >> 4;
@@ -96,8 +116,7 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
     for (int mt = 0; mt < MT; ++mt) ctx[mt] = make_ctx<MODE>(a, row0 + mt * 16 + fi);
     zero_acc<TOUT, MT>(acc);
     const int kst0 = (a.K + 15) >> 4;
-    for (int ks = 0; ks < kst0; ++ks) {
-        f32x4 b[MT];
+    auto load_b = [&](int ks, f32x4 (&b)[MT]) {
         const int k0 = ks * 16 + fq * 4;  // this lane's 4 consecutive input columns
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -122,37 +141,71 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
                 for (int e = 0; e < 4; ++e) b[mt][e] = load_elem<MODE>(a, ctx[mt], row0 + mt * 16 + fi, k0 + e);
             }
         }
+    };
+    f32x4 wn[TOUT], bn[MT];
 #pragma unroll
-        for (int ct = 0; ct < TOUT; ++ct) {
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
+    for (int ct = 0; ct < TOUT; ++ct) wn[ct] = load_wfrag(L, ct, 0, lane);
+    load_b(0, bn);
+    for (int ks = 0; ks < kst0; ++ks) {
+        f32x4 w[TOUT], b[MT];
+#pragma unroll
+        for (int ct = 0; ct < TOUT; ++ct) w[ct] = wn[ct];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = bn[mt];
+        if (ks + 1 < kst0) {  // wave-uniform
+#pragma unroll
+            for (int ct = 0; ct < TOUT; ++ct) wn[ct] = load_wfrag(L, ct, ks + 1, lane);
+            load_b(ks + 1, bn);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled across: the request above stays ahead of the MFMAs below
+        // consecutive MFMAs must not share an accumulator (40-cycle dependent latency vs 32-cycle issue): with one row tile per
+        // wave (MT = 1) two channel tiles are interleaved, with MT = 2 the two row tiles already alternate
+        constexpr int G = (MT == 1 && TOUT % 2 == 0) ? 2 : 1;
+#pragma unroll
+        for (int ct = 0; ct < TOUT; ct += G)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = LAST ? mfma4(b[mt][e], w[e], acc[ct][mt]) : mfma4(w[e], b[mt][e], acc[ct][mt]);
-        }
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[ct + g][mt] = LAST ? mfma4(b[mt][e], w[ct + g][e], acc[ct + g][mt]) : mfma4(w[ct + g][e], b[mt][e], acc[ct + g][mt]);
     }
-    if (LAST) affine_r<TOUT, MT>(L, fi, acc);
-    else affine_t<TOUT, MT>(L, fq, acc);
 }
 
-// later layers: the previous layer's accumulators are the operand fragments
+// later layers: the previous layer's accumulators are the operand fragments; `ring` holds weight fragments 0 .. kWDepth-1
 template <int TIN, int TOUT, int MT, bool LAST>
-__device__ __forceinline__ void chain_layer(const ChainLayer &L, int lane, const f32x4 (&hin)[TIN][MT], f32x4 (&acc)[TOUT][MT]) {
-    const int fi = lane & 15, fq = lane >> 4;
+__device__ __forceinline__ void chain_layer(const ChainLayer &L, int lane, const f32x4 (&hin)[TIN][MT], f32x4 (&acc)[TOUT][MT],
+                                            f32x4 (&ring)[kWDepth]) {
     zero_acc<TOUT, MT>(acc);
+    constexpr int F = TIN * TOUT;
+    constexpr int G = (MT == 1 && TOUT % 2 == 0) ? 2 : 1;  // channel tiles interleaved per step (see first_layer)
+    static_assert(kWDepth % 2 == 0, "the ring is consumed G fragments at a time");
 #pragma unroll
-    for (int ks = 0; ks < TIN; ++ks)
+    for (int f = 0; f < F; f += G) {
+        const int ks = f / TOUT, ct = f % TOUT;
+        f32x4 w[G];
 #pragma unroll
-        for (int ct = 0; ct < TOUT; ++ct) {
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
+        for (int g = 0; g < G; ++g) {
+            w[g] = ring[(f + g) % kWDepth];
+            if (f + g + kWDepth < F) ring[(f + g) % kWDepth] = load_wfrag(L, (f + g + kWDepth) % TOUT, (f + g + kWDepth) / TOUT, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[ct][mt] = LAST ? mfma4(hin[ks][mt][e], w[e], acc[ct][mt]) : mfma4(w[e], hin[ks][mt][e], acc[ct][mt]);
-        }
-    if (LAST) affine_r<TOUT, MT>(L, fi, acc);
-    else affine_t<TOUT, MT>(L, fq, acc);
+                    acc[ct + g][mt] = LAST ? mfma4(hin[ks][mt][e], w[g][e], acc[ct + g][mt]) : mfma4(w[g][e], hin[ks][mt][e], acc[ct + g][mt]);
+    }
+}
+
+// epilogue of a layer whose accumulators feed the next one (transposed) or the pooling / stores (row-major)
+template <int TOUT, int MT, bool LAST>
+__device__ __forceinline__ void affine(const ChainLayer &L, int lane, f32x4 (&acc)[TOUT][MT]) {
+    if (LAST) affine_r<TOUT, MT>(L, lane & 15, acc);
+    else affine_t<TOUT, MT>(L, lane >> 4, acc);
 }
 
 // row-major output tile: acc[ct][mt][r] = out[row0 + 16 mt + 4 fq + r][16 ct + fi]; pool over S consecutive rows or store
@@ -269,28 +322,39 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = (blockIdx.x * 4 + wave) * (16 * MT);
     f32x4 h1[T1][MT];
+    f32x4 ring[kWDepth];  // weight fragments in flight for the next chained layer (requested BEFORE the current layer's epilogue)
     if constexpr (T2 == 0) {
         first_layer<MODE, T1, MT, true>(a, s.layer[0], lane, row0, h1);
+        affine<T1, MT, true>(s.layer[0], lane, h1);
         finish<T1, MT>(a, s.layer[0].cout, lane, wave, row0, h1, xch);
     } else {
         first_layer<MODE, T1, MT, false>(a, s.layer[0], lane, row0, h1);
+        preload_ring<T1, T2>(s.layer[1], lane, ring);
+        affine<T1, MT, false>(s.layer[0], lane, h1);
         if (s.tap_layer == 0) tap_store<T1, MT>(s, s.layer[0].cout, lane, row0, h1);
         f32x4 h2[T2][MT];
         if constexpr (T3 == 0) {
-            chain_layer<T1, T2, MT, true>(s.layer[1], lane, h1, h2);
+            chain_layer<T1, T2, MT, true>(s.layer[1], lane, h1, h2, ring);
+            affine<T2, MT, true>(s.layer[1], lane, h2);
             finish<T2, MT>(a, s.layer[1].cout, lane, wave, row0, h2, xch);
         } else {
-            chain_layer<T1, T2, MT, false>(s.layer[1], lane, h1, h2);
+            chain_layer<T1, T2, MT, false>(s.layer[1], lane, h1, h2, ring);
+            preload_ring<T2, T3>(s.layer[2], lane, ring);
+            affine<T2, MT, false>(s.layer[1], lane, h2);
             if (s.tap_layer == 1) tap_store<T2, MT>(s, s.layer[1].cout, lane, row0, h2);
             f32x4 h3[T3][MT];
             if constexpr (T4 == 0) {
-                chain_layer<T2, T3, MT, true>(s.layer[2], lane, h2, h3);
+                chain_layer<T2, T3, MT, true>(s.layer[2], lane, h2, h3, ring);
+                affine<T3, MT, true>(s.layer[2], lane, h3);
                 finish<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
             } else {
-                chain_layer<T2, T3, MT, false>(s.layer[2], lane, h2, h3);
+                chain_layer<T2, T3, MT, false>(s.layer[2], lane, h2, h3, ring);
+                preload_ring<T3, T4>(s.layer[3], lane, ring);
+                affine<T3, MT, false>(s.layer[2], lane, h3);
                 if (s.tap_layer == 2) tap_store<T3, MT>(s, s.layer[2].cout, lane, row0, h3);
                 f32x4 h4[T4][MT];
-                chain_layer<T3, T4, MT, true>(s.layer[3], lane, h3, h4);
+                chain_layer<T3, T4, MT, true>(s.layer[3], lane, h3, h4, ring);
+                affine<T4, MT, true>(s.layer[3], lane, h4);
                 finish<T4, MT>(a, s.layer[3].cout, lane, wave, row0, h4, xch);
             }
         }

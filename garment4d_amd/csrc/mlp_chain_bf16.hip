@@ -57,7 +57,7 @@ __device__ __forceinline__ void affine_t_h(const ChainLayerH &L, int g, f32x4 (&
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float y = acc[ct][mt][r] * sc[r] + sh[r];
+                float y = __builtin_fmaf(acc[ct][mt][r], sc[r], sh[r]);
                 if (L.relu) y = fmaxf(y, 0.f);
                 acc[ct][mt][r] = y;
             }
@@ -73,7 +73,7 @@ __device__ __forceinline__ void affine_r_h(const ChainLayerH &L, int fi, f32x4 (
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float y = acc[ct][mt][r] * sc + sh;
+                float y = __builtin_fmaf(acc[ct][mt][r], sc, sh);
                 if (L.relu) y = fmaxf(y, 0.f);
                 acc[ct][mt][r] = y;
             }

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(512) mlp_stack_kernel(const StackArgs s) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float y = acc[mt][r] * sc + sh;
+                    float y = __builtin_fmaf(acc[mt][r], sc, sh);
                     if (L.relu) y = fmaxf(y, 0.f);
                     acc[mt][r] = y;
                 }

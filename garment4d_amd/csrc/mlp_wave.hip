@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256, 3) mlp_wave_kernel(const WaveArgs s) {
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float y = acc[mt][ct][r] * sc + sh;
+                        float y = __builtin_fmaf(acc[mt][ct][r], sc, sh);
                         if (L.relu) y = fmaxf(y, 0.f);
                         acc[mt][ct][r] = y;
                     }
