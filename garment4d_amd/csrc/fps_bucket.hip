@@ -4,8 +4,9 @@
 // In round j only points closer to the new sample than their current min-distance change, and every min-distance
 // is <= g_j, the value of the sample just selected (the global max).  The cloud is sorted along a Morton curve
 // (bitonic sort in LDS, once per launch) and cut into buckets of 64 consecutive points -- one VGPR "slot" of one
-// wave, buckets dealt round-robin to the 16 waves so that the buckets near a sample sit in different waves.  Each
-// wave keeps the bounding boxes of its buckets lane-distributed.  A round is then
+// wave; a wave owns P CONSECUTIVE buckets of the Morton order, so the ~14 buckets a round touches sit in 2-3 waves and
+// the other waves only republish their cached candidate (dealing them round-robin makes ~14 waves pay the fixed
+// arg-max cost every round: 0.81 instead of 0.75 us per round).  Each wave keeps the boxes of its buckets lane-distributed.  A round is then
 //
 //   1. lane i tests box i against the new sample: d_box = dist2<FM>(gx, gy, gz) with gx = the gap between the sample
 //      and the box along x, ... evaluated with the SAME fp32 operations (same contraction shape FM) as the point distance.
@@ -98,7 +99,7 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
 template <int W, int P, int FM>
-__global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
+__global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all, int *__restrict__ idx_all) {
     constexpr int T = 64 * W, NPAD = T * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -167,7 +168,10 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
     float px[P], py[P], pz[P], md[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int q = (i * W + wave) * 64 + lane;
+        // buckets are dealt to the waves in runs of `deal` consecutive (Morton-adjacent) buckets: slot i of wave w holds bucket
+        // ((i / deal) * W + w) * deal + i % deal.  deal = 1 spreads the ~14 buckets a round touches over ~14 waves (every one of
+        // them pays the fixed arg-max cost), deal = P keeps them in 2-3 waves while the others republish their cached candidate
+        const int q = (((i / deal) * W + wave) * deal + (i % deal)) * 64 + lane;
         const unsigned long long key = keys[q];
         pk[i] = (key == ~0ull) ? -1 : (int)(unsigned)key;
     }
@@ -298,7 +302,10 @@ static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float
     auto kern = fps_bucket_kernel<W, P, FM>;
     static unsigned long long attr_done = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32(bucketed)")) return rc;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
+    // measured at N = 8192, M = 1024, B = 8 (scripts/time_fps.py): deal 1 / 2 / 4 / 8 -> 0.812 / 0.783 / 0.757 / 0.748 us per round
+    static const int deal_env = getenv("G4D_FPS_DEAL") ? atoi(getenv("G4D_FPS_DEAL")) : 0;  // tuning hook: 1 | 2 | 4 | ... | P; 0 = P
+    const int deal = (deal_env >= 1 && deal_env <= P && P % deal_env == 0) ? deal_env : P;
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal, xyz, temp, idx);
     return check_launch("g4d_fps_f32(bucketed)");
 }
 
