@@ -106,40 +106,73 @@ __device__ __forceinline__ void preload_ring(const ChainLayer &L, int lane, f32x
         if (f < TIN * TOUT) ring[f] = load_wfrag(L, f % TOUT, f / TOUT, lane);
 }
 
-// first layer: the input is streamed from the loader, 16 columns per step; the weights AND the input fragment of step
-// ks + 1 are requested before the MFMAs of step ks
+#ifdef G4D_CHAIN_DEBUG
+__device__ long long g_chain_dbg[8 * 4096];  // per wave (first 4096): 8 clock stamps (scripts/dbg_chain_phases.py)
+#define G4D_CSTAMP(i) { const int gw_ = blockIdx.x * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && gw_ < 4096) g_chain_dbg[gw_ * 8 + (i)] = (long long)__builtin_readcyclecounter(); }
+#else
+#define G4D_CSTAMP(i)
+#endif
+
+// First layer: the input is streamed from the loader, 16 columns (one k-step) at a time.
+//
+// In-kernel cycle stamps and the SQ counters showed this phase bound by INSTRUCTION issue / fetch, not by MFMA or memory:
+// ~6 non-MFMA instructions per MFMA at ~14 cycles each (straight-line code, executed once per wave, fetched cold), most of
+// them the per-lane, per-row-tile branching of the loader.  So:
+//   * rows past the end are CLAMPED to the last row instead of masked -- an output row depends on its own input row only,
+//     and rows >= `rows` are never stored or pooled into a stored group -- which removes every `valid` branch;
+//   * whether a k-step can use the 16-byte vector path is decided once per step for the whole wave (all 16 columns inside
+//     one source segment), not per lane: the k loop has ONE wave-uniform branch, the common body is base pointer + offset;
+//   * weights and inputs of step ks + 1 are requested before the MFMAs of step ks.
 template <int MODE, int TOUT, int MT, bool LAST>
 __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLayer &L, int lane, int row0, f32x4 (&acc)[TOUT][MT]) {
     const int fi = lane & 15, fq = lane >> 4;
     RowCtx<MODE> ctx[MT];
+    int rowc[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) ctx[mt] = make_ctx<MODE>(a, row0 + mt * 16 + fi);
+    for (int mt = 0; mt < MT; ++mt) {
+        rowc[mt] = min(row0 + mt * 16 + fi, a.rows - 1);
+        ctx[mt] = make_ctx<MODE>(a, rowc[mt]);
+    }
     zero_acc<TOUT, MT>(acc);
     const int kst0 = (a.K + 15) >> 4;
+    // segment A: columns [a_lo, a_hi) come from pa[mt] + column (GROUP: the feature row behind the 3 xyz columns; DIRECT: the
+    // row; INTERP: the three known rows, blended); segment B (INTERP only): columns [C2, K) from the skip row
+    const float *pa[MT], *pa1[MT], *pa2[MT], *pb[MT];
+    int a_lo, a_hi, b_lo = 0, b_hi = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        pa1[mt] = pa2[mt] = pb[mt] = nullptr;
+        if constexpr (MODE == LOAD_GROUP) pa[mt] = (a.feats ? a.feats : a.xyz) + ctx[mt].pt_base * a.C - (a.use_xyz ? 3 : 0);  // xyz-only stacks never take the fast path
+        else if constexpr (MODE == LOAD_DIRECT) pa[mt] = a.X + (size_t)rowc[mt] * a.ldx;
+        else { pa[mt] = a.known_feats + ctx[mt].k0; pa1[mt] = a.known_feats + ctx[mt].k1; pa2[mt] = a.known_feats + ctx[mt].k2;
+               pb[mt] = a.skip + ctx[mt].sk - a.C2; }
+    }
+    if constexpr (MODE == LOAD_GROUP) { a_lo = a.use_xyz ? 3 : 0; a_hi = a.K; }
+    else if constexpr (MODE == LOAD_DIRECT) { a_lo = 0; a_hi = a.K; }
+    else { a_lo = 0; a_hi = a.C2; b_lo = a.C2; b_hi = a.K; }
     auto load_b = [&](int ks, f32x4 (&b)[MT]) {
-        const int k0 = ks * 16 + fq * 4;  // this lane's 4 consecutive input columns
+        const int c0 = ks * 16;                       // wave-uniform: the step's 16 columns are [c0, c0 + 16)
+        const int k0 = c0 + fq * 4;                   // this lane's 4 consecutive columns
+        if (c0 >= a_lo && c0 + 16 <= a_hi) {          // wave-uniform fast path, segment A
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            // 4 consecutive columns of one source row = ONE 16-byte load (4-byte aligned) whenever they do not straddle the
-            // [xyz | features] seam or the end of the row
-            if (MODE == LOAD_GROUP && ctx[mt].valid && a.use_xyz && k0 >= 3 && k0 + 3 < a.K) {
-                b[mt] = *reinterpret_cast<const f32x4u *>(a.feats + ctx[mt].pt_base * a.C + (k0 - 3));
-            } else if (MODE == LOAD_GROUP && ctx[mt].valid && !a.use_xyz && k0 + 3 < a.K) {
-                b[mt] = *reinterpret_cast<const f32x4u *>(a.feats + ctx[mt].pt_base * a.C + k0);
-            } else if (MODE == LOAD_DIRECT && ctx[mt].valid && k0 + 3 < a.K) {
-                b[mt] = *reinterpret_cast<const f32x4u *>(a.X + (size_t)(row0 + mt * 16 + fi) * a.ldx + k0);
-            } else if (MODE == LOAD_INTERP && ctx[mt].valid && k0 + 3 < a.C2) {  // three_interpolate of 4 consecutive channels
-                const f32x4 f0 = *reinterpret_cast<const f32x4u *>(a.known_feats + ctx[mt].k0 + k0);
-                const f32x4 f1 = *reinterpret_cast<const f32x4u *>(a.known_feats + ctx[mt].k1 + k0);
-                const f32x4 f2 = *reinterpret_cast<const f32x4u *>(a.known_feats + ctx[mt].k2 + k0);
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (MODE == LOAD_INTERP) {  // three_interpolate of 4 consecutive channels, load_elem's operation order
+                    const f32x4 f0 = *reinterpret_cast<const f32x4u *>(pa[mt] + k0), f1 = *reinterpret_cast<const f32x4u *>(pa1[mt] + k0),
+                                f2 = *reinterpret_cast<const f32x4u *>(pa2[mt] + k0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[mt][e] = ctx[mt].w0 * f0[e] + ctx[mt].w1 * f1[e] + ctx[mt].w2 * f2[e];  // load_elem's order
-            } else if (MODE == LOAD_INTERP && ctx[mt].valid && k0 >= a.C2 && k0 + 3 < a.K) {
-                b[mt] = *reinterpret_cast<const f32x4u *>(a.skip + ctx[mt].sk + (k0 - a.C2));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b[mt][e] = load_elem<MODE>(a, ctx[mt], row0 + mt * 16 + fi, k0 + e);
+                    for (int e = 0; e < 4; ++e) b[mt][e] = ctx[mt].w0 * f0[e] + ctx[mt].w1 * f1[e] + ctx[mt].w2 * f2[e];
+                } else {
+                    b[mt] = *reinterpret_cast<const f32x4u *>(pa[mt] + k0);
+                }
             }
+        } else if (MODE == LOAD_INTERP && c0 >= b_lo && c0 + 16 <= b_hi) {   // wave-uniform fast path, segment B
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[mt] = *reinterpret_cast<const f32x4u *>(pb[mt] + k0);
+        } else {                                      // a step that straddles a seam or the end of the row: element by element
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[mt][e] = load_elem<MODE>(a, ctx[mt], rowc[mt], k0 + e);
         }
     };
     f32x4 wn[TOUT], bn[MT];
@@ -157,7 +190,7 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
             for (int ct = 0; ct < TOUT; ++ct) wn[ct] = load_wfrag(L, ct, ks + 1, lane);
             load_b(ks + 1, bn);
         }
-        __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled across: the request above stays ahead of the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled across: the requests above stay ahead of the MFMAs below
         // consecutive MFMAs must not share an accumulator (40-cycle dependent latency vs 32-cycle issue): with one row tile per
         // wave (MT = 1) two channel tiles are interleaved, with MT = 2 the two row tiles already alternate
         constexpr int G = (MT == 1 && TOUT % 2 == 0) ? 2 : 1;
@@ -208,93 +241,101 @@ __device__ __forceinline__ void affine(const ChainLayer &L, int lane, f32x4 (&ac
     else affine_t<TOUT, MT>(L, lane >> 4, acc);
 }
 
-// row-major output tile: acc[ct][mt][r] = out[row0 + 16 mt + 4 fq + r][16 ct + fi]; pool over S consecutive rows or store
-template <int TOUT, int MT>
-__device__ __forceinline__ void finish(const LinearArgs &a, int cout, int lane, int wave, int row0, f32x4 (&acc)[TOUT][MT], float *xch) {
+// One row-major output tile, channel tile `ct` (may be a run-time value): t[mt][r] = out[row0 + 16 mt + 4 fq + r][16 ct + fi].
+// Stores it, or pools it over S consecutive rows; when a pooling group spans several waves (S > 16 MT) the wave's partial goes
+// to xch[wave][channel] and finish_cross() completes the groups after the last tile.
+template <int MT>
+__device__ __forceinline__ void finish_tile(const LinearArgs &a, int cout, int lane, int wave, int row0, int ct, const f32x4 (&t)[MT],
+                                            float *xch, int xld) {
     const int fi = lane & 15, fq = lane >> 4;
+    const int ch = ct * 16 + fi;
+    const bool ch_ok = ch < cout;
     if (a.pool == 0) {
 #pragma unroll
-        for (int ct = 0; ct < TOUT; ++ct) {
-            const int ch = ct * 16 + fi;
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + mt * 16 + fq * 4 + r;
-                    if (ch < cout && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = acc[ct][mt][r];
-                }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + mt * 16 + fq * 4 + r;
+                if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = t[mt][r];
+            }
         return;
     }
     const bool is_max = a.pool == 1;
     const float inv = is_max ? 1.f : 1.f / (float)a.S;
     const int S = a.S;
+    float v[MT];
 #pragma unroll
-    for (int ct = 0; ct < TOUT; ++ct) {
-        const int ch = ct * 16 + fi;
-        const bool ch_ok = ch < cout;
-        float v[MT];
+    for (int mt = 0; mt < MT; ++mt)
+        v[mt] = is_max ? fmaxf(fmaxf(t[mt][0], t[mt][1]), fmaxf(t[mt][2], t[mt][3])) : ((t[mt][0] + t[mt][1]) + (t[mt][2] + t[mt][3]));
+    if (S < 16) {  // 4 | 8 rows: 4 | 2 groups per tile
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            v[mt] = is_max ? fmaxf(fmaxf(acc[ct][mt][0], acc[ct][mt][1]), fmaxf(acc[ct][mt][2], acc[ct][mt][3]))
-                           : ((acc[ct][mt][0] + acc[ct][mt][1]) + (acc[ct][mt][2] + acc[ct][mt][3]));
-        if (S < 16) {  // 4 | 8 rows: 4 | 2 groups per tile
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float x = v[mt];
-                if (S == 8) {
-                    const float y = __shfl_xor(x, 16);
-                    x = is_max ? fmaxf(x, y) : x + y;
-                }
-                const int first_row = row0 + mt * 16 + (S == 8 ? (fq >> 1) * 8 : fq * 4);
-                const bool writer = S == 8 ? (fq & 1) == 0 : true;
-                if (writer && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
+        for (int mt = 0; mt < MT; ++mt) {
+            float x = v[mt];
+            if (S == 8) {
+                const float y = __shfl_xor(x, 16);
+                x = is_max ? fmaxf(x, y) : x + y;
             }
-            continue;
+            const int first_row = row0 + mt * 16 + (S == 8 ? (fq >> 1) * 8 : fq * 4);
+            const bool writer = S == 8 ? (fq & 1) == 0 : true;
+            if (writer && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {  // the 16 rows of a tile: across the four fq groups
-            const float y = __shfl_xor(v[mt], 16);
-            v[mt] = is_max ? fmaxf(v[mt], y) : v[mt] + y;
-            const float z = __shfl_xor(v[mt], 32);
-            v[mt] = is_max ? fmaxf(v[mt], z) : v[mt] + z;
-        }
-        constexpr int R = 16 * MT;  // rows per wave
-        if (S <= R) {
-            const int tiles_per_group = S >> 4;  // 1 | 2 | 4
-#pragma unroll
-            for (int g = 0; g < MT; ++g) {
-                if (g * tiles_per_group >= MT) break;
-                float x = v[g * tiles_per_group];
-#pragma unroll
-                for (int t = 1; t < MT; ++t)
-                    if (t < tiles_per_group) x = is_max ? fmaxf(x, v[g * tiles_per_group + t]) : x + v[g * tiles_per_group + t];
-                const int first_row = row0 + g * S;
-                if (lane < 16 && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
-            }
-        } else {  // a group spans S / R consecutive waves of the workgroup: partials meet in LDS
-            float x = v[0];
-#pragma unroll
-            for (int t = 1; t < MT; ++t) x = is_max ? fmaxf(x, v[t]) : x + v[t];
-            if (lane < 16) xch[wave * (TOUT * 16) + ch] = x;
-        }
+        return;
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {  // the 16 rows of a tile: across the four fq groups
+        const float y = __shfl_xor(v[mt], 16);
+        v[mt] = is_max ? fmaxf(v[mt], y) : v[mt] + y;
+        const float z = __shfl_xor(v[mt], 32);
+        v[mt] = is_max ? fmaxf(v[mt], z) : v[mt] + z;
+    }
+    constexpr int R = 16 * MT;  // rows per wave
+    if (S <= R) {
+        const int tiles_per_group = S >> 4;  // 1 | 2 | 4
+#pragma unroll
+        for (int g = 0; g < MT; ++g) {
+            if (g * tiles_per_group >= MT) break;
+            float x = v[g * tiles_per_group];
+#pragma unroll
+            for (int tt = 1; tt < MT; ++tt)
+                if (tt < tiles_per_group) x = is_max ? fmaxf(x, v[g * tiles_per_group + tt]) : x + v[g * tiles_per_group + tt];
+            const int first_row = row0 + g * S;
+            if (lane < 16 && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
+        }
+    } else {  // a group spans S / R consecutive waves of the workgroup: partials meet in LDS
+        float x = v[0];
+#pragma unroll
+        for (int tt = 1; tt < MT; ++tt) x = is_max ? fmaxf(x, v[tt]) : x + v[tt];
+        if (lane < 16) xch[wave * xld + ch] = x;
+    }
+}
+
+// second half of the pooling when a group spans waves; wave-uniform, every wave of the workgroup calls it
+template <int MT>
+__device__ __forceinline__ void finish_cross(const LinearArgs &a, int cout, int lane, int wave, int row0, const float *xch, int xld) {
     constexpr int R = 16 * MT;
-    if (a.pool != 0 && S > R) {  // wave-uniform; every wave of the workgroup takes this branch
-        __syncthreads();
-        const int span = S / R;  // 2 | 4 waves per group
-        if ((wave % span) == 0) {
-            const int first_row = row0;
-            for (int ch = lane; ch < TOUT * 16; ch += 64) {
-                float x = xch[wave * (TOUT * 16) + ch];
-                for (int w = 1; w < span; ++w) {
-                    const float y = xch[(wave + w) * (TOUT * 16) + ch];
-                    x = is_max ? fmaxf(x, y) : x + y;
-                }
-                if (ch < cout && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
+    if (a.pool == 0 || a.S <= R) return;
+    const bool is_max = a.pool == 1;
+    const float inv = is_max ? 1.f : 1.f / (float)a.S;
+    __syncthreads();
+    const int span = a.S / R;  // 2 | 4 waves per group
+    if ((wave % span) == 0) {
+        for (int ch = lane; ch < xld; ch += 64) {
+            float x = xch[wave * xld + ch];
+            for (int w = 1; w < span; ++w) {
+                const float y = xch[(wave + w) * xld + ch];
+                x = is_max ? fmaxf(x, y) : x + y;
             }
+            if (ch < cout && row0 < a.rows) a.out[(size_t)(row0 / a.S) * a.ldo + a.col0 + ch] = x * inv;
         }
     }
+}
+
+// whole row-major tile set of a single-layer launch
+template <int TOUT, int MT>
+__device__ __forceinline__ void finish(const LinearArgs &a, int cout, int lane, int wave, int row0, f32x4 (&acc)[TOUT][MT], float *xch) {
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct) finish_tile<MT>(a, cout, lane, wave, row0, ct, acc[ct], xch, TOUT * 16);
+    finish_cross<MT>(a, cout, lane, wave, row0, xch, TOUT * 16);
 }
 
 // hidden-layer tap: the transposed tile holds out[row = 16 mt + fi][channels 16 ct + 4 fq .. + 3]
@@ -321,30 +362,36 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = (blockIdx.x * 4 + wave) * (16 * MT);
+    G4D_CSTAMP(0)
     f32x4 h1[T1][MT];
     f32x4 ring[kWDepth];  // weight fragments in flight for the next chained layer (requested BEFORE the current layer's epilogue)
     if constexpr (T2 == 0) {
         first_layer<MODE, T1, MT, true>(a, s.layer[0], lane, row0, h1);
+        G4D_CSTAMP(1)
         affine<T1, MT, true>(s.layer[0], lane, h1);
         finish<T1, MT>(a, s.layer[0].cout, lane, wave, row0, h1, xch);
     } else {
         first_layer<MODE, T1, MT, false>(a, s.layer[0], lane, row0, h1);
+        G4D_CSTAMP(1)
         preload_ring<T1, T2>(s.layer[1], lane, ring);
         affine<T1, MT, false>(s.layer[0], lane, h1);
         if (s.tap_layer == 0) tap_store<T1, MT>(s, s.layer[0].cout, lane, row0, h1);
         f32x4 h2[T2][MT];
         if constexpr (T3 == 0) {
             chain_layer<T1, T2, MT, true>(s.layer[1], lane, h1, h2, ring);
+            G4D_CSTAMP(3)
             affine<T2, MT, true>(s.layer[1], lane, h2);
             finish<T2, MT>(a, s.layer[1].cout, lane, wave, row0, h2, xch);
         } else {
             chain_layer<T1, T2, MT, false>(s.layer[1], lane, h1, h2, ring);
+            G4D_CSTAMP(2)
             preload_ring<T2, T3>(s.layer[2], lane, ring);
             affine<T2, MT, false>(s.layer[1], lane, h2);
             if (s.tap_layer == 1) tap_store<T2, MT>(s, s.layer[1].cout, lane, row0, h2);
             f32x4 h3[T3][MT];
             if constexpr (T4 == 0) {
                 chain_layer<T2, T3, MT, true>(s.layer[2], lane, h2, h3, ring);
+                G4D_CSTAMP(3)
                 affine<T3, MT, true>(s.layer[2], lane, h3);
                 finish<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
             } else {
@@ -354,11 +401,13 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
                 if (s.tap_layer == 2) tap_store<T3, MT>(s, s.layer[2].cout, lane, row0, h3);
                 f32x4 h4[T4][MT];
                 chain_layer<T3, T4, MT, true>(s.layer[3], lane, h3, h4, ring);
+                G4D_CSTAMP(3)
                 affine<T4, MT, true>(s.layer[3], lane, h4);
                 finish<T4, MT>(a, s.layer[3].cout, lane, wave, row0, h4, xch);
             }
         }
     }
+    G4D_CSTAMP(4)
 }
 
 template <int T1, int T2, int T3, int T4, int MT>
@@ -381,6 +430,12 @@ static int chain_key(int nlayers, const int *Cout) {
     for (int l = 0; l < 4; ++l) key = key * 100 + (l < nlayers ? (Cout[l] + 15) / 16 : 0);
     return key;
 }
+
+#ifdef G4D_CHAIN_DEBUG
+extern "C" int g4d_chain_debug_read(long long *host_out) {  // 8 x 4096 cycle stamps of the last launch
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g4d::g_chain_dbg), sizeof(long long) * 8 * 4096);
+}
+#endif
 
 extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
     switch (chain_key(nlayers, Cout)) {
