@@ -62,6 +62,7 @@ SIGNATURES = {
     "g4d_segment_take_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_vertex_normals_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_spmm_axpy_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _F, _vp, _vp],
+    "g4d_jacobi_smooth_f32": [_I, _I, _I, _I, _F, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_gather_rows_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_lbs_shape_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp],
     "g4d_joint_regress_f32": [_I, _I, _I, _vp, _I, _vp, _vp, _vp],

@@ -100,6 +100,75 @@ __global__ void __launch_bounds__(256) spmm_axpy_rows_kernel(long long rows, int
         if (c0 + j < c) out[(size_t)row * c + c0 + j] = self[j] + coeff * acc[j];
 }
 
+// ALL `iters` Jacobi steps  S <- S + coeff * (adj . S)  of the garment-weight smoothing (mesh_encoder.py:385-390: 100 torch.spmm
+// + add round trips through HBM in the reference) in ONE launch: a workgroup owns a (frame, 4-column slab) -- the (vg x 4) slab
+// lives in LDS, double buffered, for the whole iteration; a thread owns vg / 1024 vertices and keeps their adjacency rows
+// (column, value pairs, <= kJDeg each: a quad mesh has 4-7 incl. the diagonal) in registers, so a step touches no global memory:
+// kJDeg 16-byte LDS gathers + FMAs per vertex, one barrier.  HBM traffic = the slab once in, once out (2 * 4 * vg * c bytes per
+// frame instead of 100 x that); arithmetic order = spmm_axpy_rows_kernel's (acc in CSR order, then self + coeff * acc), so the
+// result is bit-identical to the step-by-step route.
+constexpr int kJThreads = 1024, kJCols = 4, kJDeg = 8, kJVerts = 5;  // up to 5 * 1024 = 5120 vertices per workgroup
+
+__global__ void __launch_bounds__(kJThreads) jacobi_smooth_kernel(int vg, int c, int iters, float coeff, const float *__restrict__ S,
+                                                                 const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                                                 const float *__restrict__ vals, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float jbuf[];  // [2][vg][4]
+    const int t = threadIdx.x;
+    const int slabs = (c + kJCols - 1) / kJCols;
+    const int f = blockIdx.x / slabs, c0 = (blockIdx.x - f * slabs) * kJCols;
+    const float *src = S + (size_t)f * vg * c;
+    float *dst = out + (size_t)f * vg * c;
+    float4 *cur = reinterpret_cast<float4 *>(jbuf), *nxt = cur + vg;
+    // adjacency rows of the owned vertices -> registers (vertex v = t + i * 1024)
+    int col[kJVerts][kJDeg];
+    float val[kJVerts][kJDeg];
+#pragma unroll
+    for (int i = 0; i < kJVerts; ++i) {
+        const int v = t + i * kJThreads;
+        const int beg = v < vg ? rowptr[v] : 0, end = v < vg ? rowptr[v + 1] : 0;
+#pragma unroll
+        for (int e = 0; e < kJDeg; ++e) {
+            const bool ok = beg + e < end;
+            col[i][e] = ok ? colidx[beg + e] : 0;   // padding entries: value 0 at column 0 (adds +0 * x: x + 0.0 * y keeps x bit for bit
+            val[i][e] = ok ? vals[beg + e] : 0.f;   //  unless y is inf / NaN -- weights are finite)
+        }
+        if (v < vg) {
+            float4 x;
+            x.x = c0 + 0 < c ? src[(size_t)v * c + c0 + 0] : 0.f; x.y = c0 + 1 < c ? src[(size_t)v * c + c0 + 1] : 0.f;
+            x.z = c0 + 2 < c ? src[(size_t)v * c + c0 + 2] : 0.f; x.w = c0 + 3 < c ? src[(size_t)v * c + c0 + 3] : 0.f;
+            cur[v] = x;
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < kJVerts; ++i) {
+            const int v = t + i * kJThreads;
+            if (v >= vg) break;
+            float4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int deg = rowptr[v + 1] - rowptr[v];  // L1-resident; only the loop bound, the entries are in registers
+#pragma unroll
+            for (int e = 0; e < kJDeg; ++e) {
+                if (e >= deg) break;
+                const float4 y = cur[col[i][e]];
+                const float a = val[i][e];
+                acc.x += a * y.x; acc.y += a * y.y; acc.z += a * y.z; acc.w += a * y.w;
+            }
+            const float4 self = cur[v];
+            nxt[v] = make_float4(self.x + coeff * acc.x, self.y + coeff * acc.y, self.z + coeff * acc.z, self.w + coeff * acc.w);
+        }
+        __syncthreads();
+        float4 *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    for (int v = t; v < vg; v += kJThreads) {
+        const float4 x = cur[v];
+        if (c0 + 0 < c) dst[(size_t)v * c + c0 + 0] = x.x;
+        if (c0 + 1 < c) dst[(size_t)v * c + c0 + 1] = x.y;
+        if (c0 + 2 < c) dst[(size_t)v * c + c0 + 2] = x.z;
+        if (c0 + 3 < c) dst[(size_t)v * c + c0 + 3] = x.w;
+    }
+}
+
 }  // namespace g4d
 
 using namespace g4d;
@@ -132,4 +201,26 @@ extern "C" int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S,
     hipLaunchKernelGGL(spmm_axpy_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows,
                        vg, c, S, rowptr, colidx, vals, coeff, out);
     return check_launch("g4d_spmm_axpy_rows_f32");
+}
+
+// All `iters` smoothing steps in one launch (see jacobi_smooth_kernel).  Requirements: vg <= 5120 and every adjacency row holds
+// <= 8 entries (checked on the HOST copy `max_row_entries` the caller passes: a quad / triangle garment mesh has 5-8 incl. the
+// diagonal); otherwise G4D_EINVAL -- the caller falls back to `iters` x g4d_spmm_axpy_rows_f32.  S and out may alias.
+extern "C" int g4d_jacobi_smooth_f32(int frames, int vg, int c, int iters, float coeff, int max_row_entries, const float *S,
+                                     const int *rowptr, const int *colidx, const float *vals, float *out, g4d_stream_t stream) {
+    G4D_REQUIRE(frames >= 0 && vg >= 0 && c >= 0 && iters >= 0, "g4d_jacobi_smooth_f32: negative size");
+    if (frames == 0 || vg == 0 || c == 0) return G4D_OK;
+    G4D_REQUIRE(S && rowptr && colidx && vals && out, "g4d_jacobi_smooth_f32: null pointer");
+    G4D_REQUIRE(vg <= kJVerts * kJThreads && max_row_entries <= kJDeg,
+                "g4d_jacobi_smooth_f32: needs vg <= %d and <= %d entries per adjacency row (vg=%d, max row=%d)", kJVerts * kJThreads, kJDeg, vg,
+                max_row_entries);
+    const size_t lds = (size_t)2 * vg * sizeof(float4);
+    G4D_REQUIRE(lds <= 160 * 1024 - 512, "g4d_jacobi_smooth_f32: vg = %d does not fit the LDS-resident slab (max 5104)", vg);
+    static unsigned long long attr = 0;  // one bit per device
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_smooth_kernel), 160 * 1024 - 512, attr, "g4d_jacobi_smooth_f32")) return rc;
+    const long long blocks = (long long)frames * ((c + kJCols - 1) / kJCols);
+    G4D_REQUIRE(blocks < (1ll << 31), "g4d_jacobi_smooth_f32: too large");
+    hipLaunchKernelGGL(jacobi_smooth_kernel, dim3((unsigned)blocks), dim3(kJThreads), lds, reinterpret_cast<hipStream_t>(stream), vg, c, iters, coeff, S,
+                       rowptr, colidx, vals, out);
+    return check_launch("g4d_jacobi_smooth_f32");
 }

@@ -74,12 +74,8 @@ class Pointnet2MSGSEG(nn.Module):
         precision="bf16" (BASELINE config 3) runs the shared MLPs with bf16 operands / fp32 accumulation; sampling,
         grouping, interpolation weights and all tensors crossing the API stay fp32."""
         assert not self.training and precision in ("fp32", "bf16")
-        prev = fused.PRECISION
-        fused.PRECISION = precision
-        try:
+        with fused.precision(precision):   # per-thread context, not a process global
             return self._forward_fused(pointcloud, channel_major)
-        finally:
-            fused.PRECISION = prev
 
     def _forward_fused(self, pointcloud, channel_major):
         xyz = pointcloud[..., 0:3].contiguous()

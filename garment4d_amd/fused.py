@@ -153,7 +153,7 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
     orow = rows // S if pool else rows
     if out is None:
         out = torch.empty((orow, layer.Cout), dtype=torch.float32, device=x2d.device)
-    if not pool and PRECISION == "fp32" and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
+    if not pool and current_precision() == "fp32" and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
         # ragged K (e.g. the 323- / 195-wide GCN inputs) or a very narrow output: the chain kernel streams the rows with
         # unaligned 16-byte loads and wins (82 vs 60 TFLOP/s at 323 -> 128); results are bit-identical (same k order)
         return mlp_stack(0, rows, layer.K, [layer], out, col0=col0, X=x2d, ldx=ldx)
@@ -166,24 +166,32 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
 _MAX_STACK_LDS = 150 * 1024
 
 
-PRECISION = "fp32"  # "bf16": MLP operands in bf16 (cfg3), set per call through encoder.forward_fused(precision=...)
+# MLP operand precision of the CURRENT CALL: "fp32" | "bf16" (BASELINE config 3: bf16 operands, fp32 accumulate).  A context
+# variable, not a module global: every host thread (and every asyncio task) has its own value, so two threads driving the
+# library on different streams with different precisions do not interfere -- the C ABI's thread-safety carries up to here.
+import contextvars
+
+_PRECISION = contextvars.ContextVar("g4d_mlp_precision", default="fp32")
+
+
+def current_precision():
+    return _PRECISION.get()
 
 
 class precision:
-    """with fused.precision("bf16"): ...  -- shared-MLP operands in bf16 (BASELINE config 3) inside the block."""
+    """with fused.precision("bf16"): ...  -- shared-MLP operands in bf16 inside the block, for the calling thread only.
+    Every public entry point that takes `precision=` (encoder.forward_fused, the model forwards) is a thin wrapper of this."""
 
     def __init__(self, mode):
         assert mode in ("fp32", "bf16")
         self.mode = mode
 
     def __enter__(self):
-        global PRECISION
-        self.prev, PRECISION = PRECISION, self.mode
+        self._tok = _PRECISION.set(self.mode)
         return self
 
     def __exit__(self, *exc):
-        global PRECISION
-        PRECISION = self.prev
+        _PRECISION.reset(self._tok)
         return False
 
 
@@ -191,7 +199,7 @@ _BF16_MIN_ROWS = 8192  # below 128 workgroups of 64 rows the one-launch bf16 sta
 
 
 def _use_bf16(rows):
-    return PRECISION == "bf16" and (rows is None or rows >= _BF16_MIN_ROWS)
+    return current_precision() == "bf16" and (rows is None or rows >= _BF16_MIN_ROWS)
 
 
 _POOL_WINDOWS = (4, 8, 16, 32, 64)  # pool windows the LDS-resident kernels reduce in registers
@@ -256,7 +264,7 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
         cV, rowptr, colidx, vals = csr
         cr, cc, cv = rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr()
     tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
-    if PRECISION == "bf16" and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
+    if current_precision() == "bf16" and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
         W16 = PA(*[L.Wc16.data_ptr() for L in layers])
         _lib.call("g4d_mlp_chain_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
                   n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
@@ -270,7 +278,7 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
                   ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
                   ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
         return out
-    if PRECISION == "fp32" and chain_fits(layers, pool, S, mode):
+    if current_precision() == "fp32" and chain_fits(layers, pool, S, mode):
         _lib.call("g4d_mlp_chain_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
                   n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
                   ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),

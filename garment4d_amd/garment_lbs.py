@@ -63,12 +63,26 @@ _SMOOTH_OPERATOR_MAX_VG = 8192   # dense operator up to 256 MB; larger meshes ru
 def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100, method=None):
     """100 Jacobi steps  W <- W + coeff * ((D^-1 A - I) . W)  over the garment mesh (:385-390).
     method "jacobi": the steps as written, one SpMM-axpy kernel each (ping-pong buffers).
-    method "operator": the same linear map applied as one dense fp32 GEMM (see smoothing_operator); differs from the
-    step-by-step result only by rounding (both are ~1e-6 from the exact product).  Default: G4D_SMOOTH or "operator"
-    for meshes up to 8192 vertices."""
+    method "fused" (default when the mesh fits: Vg <= 5104, <= 8 entries per adjacency row): all steps in ONE hand-written launch,
+    the weights of a (frame, 4-joint slab) resident in LDS (g4d_jacobi_smooth_f32) -- bit-identical to "jacobi".
+    method "operator": the same linear map applied as one dense fp32 matrix product (see smoothing_operator; a LIBRARY GEMM,
+    kept as a cross-check only); differs from the step-by-step result only by rounding.  G4D_SMOOTH overrides the default."""
     import os
     F_, Vg, J = nn_W.shape
-    method = method or os.environ.get("G4D_SMOOTH") or ("operator" if Vg <= _SMOOTH_OPERATOR_MAX_VG else "jacobi")
+    import scipy.sparse as sp
+    method = method or os.environ.get("G4D_SMOOTH") or "fused"
+    if method == "fused":
+        adj = sp.csr_matrix(normalize(adj_old) - sp.eye(adj_old.shape[0]))
+        max_row = int(np.diff(adj.indptr).max()) if adj.shape[0] else 0
+        if Vg <= 5104 and max_row <= 8:
+            rowptr, colidx, vals, n = _to_csr(adj, nn_W.device)
+            assert n == Vg
+            x = nn_W.contiguous()
+            out = torch.empty_like(x)
+            _lib.call("g4d_jacobi_smooth_f32", F_, Vg, J, int(iters), float(coeff), max_row, x.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(),
+                      vals.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+            return out
+        method = "jacobi"   # mesh too large / too irregular for the LDS-resident kernel: one launch per step
     if method == "operator":
         M = smoothing_operator(adj_old, coeff, iters, nn_W.device)
         x = nn_W.permute(1, 0, 2).reshape(Vg, F_ * J)                      # vertex-major view of all frames / joints

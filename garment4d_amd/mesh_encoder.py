@@ -98,7 +98,13 @@ class PCAGarmentEncoderSeg(nn.Module):
         dev = coeff.device
         self.PCA_comp, self.PCA_mean = self.PCA_comp.to(dev), self.PCA_mean.to(dev)
         self.PCA_expl, self.PCA_scale = self.PCA_expl.to(dev), self.PCA_scale.to(dev)
-        return ((torch.mm(coeff, self.PCA_comp) + self.PCA_mean) * self.PCA_scale).reshape(coeff.shape[0], -1, 3)  # plain library GEMM
+        # coeff (nbatch, pca_dim) . components (pca_dim, 3 Vg), then + mean, * scale: ONE launch of the MFMA layer kernel with the
+        # affine folded into its epilogue -- (x W^T + mean) * scale = x W^T * scale + mean * scale
+        key = (self.PCA_comp.data_ptr(), self.PCA_mean.data_ptr(), self.PCA_scale.data_ptr(), str(dev))
+        if getattr(self, "_pca_layer", (None,))[0] != key:
+            sc = self.PCA_scale.float().reshape(-1).expand(self.PCA_comp.shape[1]).contiguous()   # scalar or per-coordinate scale
+            self._pca_layer = (key, fused.PackedLayer(self.PCA_comp.float().t().contiguous(), sc, self.PCA_mean.float() * sc, relu=False))
+        return fused.linear(coeff.float().contiguous(), self._pca_layer[1]).reshape(coeff.shape[0], -1, 3)
 
     def calc_segmentation_results(self, x, sem_logits, n, nbatch, T, feature_pm):
         """mesh_encoder.py:109-125 on point-major tensors; returns (garment_v (F,n,3), garment_f (F,n,C) point-major)."""
@@ -119,7 +125,7 @@ class PCAGarmentEncoderSeg(nn.Module):
             frame_ids = torch.arange(F_, device=x.device)
         cm = fused.to_channel_major if self.channel_major_outputs else (lambda t: t)
         out = {"middle_results": {}}
-        feat_global, sem_logits, feats_pm, xyz_list = self.pointnet.forward_fused(x.contiguous(), precision=fused.PRECISION)
+        feat_global, sem_logits, feats_pm, xyz_list = self.pointnet.forward_fused(x.contiguous(), precision=fused.current_precision())
         out["feat_global"] = feat_global
         out["feature_list"] = [None if f is None else cm(f) for f in feats_pm]
         out["xyz_list"] = xyz_list

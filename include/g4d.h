@@ -310,6 +310,13 @@ int g4d_knn_blend_weights_f32(int frames, int frames_per_clip, int vg, int v, in
 int g4d_spmm_axpy_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx,
                            const float *vals, float coeff, float *out, g4d_stream_t stream);
 
+/* ALL `iters` smoothing steps of mesh_encoder.py:385-390 in one launch: the (vg x 4-column) slab of a frame stays in LDS for the
+ * whole iteration, adjacency rows in registers; HBM sees the weights once in and once out.  Bit-identical to `iters` calls of
+ * g4d_spmm_axpy_rows_f32.  adj = D^-1 A - I in CSR (device arrays); max_row_entries = the longest CSR row (host-side knowledge of
+ * the caller).  Needs vg <= 5104 and max_row_entries <= 8, else G4D_EINVAL (use the per-step entry point).  S and out may alias. */
+int g4d_jacobi_smooth_f32(int frames, int vg, int c, int iters, float coeff, int max_row_entries, const float *S, const int *rowptr,
+                          const int *colidx, const float *vals, float *out, g4d_stream_t stream);
+
 /* One positional encoder of the refinement loop (modules/mesh_encoder.py:452-464): for every query q of new_xyz
  * (frames,p,3) and its nsample ball-query hits j = idx (frames,p,nsample) in xyz (frames,n,3):
  *   h = relu(W1 [x_j - q ; extra_j] + b1 + table_j),   y = W2 h + b2,   out[f*p + q, col0 .. col0+32) = max_j y

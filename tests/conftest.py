@@ -60,3 +60,12 @@ def contraction_mode(request):
     yield request.param
     numerics.set_distance_contraction(prev_l)
     K.set_contraction(prev_o)
+
+
+@pytest.fixture
+def request_finalizers(request):
+    """A list of callables run (in reverse order) when the test ends, whatever its outcome."""
+    fns = []
+    yield fns
+    for f in reversed(fns):
+        f()

@@ -124,3 +124,27 @@ def test_distance_contraction_switch_without_a_gpu():
             numerics.set_distance_contraction(3)
     finally:
         numerics.set_distance_contraction(start)
+
+
+def test_mlp_precision_is_per_thread_not_a_process_global():
+    """`fused.PRECISION` was a module global mutated per call; it is a context variable now -- a thread that
+    selects bf16 does not change what another thread (another stream) computes with."""
+    import threading
+    from garment4d_amd import fused
+    seen = {}
+
+    def worker(name, mode, ev_in, ev_out):
+        with fused.precision(mode):
+            ev_out.set()
+            ev_in.wait(5)
+            seen[name] = fused.current_precision()
+
+    a_in, a_out, b_in, b_out = (threading.Event() for _ in range(4))
+    ta = threading.Thread(target=worker, args=("a", "bf16", a_in, a_out))
+    tb = threading.Thread(target=worker, args=("b", "fp32", b_in, b_out))
+    ta.start(); tb.start()
+    a_out.wait(5); b_out.wait(5)           # both threads are inside their contexts at the same time
+    assert fused.current_precision() == "fp32"
+    a_in.set(); b_in.set()
+    ta.join(); tb.join()
+    assert seen == {"a": "bf16", "b": "fp32"} and fused.current_precision() == "fp32"

@@ -131,10 +131,11 @@ def test_stack_kernel_equals_per_layer_kernels(use_stack, use_chain, monkeypatch
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("S", [4, 8, 16, 64])
 @pytest.mark.parametrize("widths,pool", [((6, 32, 32), 1), ((70, 32, 32), 1), ((70, 64, 48), 2)])
-def test_stack_pool_windows(S, widths, pool, precision, monkeypatch):
+def test_stack_pool_windows(S, widths, pool, precision, monkeypatch, request_finalizers):
     """Fused pooling over S = 4 / 8 (the refinement loop's ball sizes, mesh_encoder.py:180-189) .. 64 samples equals the
     un-pooled stack followed by the row-pool kernel -- bit for bit, the reduction is a max / the same fp32 mean."""
-    monkeypatch.setattr(fused, "PRECISION", precision)
+    tok = fused._PRECISION.set(precision)
+    request_finalizers.append(lambda: fused._PRECISION.reset(tok))
     g = torch.Generator().manual_seed(S)
     rows = 8192 + 3 * S * 4          # not a multiple of the 64-row tile; >= 8192 so that bf16 mode takes the bf16 kernel
     layers = []
@@ -217,10 +218,11 @@ def test_chain_kernel_32_rows_per_wave(widths, S, pool, monkeypatch):
 @pytest.mark.parametrize("widths", [(3, 16, 16, 32), (3, 32, 32, 64), (99, 64, 64, 128), (195, 128, 128, 256), (67, 32, 32), (99, 128, 128), (40, 64),
                                     (128, 7)])
 @pytest.mark.parametrize("S,pool", [(16, 1), (64, 1), (8, 1), (4, 2), (1, 0)])
-def test_chain_bf16_kernel(widths, S, pool, monkeypatch):
+def test_chain_bf16_kernel(widths, S, pool, monkeypatch, request_finalizers):
     """csrc/mlp_chain_bf16.hip (cfg3 precision, activations chained through the accumulators as bf16 fragments) against a torch
     emulation of the same arithmetic: operands rounded to bf16 (RNE), fp32 accumulation, fp32 affine / ReLU / pooling."""
-    monkeypatch.setattr(fused, "PRECISION", "bf16")
+    tok = fused._PRECISION.set("bf16")
+    request_finalizers.append(lambda: fused._PRECISION.reset(tok))
     g = torch.Generator().manual_seed(len(widths) * 10 + S)
     S_ = max(S, 1)
     B, N, P = 2, 400, 41 if S > 1 else 1500

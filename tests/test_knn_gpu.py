@@ -85,6 +85,34 @@ def test_smoothing_operator_equals_jacobi_steps():
     torch.testing.assert_close(b.sum(-1), torch.ones(5, Vg, device="cuda"), rtol=1e-5, atol=1e-5)   # rows stay convex weights
 
 
+@pytest.mark.parametrize("nx,ny,F_,J,iters", [(20, 24, 5, 24, 100), (64, 64, 3, 24, 100), (70, 72, 2, 22, 7), (8, 9, 4, 3, 1), (12, 12, 2, 24, 0)])
+def test_fused_jacobi_smoothing_is_bit_identical_to_the_steps(nx, ny, F_, J, iters):
+    """g4d_jacobi_smooth_f32 (all steps in one launch, slab in LDS, adjacency in registers) against `iters` launches of the
+    per-step kernel: same operation order, so not a single bit may differ; Vg up to 5040 (70 x 72), ragged column slab (J = 22)."""
+    from garment4d_amd.garment_lbs import smooth_weights
+    _, adj_old = _quad_adj_old(nx, ny)
+    Vg = adj_old.shape[0]
+    W = torch.rand(F_, Vg, J, device="cuda", generator=torch.Generator(device="cuda").manual_seed(nx)) ** 3
+    W = W / W.sum(-1, keepdim=True)
+    keep = W.clone()
+    a = smooth_weights(W, adj_old, 0.1, iters, method="jacobi") if iters else W
+    b = smooth_weights(W, adj_old, 0.1, iters, method="fused")
+    assert torch.equal(W, keep)                                  # the caller's tensor is read, never written
+    assert torch.equal(a, b)
+
+
+def test_fused_jacobi_falls_back_when_the_mesh_does_not_fit():
+    from garment4d_amd import _lib
+    from garment4d_amd.garment_lbs import smooth_weights
+    _, adj_old = _quad_adj_old(80, 80)                           # 6400 vertices > 5104: the default route takes the per-step kernels
+    W = torch.rand(1, adj_old.shape[0], 24, device="cuda")
+    a = smooth_weights(W, adj_old, 0.1, 3)
+    b = smooth_weights(W, adj_old, 0.1, 3, method="jacobi")
+    assert torch.equal(a, b)
+    with pytest.raises(_lib.G4DError):
+        _lib.call("g4d_jacobi_smooth_f32", 1, 6400, 24, 3, 0.1, 5, W.data_ptr(), W.data_ptr(), W.data_ptr(), W.data_ptr(), W.data_ptr(), _lib.stream_ptr())
+
+
 @pytest.mark.parametrize("K,J", [(256, 24), (7, 24), (64, 40), (1, 3)])
 def test_knn_blend_weights_vs_oracle(K, J):
     from garment4d_amd.garment_lbs import _blend
