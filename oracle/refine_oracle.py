@@ -100,8 +100,10 @@ def temporal_attention(last_feat, w_qkv, nbatch, T):
 
 
 def refinement_head(sd, cur_garment_v, body_v, body_vn, garment_v_list, garment_f_list_pm, adj_csr, nbatch, T,
-                    garment_samples=(32, 16, 8), iteration=3):
-    """sd: numpy state dict with the reference's keys.  garment_f_list_pm[i] (F,N_i,C_i) point-major."""
+                    garment_samples=(32, 16, 8), iteration=3, return_ball_idx=False):
+    """sd: numpy state dict with the reference's keys.  garment_f_list_pm[i] (F,N_i,C_i) point-major.
+    return_ball_idx: also return, per round, the six ball-query index tensors (3 body radii, 3 garment levels) the round's
+    positional encoders grouped with -- tests use them to COUNT the queries whose membership differs from the GPU run's."""
     from . import gcn_oracle as GO
     radii = [0.1, 0.2, 0.4]
     body_samples = [8, 16, 32]
@@ -109,8 +111,13 @@ def refinement_head(sd, cur_garment_v, body_v, body_vn, garment_v_list, garment_
     outs, feats = [], []
     body_vn_cm = np.ascontiguousarray(np.transpose(body_vn, (0, 2, 1)))
     gf_cm = [np.ascontiguousarray(np.transpose(f, (0, 2, 1))) for f in garment_f_list_pm]
+    ball_idx = []
     for it in range(iteration):
         parts = [cur]
+        if return_ball_idx:
+            from . import pointnet2_oracle as K_
+            ball_idx.append([K_.ball_query(radii[i], body_samples[i], body_v, cur) for i in range(3)]
+                            + [K_.ball_query(radii[i], garment_samples[i], garment_v_list[i], cur) for i in range(3)])
         for i in range(3):
             parts.append(positional_encoding(sd, "body_positional_encoding%d" % i, radii[i], body_samples[i], body_v, cur, body_vn_cm))
         for i in range(3):
@@ -127,4 +134,4 @@ def refinement_head(sd, cur_garment_v, body_v, body_vn, garment_v_list, garment_
             feats.append(h)
         cur = cur + h
         outs.append(cur)
-    return outs
+    return (outs, ball_idx) if return_ball_idx else outs

@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 
 
 def rel_err(a, b):
+    """largest elementwise |a - b| / (1 + |b|): < 1e-5 is the elementwise rtol = atol = 1e-5 gate"""
+    return float((np.abs(a - b) / (1.0 + np.abs(b))).max())
+
+
+def scale_err(a, b):
+    """max |a - b| relative to the tensor's scale (the bf16 gates: the rounding of an operand is relative to ITS magnitude)"""
     return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
 
 
@@ -67,10 +73,10 @@ def test_encoder_bf16_vs_bf16_emulating_oracle(monkeypatch):
     # 2e-2 of the tensor scale against the bf16-emulating oracle, 5e-2 against the pure fp32 oracle
     errs = []
     for lvl in range(0, 4):
-        e16, e32 = rel_err(l_f[lvl].cpu().numpy(), want_f[lvl]), rel_err(l_f[lvl].cpu().numpy(), want32_f[lvl])
+        e16, e32 = scale_err(l_f[lvl].cpu().numpy(), want_f[lvl]), scale_err(l_f[lvl].cpu().numpy(), want32_f[lvl])
         errs.append((lvl, e16, e32))
         assert e16 < 2e-2, f"level {lvl} vs bf16-emulating oracle: {e16}"
         assert e32 < 5e-2, f"level {lvl} vs fp32 oracle: {e32}"
     print("bf16 path rel. errors (level, vs bf16-emulating oracle, vs fp32 oracle):", errs)
-    assert rel_err(logits.cpu().numpy(), want_logits) < 2e-2
-    assert rel_err(logits.cpu().numpy(), want32_logits) < 5e-2
+    assert scale_err(logits.cpu().numpy(), want_logits) < 2e-2
+    assert scale_err(logits.cpu().numpy(), want32_logits) < 5e-2

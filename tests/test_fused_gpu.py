@@ -10,13 +10,13 @@ from conftest import sub_state_dict
 from garment4d_amd import fused, pointnet2_modules as PM, synthetic as syn
 
 pytestmark = pytest.mark.gpu
-# north_star: 1e-5 fp32 for grouped features.  The MFMA contraction sums in a different order than the
-# reference's conv (exact fp32 FMA chain vs BLAS), so the bound is relative to the tensor's scale.
+# north_star: 1e-5 fp32 for grouped features -- elementwise |a - b| <= tol * (1 + |b|), i.e. rtol = atol = tol.  (The MFMA
+# contraction sums in a different order than the reference's conv; measured worst case at the benched sizes: 4.7e-6.)
 def close(a, b, tol=1e-5):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
-    scale = max(1.0, float(np.abs(b).max()))
-    err = float(np.abs(a - b).max())
-    assert err <= tol * scale, f"max abs err {err:.3e} > {tol:.0e} * scale {scale:.3f}"
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    err = np.abs(a - b) / (1.0 + np.abs(b))
+    assert float(err.max()) <= tol, f"max elementwise err {float(err.max()):.3e} > {tol:.0e} (rtol = atol)"
 
 
 def dev(a):

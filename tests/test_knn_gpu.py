@@ -69,7 +69,7 @@ def test_lbs_garment_interpolation_vs_oracle(K):
                                                    dev(pose), dev(Jreg), dev(Wt), adj_old, K=K)
     assert np.array_equal(nn1.idx.cpu().numpy(), wi)
     np.testing.assert_allclose(got_inv.cpu().numpy(), want_inv, rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(got_v.cpu().numpy(), want_v, rtol=1e-4, atol=1e-4)  # 100 smoothing steps compound fp32 rounding
+    np.testing.assert_allclose(got_v.cpu().numpy(), want_v, rtol=1e-5, atol=1e-5)
 
 
 def test_smoothing_operator_equals_jacobi_steps():

@@ -98,7 +98,7 @@ def test_full_forward_vs_oracle(garment, lbs_k):
         out = m(dev(scene["x"]), _body_model(scene["body"]), {k: dev(v) for k, v in scene["batch"].items()})
     want = MOr.full_forward(sd, scene["x"], scene["batch"], scene["body"], garment, scene["pca"], scene["template"][1], lbs_k)
 
-    def close(a, b, tol=2e-4):
+    def close(a, b, tol=1e-5):   # north_star: 1e-5 fp32, elementwise
         np.testing.assert_allclose(a.cpu().numpy() if torch.is_tensor(a) else a, b, rtol=tol, atol=tol)
 
     close(out["sem_logits"], want["sem_logits"])
@@ -114,15 +114,50 @@ def test_full_forward_vs_oracle(garment, lbs_k):
     close(out["tpose_garment"], want["tpose_garment"])
     assert out["lbs_pred_garment_v"].shape == (nbatch, T, scene["template"][0].shape[0], 3)
 
-    def mostly_close(a, b, tol):
-        err = np.abs(a.cpu().numpy().reshape(b.shape) - b).max(-1)
-        assert np.quantile(err, 0.99) <= tol, (np.quantile(err, 0.99), err.max())
+    # ---- garment skinning and refinement: max-error gates, with the DISCRETE differences counted, not averaged away -----------
+    # The regressed T-pose garment differs between the two implementations by fp32 rounding (checked above to 2e-4), so a body
+    # vertex sitting at the edge of a garment vertex's K-nearest set, or a point on the boundary of a refinement ball, can fall
+    # on the other side.  Such vertices are identified by re-running the searches on both sides' own inputs; every other vertex
+    # must meet a maximum-error bound.
+    from garment4d_amd.knn import knn_points
+    from oracle import refine_oracle as RO
+    Vg = scene["template"][0].shape[0]
+    body_t = scene["batch"]["Tpose_smpl_vertices_torch"].reshape(nbatch, -1, 3)
+    root = scene["batch"]["Tpose_smpl_root_joints_torch"].reshape(nbatch, 1, 3)
+    K64 = min(64, lbs_k)
+    gi = knn_points((out["tpose_garment"].reshape(nbatch, Vg, 3) + dev(root)).contiguous(), dev(body_t), K=lbs_k).idx.cpu().numpy()
+    wi = RO.knn_points(want["tpose_garment"].reshape(nbatch, Vg, 3) + root, body_t, lbs_k)[1]
+    knn_flip64 = (np.sort(gi[..., :K64], -1) != np.sort(wi[..., :K64], -1)).any(-1)          # (nbatch, Vg): the un-posing's K set differs
+    knn_flipK = (np.sort(gi, -1) != np.sort(wi, -1)).any(-1)
+    print(f"[parity] {garment}: garment vertices whose {K64}-NN / {lbs_k}-NN body sets differ: {int(knn_flip64.sum())} / {int(knn_flipK.sum())} of {nbatch * Vg}")
 
-    mostly_close(out["lbs_stage1_pred_garment_v"], want["lbs_stage1_pred_garment_v"], 1e-4)
-    mostly_close(out["lbs_pred_garment_v"], want["lbs_pred_garment_v"], 2e-4)
+    def bounded(name, a, b, tol, clean):
+        """max |a - b| over the vertices flagged clean <= tol; the others are reported"""
+        err = np.abs(a.cpu().numpy().reshape(b.shape) - b).max(-1)                           # (nbatch, T, Vg)
+        c = np.broadcast_to(clean, err.shape)
+        print(f"[parity] {garment} {name}: max err clean {err[c].max():.3g} (gate {tol:.3g}); flagged vertices {int((~c).sum())}, their max err "
+              f"{err[~c].max() if (~c).any() else 0.0:.3g}")
+        assert c.mean() > 0.5, "more than half of the vertices are flagged: the scene is degenerate"
+        assert err[c].max() <= tol, (name, float(err[c].max()), tol)
+        return err
+
+    bounded("lbs_stage1_pred_garment_v (un-posed template)", out["lbs_stage1_pred_garment_v"], want["lbs_stage1_pred_garment_v"], 1e-5,
+            ~knn_flip64[:, None, :])
+    # the 100 smoothing steps spread a flipped vertex's weight change (~1/K of one body vertex's weights) over its mesh neighbourhood:
+    # vertices of a clip WITHOUT any flipped K-set meet the tight gate, clips with flips a looser one
+    clip_clean = ~knn_flipK.any(1)
+    bounded("lbs_pred_garment_v", out["lbs_pred_garment_v"], want["lbs_pred_garment_v"], 1e-5,
+            clip_clean[:, None, None] | np.zeros((nbatch, T, Vg), dtype=bool))
+    if (~clip_clean).any():
+        e = np.abs(out["lbs_pred_garment_v"].cpu().numpy() - want["lbs_pred_garment_v"]).max(-1)[~clip_clean]
+        assert e.max() <= 2e-3, e.max()
     assert len(out["iter_regressed_lbs_garment_v"]) == 3
-    for a, b in zip(out["iter_regressed_lbs_garment_v"], want["iter_regressed_lbs_garment_v"]):
-        mostly_close(a, b, 5e-4 * max(1.0, np.abs(b).max()))
+    for r, (a, b) in enumerate(zip(out["iter_regressed_lbs_garment_v"], want["iter_regressed_lbs_garment_v"])):
+        e = np.abs(a.cpu().numpy().reshape(b.shape) - b).max(-1)
+        scale = max(1.0, float(np.abs(b).max()))
+        frac = float((e > 1e-5 * scale).mean())
+        print(f"[parity] {garment} refinement round {r}: max err {e.max():.3g}, vertices above 1e-5: {frac:.3g} (a ball-membership flip would show here)")
+        assert frac <= 0.02 and e.max() <= 5e-2 * scale, (r, frac, float(e.max()))
 
 
 @pytest.mark.parametrize("reduce_fn", ["sum", "mean"])
@@ -202,7 +237,7 @@ def test_forward_frames_two_ranks_equals_unsharded():
     np.testing.assert_allclose(posed, ref["lbs_pred_garment_v"].reshape(nbatch * T, -1, 3).cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg="posed")
     want = ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy()
     err = np.abs(final - want).reshape(nbatch * T, -1).max(1)
-    np.testing.assert_allclose(final, want, rtol=1e-4, atol=1e-5, err_msg=f"final; per-frame max err {err}")
+    np.testing.assert_allclose(final, want, rtol=1e-5, atol=1e-5, err_msg=f"final; per-frame max err {err}")
 
 
 def _clip_rank_worker(rank, world, port, nbatch, T, N, ret):
@@ -248,4 +283,4 @@ def test_forward_clip_sharded_ranks_do_not_exchange():
     coeff = np.concatenate([ret[0]["coeff"], ret[1]["coeff"]], 0)
     final = np.concatenate([ret[0]["final"], ret[1]["final"]], 0)
     np.testing.assert_allclose(coeff, ref["garment_PCA_coeff"].cpu().numpy(), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(final, ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(final, ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy(), rtol=1e-5, atol=1e-5)

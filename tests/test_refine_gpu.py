@@ -69,21 +69,49 @@ def test_first_round_vs_oracle(garment, pe_kernel, monkeypatch):
     want = RO.refinement_head(sd, cur, body_v, body_vn, gv, gf, adj, nbatch, T, garment_samples=tuple(head.garment_sample_num_list),
                               iteration=1)
     assert len(got) == 1
-    np.testing.assert_allclose(got[0].cpu().numpy(), want[0], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got[0].cpu().numpy(), want[0], rtol=1e-5, atol=1e-5)   # measured: 1e-7
+
+
+def membership_flips(got_prev, want_idx, body_v, gv, body_samples, garment_samples, radii=(0.1, 0.2, 0.4)):
+    """Per frame: how many of the round's 6 x Vg ball queries return a different index row on the GPU (queries = the GPU's own
+    previous-round vertices) than in the oracle (its own previous-round vertices).  The two vertex sets differ by fp32 rounding,
+    so a body / garment point within ~1e-6 of a ball's boundary can change sides: a DISCRETE difference, counted here instead of
+    being averaged away by a quantile."""
+    from garment4d_amd import fused
+    q = got_prev.contiguous()
+    idx = fused.ball_query_msg(list(radii), list(body_samples), dev(body_v), q, coherent=True)
+    idx += [fused.ball_query_msg([radii[i]], [garment_samples[i]], dev(gv[i]), q)[0] for i in range(3)]
+    flips = np.zeros(q.shape[0], dtype=np.int64)
+    for a, b in zip(idx, want_idx):
+        flips += (a.cpu().numpy() != b).any(-1).sum(-1)
+    return flips
 
 
 def test_three_rounds_vs_oracle():
-    """Rounds 2, 3 re-query the balls around vertices that differ by rounding between the two implementations, so a
-    vertex sitting within 1e-6 of a ball boundary may legitimately change membership: compare all but a sliver."""
+    """Rounds 2 and 3 re-query the balls around vertices that differ by rounding between the two implementations.  Frames whose
+    queries all return the oracle's rows (and whose clip had none flipped in an earlier round: the attention mixes a clip's
+    frames) must agree to a MAXIMUM error bound; flipped queries are counted and must be rare."""
     nbatch, T = 2, 3
     head, sd, cur, body_v, body_vn, gv, gf, adj = _case(nbatch, T, seed=5)
     got = _run(head, cur, body_v, body_vn, gv, gf, adj, nbatch, T)
-    want = RO.refinement_head(sd, cur, body_v, body_vn, gv, gf, adj, nbatch, T)
+    want, want_idx = RO.refinement_head(sd, cur, body_v, body_vn, gv, gf, adj, nbatch, T, return_ball_idx=True)
     assert len(got) == 3
-    for g, w in zip(got, want):
-        err = np.abs(g.cpu().numpy() - w).max(-1)
-        scale = np.abs(w).max()
-        assert np.quantile(err, 0.99) <= 2e-4 * max(scale, 1.0), (np.quantile(err, 0.99), err.max(), scale)
+    Vg = cur.shape[1]
+    dirty_clip = np.zeros(nbatch, dtype=bool)        # a flip anywhere in the clip in an EARLIER round
+    total_flips = 0
+    for r, (g, w) in enumerate(zip(got, want)):
+        flips = np.zeros(nbatch * T, dtype=np.int64) if r == 0 else membership_flips(got[r - 1], want_idx[r], body_v, gv, head.body_sample_num_list,
+                                                                                      head.garment_sample_num_list)
+        total_flips += int(flips.sum())
+        clean = (flips == 0) & ~np.repeat(dirty_clip, T)
+        err = np.abs(g.cpu().numpy() - w).reshape(nbatch * T, -1).max(-1)
+        scale = max(float(np.abs(w).max()), 1.0)
+        print(f"[parity] round {r}: flipped queries per frame {flips.tolist()} of {6 * Vg}; max err clean frames "
+              f"{err[clean].max() if clean.any() else float('nan'):.3g}, other frames {err[~clean].max() if (~clean).any() else 0:.3g}")
+        assert clean.any(), "every frame had a membership flip: pick another seed"
+        assert err[clean].max() <= 1e-5 * scale, (r, err, flips)   # measured: 1.2e-7 with no flip on this seed
+        dirty_clip |= (flips.reshape(nbatch, T) > 0).any(1)
+    assert total_flips <= 1e-3 * 2 * 6 * Vg * nbatch * T, total_flips
 
 
 def test_attention_only_mixes_frames_of_a_clip():
@@ -112,4 +140,41 @@ def test_temporal_attention_kernels(nclips, T, Vg, C):
         q, k, v = [z.reshape(nclips, T, Vg * C).double() for z in lin(feats).reshape(nclips, T, Vg, 3 * C).chunk(3, -1)]
         want = (torch.softmax(q @ k.transpose(1, 2) / T ** 0.5, -1) @ v).reshape(nclips * T, Vg, C).float()
     assert (out[..., :3] == 9.0).all() and (out[..., 3 + C:] == 9.0).all()
-    torch.testing.assert_close(out[..., 3:3 + C], want, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(out[..., 3:3 + C], want, rtol=1e-5, atol=1e-5)
+
+
+def test_cfg4_shaped_round_vs_oracle_on_sampled_frames():
+    """BASELINE config 4 geometry for the refinement head: one clip of T = 30 frames, Vg = 4096 garment vertices (64 x 64 quad
+    cylinder), V = 6890 body vertices, garment levels of 1722 / 512 / 64 points -- the launch shapes scripts/time_model.py times
+    (983k-row positional encoders, the 3-radius body ball query, 122,880-row GCN layers).  The first round has no temporal
+    mixing, so the oracle is run on three sampled frames and must match those frames of the full 30-frame GPU run."""
+    rng = np.random.default_rng(11)
+    nbatch, T, V = 1, 30, 6890
+    verts, faces = syn.quad_cylinder(64, 64)
+    Vg = verts.shape[0]
+    assert Vg == 4096
+    body_v = ((syn.body_like_cloud(T, V, seed=12, dup_frac=0.0, zero_frac=0.0) - np.array([0.5, 0.9, 0.5], np.float32))).astype(np.float32)
+    body_vn = rng.standard_normal((T, V, 3)).astype(np.float32)
+    body_vn /= np.linalg.norm(body_vn, axis=-1, keepdims=True)
+    cur = (body_v[:, rng.permutation(V)[:Vg]] * 1.05 + rng.standard_normal((T, Vg, 3)).astype(np.float32) * 0.01).astype(np.float32)
+    gv, gf = [], []
+    for n, c in ((1722, 64), (512, 96), (64, 384)):
+        sel = rng.integers(0, Vg, n)
+        gv.append((cur[:, sel] + rng.standard_normal((T, n, 3)).astype(np.float32) * 0.02).astype(np.float32))
+        gf.append(rng.standard_normal((T, n, c)).astype(np.float32))
+    adj = GO.adjacency_from_faces(faces, Vg)
+    torch.manual_seed(13)
+    head = GarmentRefinementHead(garment_name="Tshirt").cuda().eval()
+    with torch.no_grad():
+        for p in head.parameters():
+            p.mul_(0.5)
+    head.iteration = 1
+    sd = {k: v.detach().cpu().numpy() for k, v in head.state_dict().items()}
+    got = _run(head, cur, body_v, body_vn, gv, gf, adj, nbatch, T)[0].cpu().numpy()
+    frames = [0, 14, 29]
+    want = RO.refinement_head(sd, cur[frames], body_v[frames], body_vn[frames], [x[frames] for x in gv], [x[frames] for x in gf], adj, 1, 3,
+                              garment_samples=tuple(head.garment_sample_num_list), iteration=1)[0]
+    err = np.abs(got[frames] - want)
+    print(f"[parity] cfg4-shaped round: max_abs {err.max():.3g} (offsets up to {np.abs(want - cur[frames]).max():.3g}), "
+          f"elements outside rtol=atol=1e-5: {(err > 1e-5 + 1e-5 * np.abs(want)).mean():.3g}")
+    np.testing.assert_allclose(got[frames], want, rtol=1e-5, atol=1e-5)
