@@ -23,6 +23,8 @@ SIGNATURES = {
     "g4d_ball_query_f32": [_I, _I, _I, _F, _I, _vp, _vp, _vp, _vp],
     "g4d_ball_query_msg_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_ball_query_boxes_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_ball_query_lanes_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_ball_query_lanes_qsort_bytes": [_I, _I],
     "g4d_ball_grid_bytes": [_I, _I],
     "g4d_ball_grid_build_f32": [_I, _I, _F, _vp, _vp, _vp],
     "g4d_ball_grid_query_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _vp],
@@ -74,7 +76,7 @@ SIGNATURES = {
 _lib = None
 
 
-RESTYPES = {"g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t}   # everything else returns an int status
+RESTYPES = {"g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):

@@ -230,6 +230,10 @@ __global__ void __launch_bounds__(256) ball_grid_query_kernel(int n, int m, int 
         // 4 x 64 entries per step: the four record loads of a lane are issued together (the walk is a chain of L2 round trips
         // otherwise), then each is tested against every radius; hits are appended in arrival order, the selection below sorts
         for (int j0 = 0; j0 < total; j0 += 4 * 64) {
+            bool all_dense = true;  // every scale already holds more than kCap hits: the lists are useless, the scan fallback decides
+#pragma unroll
+            for (int sc = 0; sc < NS; ++sc) all_dense &= h[sc] > kCap;
+            if (all_dense) break;
             float4 p[4];
             bool valid[4];
 #pragma unroll
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__(256) ball_grid_query_kernel(int n, int m, int 
     }
 }
 
-static int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st) {
+int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st) {  // also used by ball_query.hip (query sorting)
     const int cmax = grid_cmax(n);
     const size_t lds = ((size_t)cmax + 1) * 4 + 16 * 8 * 4;
     static unsigned long long attr = 0;  // one bit per device
@@ -345,6 +349,9 @@ static int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipS
                        reinterpret_cast<unsigned char *>(ws), grid_cloud_bytes(n));
     return check_launch("g4d_ball_grid_build_f32");
 }
+
+size_t grid_bytes_per_cloud(int n) { return grid_cloud_bytes(n); }
+size_t grid_records_offset(int n) { return kGridHdrBytes + ((((size_t)grid_cmax(n) + 1) * 4 + 63) & ~(size_t)63); }
 
 template <int NS, int FM>
 static void grid_query_launch(dim3 grid, hipStream_t st, int n, int m, int qpw, const BgArgs &a, const float *new_xyz, const float *xyz,

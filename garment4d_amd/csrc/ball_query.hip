@@ -18,6 +18,7 @@
 //     holds ~0.4 % of a unit cloud), the per-scale bookkeeping runs only behind it;
 //   * a wave stops testing once its queries are full; the workgroup leaves when all four are.
 // Algorithmic bytes: 12*B*(N+M) + 4*B*M*sum(nsample); B*M*N distance evaluations worst case.
+#include <cmath>
 #include <cstdlib>
 
 #include "g4d_common.h"
@@ -219,6 +220,99 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
 }
 
+// "Lanes = queries" ball query for SPATIALLY COHERENT query sets against an index-coherent cloud (the body / garment queries of
+// modules/mesh_encoder.py:452-464: 64 consecutive garment vertices form a compact patch, 64 consecutive body vertices a compact
+// block).  The dense regime -- balls holding 100-2000 points of which 8-32 are wanted -- is decided by early exit in index
+// order, not by spatial cells, and the wave-per-query scan pays its ballot / prefix bookkeeping once per (query, block).  Here a
+// wave owns 64 queries, one per lane, and walks the cloud's 64-point blocks in index order:
+//   * a block is skipped for the whole wave when its box is at least r_open away from the bounding box of the wave's still
+//     collecting queries (the same dist2<FM> on the box-to-box gaps: monotone rounding, never skips a hit; r_open = the largest
+//     radius some lane still collects for);
+//   * the points of a visited block are wave-uniform (scalar loads); a lane tests its own query, appends hits to its own row:
+//     ascending index order is the visiting order, no ballot, no prefix sum; one ballot per point skips the per-scale work when
+//     no lane is within the largest open radius;
+//   * the walk ends when every lane has every scale full.
+// Output identical to ball_query_kernel for ANY input; it is FASTER only when the 64 queries of a wave are close together.
+// SORTED: the queries are taken from the cell-ordered records of a grid built over them (ball_grid.hip) -- 64 consecutive records
+// are spatially compact whatever the queries' own order -- and each lane writes the row of its record's ORIGINAL index.
+template <int NS, int FM, bool SORTED>
+__global__ void __launch_bounds__(256) ball_query_lanes_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
+                                                              const float *__restrict__ xyz_all, const float *__restrict__ boxes_all,
+                                                              const unsigned char *__restrict__ qgrid, size_t qgrid_stride, size_t qrec_off) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const bool qok = slot < m;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    float qx, qy, qz;
+    int q;
+    if constexpr (SORTED) {
+        const float4 rec = reinterpret_cast<const float4 *>(qgrid + (size_t)b * qgrid_stride + qrec_off)[qok ? slot : m - 1];
+        qx = rec.x; qy = rec.y; qz = rec.z; q = __float_as_int(rec.w);
+    } else {
+        q = qok ? slot : m - 1;
+        const float *qp = new_xyz_all + ((size_t)b * m + q) * 3;
+        qx = qp[0]; qy = qp[1]; qz = qp[2];
+    }
+    const int nblk = (n + 63) >> 6;
+    const float *boxes = boxes_all + (size_t)b * nblk * 6;
+    int cnt[NS], first[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { cnt[s] = qok ? 0 : a.nsample[s]; first[s] = 0; }
+    const float INF = __builtin_inff();
+    for (int blk = 0; blk < nblk; ++blk) {
+        // wave state: which scales still collect, and the box of the lanes that do (NaN query coordinates drop out of min / max)
+        float r2open = -1.f;
+        bool lane_open = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bool o = cnt[s] < a.nsample[s];
+            lane_open |= o;
+            if (__builtin_amdgcn_ballot_w64(o) != 0ull) r2open = fmaxf(r2open, a.radius2[s]);
+        }
+        if (r2open < 0.f) break;  // wave-uniform: every lane full
+        float lx = lane_open ? qx : INF, ly = lane_open ? qy : INF, lz = lane_open ? qz : INF;
+        float hx = lane_open ? qx : -INF, hy = lane_open ? qy : -INF, hz = lane_open ? qz : -INF;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lx = fminf(lx, __shfl_xor(lx, o)); ly = fminf(ly, __shfl_xor(ly, o)); lz = fminf(lz, __shfl_xor(lz, o));
+            hx = fmaxf(hx, __shfl_xor(hx, o)); hy = fmaxf(hy, __shfl_xor(hy, o)); hz = fmaxf(hz, __shfl_xor(hz, o));
+        }
+        // skip ahead over blocks whose box cannot hold a hit of any collecting lane; the wave box is recomputed only here
+        int nb = blk;
+        for (; nb < nblk; ++nb) {
+            const float *bx = boxes + (size_t)nb * 6;
+            const float gx = fmaxf(fmaxf(bx[0] - hx, lx - bx[3]), 0.f), gy = fmaxf(fmaxf(bx[1] - hy, ly - bx[4]), 0.f),
+                        gz = fmaxf(fmaxf(bx[2] - hz, lz - bx[5]), 0.f);
+            if (dist2<FM>(gx, gy, gz) < r2open) break;  // wave-uniform (all operands are)
+        }
+        blk = nb;
+        if (blk >= nblk) break;
+        const int k0 = blk << 6, kn = min(64, n - k0);
+        for (int p = 0; p < kn; ++p) {
+            const int k = k0 + p;
+            const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];  // wave-uniform address: scalar loads
+            const float d2 = dist2<FM>(qx - x, qy - y, qz - z);                        // ball_query_gpu.cu:30 under the contraction contract
+            if (__builtin_amdgcn_ballot_w64(d2 < r2open) == 0ull) continue;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bool take = d2 < a.radius2[s] && cnt[s] < a.nsample[s];
+                if (take) {
+                    if (cnt[s] == 0) first[s] = k;
+                    a.idx[s][((size_t)b * m + q) * a.nsample[s] + cnt[s]] = k;
+                    ++cnt[s];
+                }
+            }
+        }
+    }
+    // pad with the first hit (ball_query_gpu.cu:32-36); rows without a hit are zeros (first = 0)
+    if (qok) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            for (int l = cnt[s]; l < a.nsample[s]; ++l) a.idx[s][((size_t)b * m + q) * a.nsample[s] + l] = first[s];
+    }
+}
+
 template <int NS, bool BOXES, int FM>
 static void launch_bq_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
                          const float *boxes) {
@@ -292,6 +386,53 @@ extern "C" int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const 
                                         const float *new_xyz, const float *xyz, int *const *idx, float *boxes, g4d_stream_t stream) {
     G4D_REQUIRE(boxes != nullptr, "g4d_ball_query_boxes_f32: boxes scratch is NULL");
     return ball_query_msg_impl(b, n, m, nscales, radii, nsamples, new_xyz, xyz, idx, boxes, stream);
+}
+
+extern "C" size_t g4d_ball_query_lanes_qsort_bytes(int b, int m) { return (b <= 0 || m <= 0) ? 0 : (size_t)b * g4d::grid_bytes_per_cloud(m); }
+
+extern "C" int g4d_ball_query_lanes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                                        const float *xyz, int *const *idx, float *boxes, void *qsort, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nscales >= 1 && nscales <= 4 && b <= 65535, "g4d_ball_query_lanes_f32: bad sizes");
+    G4D_REQUIRE(radii && nsamples && idx, "g4d_ball_query_lanes_f32: null pointer");
+    if (b == 0 || m == 0) return G4D_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BqArgs a = {};
+    for (int s = 0; s < nscales; ++s) {
+        G4D_REQUIRE(nsamples[s] > 0 && idx[s], "g4d_ball_query_lanes_f32: bad scale %d", s);
+        a.radius2[s] = radii[s] * radii[s];
+        a.radius2_max = s == 0 ? a.radius2[0] : (a.radius2[s] > a.radius2_max ? a.radius2[s] : a.radius2_max);
+        a.nsample[s] = nsamples[s];
+        a.idx[s] = idx[s];
+        if (n == 0) {
+            hipError_t e = hipMemsetAsync(idx[s], 0, sizeof(int) * (size_t)b * m * nsamples[s], st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    if (n == 0) return G4D_OK;
+    G4D_REQUIRE(new_xyz && xyz && boxes, "g4d_ball_query_lanes_f32: null pointer (boxes scratch = b * ceil(n/64) * 6 floats)");
+    const int nblk = (n + 63) / 64;
+    const long long total = (long long)b * nblk;
+    hipLaunchKernelGGL(ball_boxes_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
+    dim3 grid((unsigned)((m + 255) / 256), (unsigned)b);
+    const unsigned char *qg = reinterpret_cast<const unsigned char *>(qsort);
+    const size_t qstride = grid_bytes_per_cloud(m), qoff = grid_records_offset(m);
+    if (qsort) {
+        // sort the queries into cells of half the largest radius: 64 consecutive records = a compact wave
+        const int rc = grid_build(b, m, 0.5f * sqrtf(a.radius2_max) / 1.01f, new_xyz, qsort, st);
+        if (rc != G4D_OK) return rc;
+    }
+#define G4D_LANES(NSV)                                                                                                            \
+    if (qsort) hipLaunchKernelGGL((ball_query_lanes_kernel<NSV, FM, true>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes, qg, qstride, qoff); \
+    else hipLaunchKernelGGL((ball_query_lanes_kernel<NSV, FM, false>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes, qg, qstride, qoff);
+    G4D_WITH_FM(distance_contraction(), switch (nscales) {
+        case 1: G4D_LANES(1) break;
+        case 2: G4D_LANES(2) break;
+        case 3: G4D_LANES(3) break;
+        default: G4D_LANES(4) break;
+    })
+#undef G4D_LANES
+    return check_launch("g4d_ball_query_lanes_f32");
 }
 
 extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,

@@ -335,6 +335,13 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
 # captured hipGraph the fork / join costs more than the overlap gains (single-batch latency 1.46 -> 1.57 ms, 16-batch throughput
 # 23.3k -> 10.8k frames/s: the runtime serialises graph branches through extra cross-stream dependencies); DESIGN.md section 5
 OVERLAP_SAMPLING = os.environ.get("G4D_OVERLAP_SAMPLING", "0") != "0"
+# coherent=True route.  Default: wave-per-query with 64-point block bounds (g4d_ball_query_boxes_f32), robust to the vertex numbering.
+# G4D_BQ_LANES=1: one LANE per query (g4d_ball_query_lanes_f32) -- measured on config 4's body query (983k queries x 6890 points,
+# scripts/time_body_query.py): 0.78 ms vs 1.33 ms when the queries of a wave sit at one height of a ring-ordered body (the
+# synthetic scene), but 2.0 ms vs 1.28 ms for a patch-ordered body and 4.1-4.6 ms for incoherent queries; cell-sorting the queries
+# first (G4D_BQ_LANES_SORT=1) makes waves compact but lets their lanes fill at different times: 2.2-2.7 ms.  Off by default.
+LANES_SORT = os.environ.get("G4D_BQ_LANES_SORT", "0") != "0"
+COHERENT_LANES = os.environ.get("G4D_BQ_LANES", "0") != "0"
 GRID_MIN_N = int(os.environ.get("G4D_BQ_GRID_MIN_N", "4096"))  # clouds at least this large go through the cell grid (csrc/ball_grid.hip)
 
 
@@ -357,8 +364,8 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     B, N, _ = xyz.shape
     P = new_xyz.shape[1]
     outs = [torch.empty((B, P, ns), dtype=torch.int32, device=xyz.device) for ns in nsamples]
-    if grid is None:
-        grid = (not coherent) and N >= GRID_MIN_N
+    if grid is None:   # the cells are sized by the largest radius: a much smaller scale would wade through 64x its share of points
+        grid = (not coherent) and N >= GRID_MIN_N and max(radii) <= 2.01 * min(radii)
     if grid is True:
         grid = build_ball_grid(xyz, max(float(r) for r in radii)) if (B and N and P) else False
     done = 0
@@ -372,8 +379,13 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
                       new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), grid[0].data_ptr(), grid[1], _lib.stream_ptr())
         elif coherent and N >= 256:
             boxes = torch.empty((B, (N + 63) // 64, 6), dtype=torch.float32, device=xyz.device)
-            _lib.call("g4d_ball_query_boxes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
-                      new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), boxes.data_ptr(), _lib.stream_ptr())
+            if COHERENT_LANES:   # one lane per query; the queries are cell-sorted first so that a wave's 64 are compact
+                qs = torch.empty(max(_lib.lib().g4d_ball_query_lanes_qsort_bytes(B, P), 16), dtype=torch.uint8, device=xyz.device) if LANES_SORT else None
+                _lib.call("g4d_ball_query_lanes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
+                          new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), boxes.data_ptr(), _ptr(qs), _lib.stream_ptr())
+            else:
+                _lib.call("g4d_ball_query_boxes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
+                          new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), boxes.data_ptr(), _lib.stream_ptr())
         else:
             _lib.call("g4d_ball_query_msg_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
                       new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), _lib.stream_ptr())

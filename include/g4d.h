@@ -97,6 +97,17 @@ int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii,
 int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
                              const float *xyz, int *const *idx, float *boxes, g4d_stream_t stream);
 
+/* g4d_ball_query_msg_f32 for COHERENT query sets (64 consecutive queries close together: mesh vertices in mesh order) against an
+ * index-coherent cloud, dense balls (far more hits than nsample): one LANE per query, the cloud's 64-point blocks visited in index
+ * order by the whole wave, blocks culled against the bounding box of the wave's still-collecting queries (`boxes` = the same
+ * b * ceil(n/64) * 6 floats of scratch as g4d_ball_query_boxes_f32).  `qsort`: optional g4d_ball_query_lanes_qsort_bytes(b, m)
+ * bytes of scratch -- when given, the queries are first counting-sorted into cells of half the largest radius, so that the 64
+ * queries of a wave are compact WHATEVER order the caller's queries come in (NULL: the caller's order is used as is and had
+ * better be coherent).  Same results as g4d_ball_query_msg_f32 for ANY input. */
+size_t g4d_ball_query_lanes_qsort_bytes(int b, int m);
+int g4d_ball_query_lanes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
+                             const float *xyz, int *const *idx, float *boxes, void *qsort, g4d_stream_t stream);
+
 /* Cell-bucketed ball query (csrc/ball_grid.hip): the same results as g4d_ball_query_msg_f32, bit for bit, for ANY input, with
  * work proportional to the points NEAR each query instead of to N -- for large clouds with small balls (BASELINE configs 2, 5).
  * `grid` is caller-provided device scratch of g4d_ball_grid_bytes(b, n) bytes: a per-cloud uniform grid (cell edge 1.01 * rmax)

@@ -243,3 +243,33 @@ def test_fps_bucketed_variant_is_index_exact():
     env = dict(os.environ, G4D_FPS_BUCKET="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("order", ["mesh", "random"])
+@pytest.mark.parametrize("B,N,P", [(2, 6890, 1000), (1, 300, 64), (3, 1722, 130), (1, 64, 1)])
+def test_ball_query_lanes_kernel_equals_the_scan(B, N, P, order, monkeypatch):
+    """g4d_ball_query_lanes_f32 (one lane per query, block culling against the wave's query box) against the scan and the oracle:
+    mesh-ordered and randomly ordered queries (the latter only slower), duplicate / zero-padded clouds, a NaN query, queries far
+    away, P not a multiple of 64."""
+    from garment4d_amd import fused
+    rows = max(2, int(np.sqrt(N)))
+    verts, _ = syn.quad_cylinder(rows, max(2, N // rows))
+    xyz = np.zeros((B, N, 3), np.float32)
+    nv = min(N, verts.shape[0])
+    xyz[:, :nv] = verts[:nv] * np.array([0.8, 0.6, 0.5], np.float32)          # the tail stays zero-padded (ties)
+    xyz += np.random.default_rng(N).standard_normal((B, 1, 3)).astype(np.float32) * 0.01
+    rng = np.random.default_rng(P)
+    sel = np.sort(rng.integers(0, N, P)) if order == "mesh" else rng.integers(0, N, P)
+    q = (xyz[:, sel] * 1.05 + rng.standard_normal((B, P, 3)).astype(np.float32) * 0.01).astype(np.float32)
+    if P > 5:
+        q[0, 3] = np.nan
+        q[-1, 5] = 40.0
+    radii, ns = [0.1, 0.2, 0.4], [8, 16, 32]
+    scan = [t.cpu().numpy() for t in fused.ball_query_msg(radii, ns, dev(xyz), dev(q), coherent=False, grid=False)]
+    monkeypatch.setattr(fused, "COHERENT_LANES", True)
+    for sort in (True, False):           # queries cell-sorted inside the call | taken in the caller's order
+        monkeypatch.setattr(fused, "LANES_SORT", sort)
+        lanes = [t.cpu().numpy() for t in fused.ball_query_msg(radii, ns, dev(xyz), dev(q), coherent=True)]
+        for a, b, r, n_ in zip(lanes, scan, radii, ns):
+            assert np.array_equal(a, b), (order, sort, r)
+            assert np.array_equal(a, K.ball_query(r, n_, xyz, q)), (order, sort, r)
