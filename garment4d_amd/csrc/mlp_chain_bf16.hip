@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "mlp_common.h"
+#include "chain_finish.h"
 
 namespace g4d {
 
@@ -122,28 +123,84 @@ __device__ __forceinline__ f32x4 load4(const LinearArgs &a, const RowCtx<MODE> &
     return v;
 }
 
+// First layer (see mlp_chain.hip first_layer for the measurements behind this shape): rows past the end are clamped, not masked;
+// a 32-column k-step takes the two-16-byte-loads path when it lies inside one source segment -- decided once per step for the
+// whole wave -- and the operands of step ks + 1 are requested before the MFMAs of step ks.
 template <int MODE, int TOUT, int MT, bool LAST>
 __device__ __forceinline__ void first_layer_h(const LinearArgs &a, const ChainLayerH &L, int lane, int row0, f32x4 (&acc)[TOUT][MT]) {
     const int fi = lane & 15, g = lane >> 4;
     RowCtx<MODE> ctx[MT];
+    int rowc[MT];
+    const float *pa[MT], *pa1[MT], *pa2[MT], *pb[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) ctx[mt] = make_ctx<MODE>(a, row0 + mt * 16 + fi);
+    for (int mt = 0; mt < MT; ++mt) {
+        rowc[mt] = min(row0 + mt * 16 + fi, a.rows - 1);
+        ctx[mt] = make_ctx<MODE>(a, rowc[mt]);
+        pa1[mt] = pa2[mt] = pb[mt] = nullptr;
+        if constexpr (MODE == LOAD_GROUP) pa[mt] = (a.feats ? a.feats : a.xyz) + ctx[mt].pt_base * a.C - (a.use_xyz ? 3 : 0);
+        else if constexpr (MODE == LOAD_DIRECT) pa[mt] = a.X + (size_t)rowc[mt] * a.ldx;
+        else { pa[mt] = a.known_feats + ctx[mt].k0; pa1[mt] = a.known_feats + ctx[mt].k1; pa2[mt] = a.known_feats + ctx[mt].k2;
+               pb[mt] = a.skip + ctx[mt].sk - a.C2; }
+    }
+    int a_lo, a_hi, b_lo = 0, b_hi = 0;
+    if constexpr (MODE == LOAD_GROUP) { a_lo = a.use_xyz ? 3 : 0; a_hi = a.K; }
+    else if constexpr (MODE == LOAD_DIRECT) { a_lo = 0; a_hi = a.K; }
+    else { a_lo = 0; a_hi = a.C2; b_lo = a.C2; b_hi = a.K; }
     zero_acc_h<TOUT, MT>(acc);
     const int kst0 = (a.K + 31) >> 5;
+    auto load_b = [&](int ks, uint4 (&b)[MT]) {
+        const int c0 = ks * 32, k_lo = c0 + g * 4, k_hi = c0 + 16 + g * 4;  // this lane's 8 columns: [k_lo, +4) and [k_hi, +4)
+        if (c0 >= a_lo && c0 + 32 <= a_hi) {  // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (MODE == LOAD_INTERP) {
+                    f32x4 lo, hi;
+                    const f32x4 l0 = *reinterpret_cast<const f32x4u_b *>(pa[mt] + k_lo), l1 = *reinterpret_cast<const f32x4u_b *>(pa1[mt] + k_lo),
+                                l2 = *reinterpret_cast<const f32x4u_b *>(pa2[mt] + k_lo);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4u_b *>(pa[mt] + k_hi), h1 = *reinterpret_cast<const f32x4u_b *>(pa1[mt] + k_hi),
+                                h2 = *reinterpret_cast<const f32x4u_b *>(pa2[mt] + k_hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = ctx[mt].w0 * l0[e] + ctx[mt].w1 * l1[e] + ctx[mt].w2 * l2[e];
+                        hi[e] = ctx[mt].w0 * h0[e] + ctx[mt].w1 * h1[e] + ctx[mt].w2 * h2[e];
+                    }
+                    b[mt] = pack8(lo, hi);
+                } else {
+                    const f32x4 lo = *reinterpret_cast<const f32x4u_b *>(pa[mt] + k_lo), hi = *reinterpret_cast<const f32x4u_b *>(pa[mt] + k_hi);
+                    b[mt] = pack8(lo, hi);
+                }
+            }
+        } else if (MODE == LOAD_INTERP && c0 >= b_lo && c0 + 32 <= b_hi) {  // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 lo = *reinterpret_cast<const f32x4u_b *>(pb[mt] + k_lo), hi = *reinterpret_cast<const f32x4u_b *>(pb[mt] + k_hi);
+                b[mt] = pack8(lo, hi);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[mt] = pack8(load4<MODE>(a, ctx[mt], rowc[mt], k_lo), load4<MODE>(a, ctx[mt], rowc[mt], k_hi));
+        }
+    };
+    uint4 wn[TOUT], bn[MT];
+#pragma unroll
+    for (int ct = 0; ct < TOUT; ++ct) wn[ct] = *reinterpret_cast<const uint4 *>(L.W + ((size_t)(ct * L.kst) * 64 + lane) * 8);
+    load_b(0, bn);
     for (int ks = 0; ks < kst0; ++ks) {
-        uint4 b[MT];
+        uint4 w[TOUT], b[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {  // this lane's 8 columns of the 32-block: [4 g, 4 g + 4) and [16 + 4 g, 16 + 4 g + 4)
-            const f32x4 lo = load4<MODE>(a, ctx[mt], row0 + mt * 16 + fi, ks * 32 + g * 4);
-            const f32x4 hi = load4<MODE>(a, ctx[mt], row0 + mt * 16 + fi, ks * 32 + 16 + g * 4);
-            b[mt] = pack8(lo, hi);
+        for (int ct = 0; ct < TOUT; ++ct) w[ct] = wn[ct];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = bn[mt];
+        if (ks + 1 < kst0) {  // wave-uniform
+#pragma unroll
+            for (int ct = 0; ct < TOUT; ++ct) wn[ct] = *reinterpret_cast<const uint4 *>(L.W + ((size_t)(ct * L.kst + ks + 1) * 64 + lane) * 8);
+            load_b(ks + 1, bn);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ct = 0; ct < TOUT; ++ct) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 8);
+        for (int ct = 0; ct < TOUT; ++ct)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = LAST ? mfma32(b[mt], w, acc[ct][mt]) : mfma32(w, b[mt], acc[ct][mt]);
-        }
+            for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = LAST ? mfma32(b[mt], w[ct], acc[ct][mt]) : mfma32(w[ct], b[mt], acc[ct][mt]);
     }
     if (LAST) affine_r_h<TOUT, MT>(L, fi, acc);
     else affine_t_h<TOUT, MT>(L, g, acc);
@@ -165,93 +222,7 @@ __device__ __forceinline__ void chain_layer_h(const ChainLayerH &L, int lane, co
     else affine_t_h<TOUT, MT>(L, g, acc);
 }
 
-// identical to mlp_chain.hip:finish (row-major fp32 tile -> pool / store)
-template <int TOUT, int MT>
-__device__ __forceinline__ void finish_h(const LinearArgs &a, int cout, int lane, int wave, int row0, f32x4 (&acc)[TOUT][MT], float *xch) {
-    const int fi = lane & 15, fq = lane >> 4;
-    if (a.pool == 0) {
-#pragma unroll
-        for (int ct = 0; ct < TOUT; ++ct) {
-            const int ch = ct * 16 + fi;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + mt * 16 + fq * 4 + r;
-                    if (ch < cout && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = acc[ct][mt][r];
-                }
-        }
-        return;
-    }
-    const bool is_max = a.pool == 1;
-    const float inv = is_max ? 1.f : 1.f / (float)a.S;
-    const int S = a.S;
-    constexpr int R = 16 * MT;
-#pragma unroll
-    for (int ct = 0; ct < TOUT; ++ct) {
-        const int ch = ct * 16 + fi;
-        const bool ch_ok = ch < cout;
-        float v[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            v[mt] = is_max ? fmaxf(fmaxf(acc[ct][mt][0], acc[ct][mt][1]), fmaxf(acc[ct][mt][2], acc[ct][mt][3]))
-                           : ((acc[ct][mt][0] + acc[ct][mt][1]) + (acc[ct][mt][2] + acc[ct][mt][3]));
-        if (S < 16) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float x = v[mt];
-                if (S == 8) {
-                    const float y = __shfl_xor(x, 16);
-                    x = is_max ? fmaxf(x, y) : x + y;
-                }
-                const int first_row = row0 + mt * 16 + (S == 8 ? (fq >> 1) * 8 : fq * 4);
-                const bool writer = S == 8 ? (fq & 1) == 0 : true;
-                if (writer && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
-            }
-            continue;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float y = __shfl_xor(v[mt], 16);
-            v[mt] = is_max ? fmaxf(v[mt], y) : v[mt] + y;
-            const float z = __shfl_xor(v[mt], 32);
-            v[mt] = is_max ? fmaxf(v[mt], z) : v[mt] + z;
-        }
-        if (S <= R) {
-            const int tiles_per_group = S >> 4;
-#pragma unroll
-            for (int gi = 0; gi < MT; ++gi) {
-                if (gi * tiles_per_group >= MT) break;
-                float x = v[gi * tiles_per_group];
-#pragma unroll
-                for (int t = 1; t < MT; ++t)
-                    if (t < tiles_per_group) x = is_max ? fmaxf(x, v[gi * tiles_per_group + t]) : x + v[gi * tiles_per_group + t];
-                const int first_row = row0 + gi * S;
-                if (lane < 16 && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / S) * a.ldo + a.col0 + ch] = x * inv;
-            }
-        } else {
-            float x = v[0];
-#pragma unroll
-            for (int t = 1; t < MT; ++t) x = is_max ? fmaxf(x, v[t]) : x + v[t];
-            if (lane < 16) xch[wave * (TOUT * 16) + ch] = x;
-        }
-    }
-    if (a.pool != 0 && S > R) {
-        __syncthreads();
-        const int span = S / R;
-        if ((wave % span) == 0) {
-            for (int ch = lane; ch < TOUT * 16; ch += 64) {
-                float x = xch[wave * (TOUT * 16) + ch];
-                for (int w = 1; w < span; ++w) {
-                    const float y = xch[(wave + w) * (TOUT * 16) + ch];
-                    x = is_max ? fmaxf(x, y) : x + y;
-                }
-                if (ch < cout && row0 < a.rows) a.out[(size_t)(row0 / S) * a.ldo + a.col0 + ch] = x * inv;
-            }
-        }
-    }
-}
-
+// output stage: chain_finish.h (shared with the fp32 kernel; same row-major D layout)
 template <int TOUT, int MT>
 __device__ __forceinline__ void tap_store_h(const ChainArgsH &s, int cout, int lane, int row0, const f32x4 (&h)[TOUT][MT]) {
     const int fi = lane & 15, g = lane >> 4;
@@ -278,7 +249,7 @@ __global__ void __launch_bounds__(256) mlp_chain_bf16_kernel(const ChainArgsH s)
     f32x4 h1[T1][MT];
     if constexpr (T2 == 0) {
         first_layer_h<MODE, T1, MT, true>(a, s.layer[0], lane, row0, h1);
-        finish_h<T1, MT>(a, s.layer[0].cout, lane, wave, row0, h1, xch);
+        finish<T1, MT>(a, s.layer[0].cout, lane, wave, row0, h1, xch);
     } else {
         first_layer_h<MODE, T1, MT, false>(a, s.layer[0], lane, row0, h1);
         if (s.tap_layer == 0) tap_store_h<T1, MT>(s, s.layer[0].cout, lane, row0, h1);
@@ -287,7 +258,7 @@ __global__ void __launch_bounds__(256) mlp_chain_bf16_kernel(const ChainArgsH s)
         f32x4 h2[T2][MT];
         if constexpr (T3 == 0) {
             chain_layer_h<(T1 + 1) / 2, T2, MT, true>(s.layer[1], lane, b1, h2);
-            finish_h<T2, MT>(a, s.layer[1].cout, lane, wave, row0, h2, xch);
+            finish<T2, MT>(a, s.layer[1].cout, lane, wave, row0, h2, xch);
         } else {
             chain_layer_h<(T1 + 1) / 2, T2, MT, false>(s.layer[1], lane, b1, h2);
             if (s.tap_layer == 1) tap_store_h<T2, MT>(s, s.layer[1].cout, lane, row0, h2);
@@ -296,7 +267,7 @@ __global__ void __launch_bounds__(256) mlp_chain_bf16_kernel(const ChainArgsH s)
             f32x4 h3[T3][MT];
             if constexpr (T4 == 0) {
                 chain_layer_h<(T2 + 1) / 2, T3, MT, true>(s.layer[2], lane, b2, h3);
-                finish_h<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
+                finish<T3, MT>(a, s.layer[2].cout, lane, wave, row0, h3, xch);
             } else {
                 chain_layer_h<(T2 + 1) / 2, T3, MT, false>(s.layer[2], lane, b2, h3);
                 if (s.tap_layer == 2) tap_store_h<T3, MT>(s, s.layer[2].cout, lane, row0, h3);
@@ -304,7 +275,7 @@ __global__ void __launch_bounds__(256) mlp_chain_bf16_kernel(const ChainArgsH s)
                 to_frags<T3, MT>(h3, b3);
                 f32x4 h4[T4][MT];
                 chain_layer_h<(T3 + 1) / 2, T4, MT, true>(s.layer[3], lane, b3, h4);
-                finish_h<T4, MT>(a, s.layer[3].cout, lane, wave, row0, h4, xch);
+                finish<T4, MT>(a, s.layer[3].cout, lane, wave, row0, h4, xch);
             }
         }
     }
