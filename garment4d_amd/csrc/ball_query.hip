@@ -35,15 +35,19 @@ struct BqArgs {
 typedef g4d_f32x2 f32x2;
 constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered; a multiple of 128 (two points per lane and step)
 
-// boxes: per (frame, 64-point block) axis-aligned bounds [lo.xyz, hi.xyz], written by ball_boxes_kernel
+// boxes: per (frame, G-point block) axis-aligned bounds [lo.xyz, hi.xyz]; G = 64 (one wave per block: the lanes kernel) or
+// 16 (one 16-lane row per sub-block: ball_query_kernel's BOXES variant)
+template <int G>
 __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long long total, const float *__restrict__ xyz_all,
                                                         float *__restrict__ boxes) {
+    constexpr int PER_WAVE = 64 / G;
     const int lane = threadIdx.x & 63;
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= total) return;
-    const long long b = w / nblk;
-    const int blk = (int)(w - b * nblk);
-    const int k = blk * 64 + lane;
+    const long long w = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PER_WAVE + lane / G;
+    const bool live = w < total;
+    const long long wc = live ? w : total - 1;
+    const long long b = wc / nblk;
+    const int blk = (int)(wc - b * nblk);
+    const int k = blk * G + (lane % G);
     const float inf = __builtin_inff();
     float lo[3], hi[3];
 #pragma unroll
@@ -53,13 +57,13 @@ __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long l
         hi[d] = k < n ? v : -inf;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = G / 2; o > 0; o >>= 1)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
             hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
         }
-    if (lane == 0) {
+    if (live && (lane % G) == 0) {
         float *o = boxes + (size_t)w * 6;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
     }
@@ -120,15 +124,19 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
         if (more) load_stage(base + kStage);  // in flight while this stage is consumed
         const int cn = min(kStage, n - base);
         if (BOXES) {
-            // Mesh-ordered clouds: consecutive indices are neighbours in space, so most 64-point blocks lie wholly outside
-            // a query's largest still-open ball.  Lane l < 16 tests block l of the stage against the query with the SAME
-            // fp32 expression (same contraction shape FM) as the point test: rounding is monotone, so box d2 <= d2 of every point inside
-            // the box and a block holding a hit is never skipped.  Blocks are then visited in ascending order, so the
-            // "first nsample hits by index" semantics is untouched.
-            const int nblk = (n + 63) >> 6;
-            const int sb = base >> 6, nb_stage = (cn + 63) >> 6;
-            const float *bx = boxes_all + ((size_t)b * nblk + sb + min(lane, nb_stage - 1)) * 6;
+            // Mesh-ordered clouds: consecutive indices are neighbours in space, so most of the cloud lies wholly outside a
+            // query's largest still-open ball.  The cloud is cut into SUB-BLOCKS of 16 consecutive points; lane l tests
+            // sub-block l of the stage (64 per 1024-point stage) against the query with the SAME fp32 expression (same
+            // contraction shape FM) as the point test: rounding is monotone, so box d2 <= d2 of every point inside the box
+            // and a sub-block holding a hit is never skipped.  The surviving sub-blocks are then visited four at a time in
+            // ascending order -- lanes 0-15 the lowest, 16-31 the next, ... -- so lane order is still index order and the
+            // ballot + mbcnt prefix still yields "the first nsample hits by index".  (Round 1 culled 64-point blocks: a
+            // quarter of the box tests, but ~2.5x as many point tests on config 4's body query.)
+            const int nsub = (n + 15) >> 4;
+            const int sb0 = base >> 4, nsub_stage = (cn + 15) >> 4;
+            const float *bx = boxes_all + ((size_t)b * nsub + sb0 + min(lane, nsub_stage - 1)) * 6;
             const float lox = bx[0], loy = bx[1], loz = bx[2], hix = bx[3], hiy = bx[4], hiz = bx[5];
+            const int grp = lane >> 4, sub = lane & 15;
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
                 float r2open = -1.f;  // largest radius^2 among this query's scales that still collect
@@ -139,32 +147,50 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 const float ex = fmaxf(fmaxf(lox - qx[i], qx[i] - hix), 0.f), ey = fmaxf(fmaxf(loy - qy[i], qy[i] - hiy), 0.f),
                             ez = fmaxf(fmaxf(loz - qz[i], qz[i] - hiz), 0.f);
                 const float bd2 = dist2<FM>(ex, ey, ez);
-                unsigned cand = (unsigned)__builtin_amdgcn_ballot_w64(lane < nb_stage && bd2 < r2open);
+                unsigned long long cand = __builtin_amdgcn_ballot_w64(lane < nsub_stage && bd2 < r2open);
                 while (cand) {
-                    const int c = __builtin_ctz(cand) << 6;
+                    // the four lowest surviving sub-blocks (64 = none left)
+                    const int s0 = __builtin_ctzll(cand);
                     cand &= cand - 1;
-                    const int k = base + c + lane;
-                    const float x = sp[buf][0][c + lane], y = sp[buf][1][c + lane], z = sp[buf][2][c + lane];
+                    const int s1 = cand ? __builtin_ctzll(cand) : 64;
+                    cand &= cand ? cand - 1 : 0ull;
+                    const int s2 = cand ? __builtin_ctzll(cand) : 64;
+                    cand &= cand ? cand - 1 : 0ull;
+                    const int s3 = cand ? __builtin_ctzll(cand) : 64;
+                    cand &= cand ? cand - 1 : 0ull;
+                    const int mine = grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : s3));
+                    const int c = mine * 16 + sub;                 // position inside the stage
+                    const bool live = mine < 64 && c < cn;
+                    const int cc = live ? c : 0;
+                    const int k = base + cc;
+                    const float x = sp[buf][0][cc], y = sp[buf][1][cc], z = sp[buf][2][cc];
                     const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
-                    const float d2 = dist2<FM>(dx, dy, dz);
+                    const float d2 = live ? dist2<FM>(dx, dy, dz) : __builtin_inff();
                     if (__builtin_amdgcn_ballot_w64(d2 < r2open) == 0ull) continue;
-                    bool any_open = false;
+                    bool any_open = false, closed = false;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
                             const bool hit = d2 < a.radius2[s];
                             const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                             if (mask != 0ull) {
-                                if (cnt[i][s] == 0) first[i][s] = base + c + __builtin_ctzll(mask);
+                                if (cnt[i][s] == 0) first[i][s] = __builtin_amdgcn_readlane(k, __builtin_ctzll(mask));
                                 const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                 if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
                                 cnt[i][s] += __builtin_popcountll(mask);
-                                if (cnt[i][s] >= a.nsample[s]) --open;
+                                if (cnt[i][s] >= a.nsample[s]) { --open; closed = true; }
                             }
                             any_open |= cnt[i][s] < a.nsample[s];
                         }
                     }
                     if (!any_open) break;
+                    if (closed) {  // a scale filled: shrink the pruning radius and drop the sub-blocks it no longer reaches
+                        r2open = -1.f;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+                            if (cnt[i][s] < a.nsample[s]) r2open = fmaxf(r2open, a.radius2[s]);
+                        cand &= __builtin_amdgcn_ballot_w64(bd2 < r2open);
+                    }
                 }
             }
         } else
@@ -357,9 +383,9 @@ static int ball_query_msg_impl(int b, int n, int m, int nscales, const float *ra
     while (qw > 1 && queries / qw < min_waves) qw >>= 1;
     dim3 grid((m + 4 * qw - 1) / (4 * qw), b);
     if (boxes) {
-        const int nblk = (n + 63) / 64;
+        const int nblk = (n + 15) / 16;   // 16-point sub-blocks
         const long long total = (long long)b * nblk;
-        hipLaunchKernelGGL(ball_boxes_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
+        hipLaunchKernelGGL(ball_boxes_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
         switch (nscales) {
             case 1: launch_bq<1, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
             case 2: launch_bq<2, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
@@ -413,7 +439,7 @@ extern "C" int g4d_ball_query_lanes_f32(int b, int n, int m, int nscales, const 
     G4D_REQUIRE(new_xyz && xyz && boxes, "g4d_ball_query_lanes_f32: null pointer (boxes scratch = b * ceil(n/64) * 6 floats)");
     const int nblk = (n + 63) / 64;
     const long long total = (long long)b * nblk;
-    hipLaunchKernelGGL(ball_boxes_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
+    hipLaunchKernelGGL(ball_boxes_kernel<64>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
     dim3 grid((unsigned)((m + 255) / 256), (unsigned)b);
     const unsigned char *qg = reinterpret_cast<const unsigned char *>(qsort);
     const size_t qstride = grid_bytes_per_cloud(m), qoff = grid_records_offset(m);

@@ -378,7 +378,7 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
             _lib.call("g4d_ball_grid_query_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
                       new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), grid[0].data_ptr(), grid[1], _lib.stream_ptr())
         elif coherent and N >= 256:
-            boxes = torch.empty((B, (N + 63) // 64, 6), dtype=torch.float32, device=xyz.device)
+            boxes = torch.empty((B, (N + 15) // 16, 6), dtype=torch.float32, device=xyz.device)   # 16-point sub-block bounds
             if COHERENT_LANES:   # one lane per query; the queries are cell-sorted first so that a wave's 64 are compact
                 qs = torch.empty(max(_lib.lib().g4d_ball_query_lanes_qsort_bytes(B, P), 16), dtype=torch.uint8, device=xyz.device) if LANES_SORT else None
                 _lib.call("g4d_ball_query_lanes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),

@@ -90,8 +90,8 @@ int g4d_ball_query_msg_f32(int b, int n, int m, int nscales, const float *radii,
                            const float *new_xyz, const float *xyz, int *const *idx, g4d_stream_t stream);
 
 /* g4d_ball_query_msg_f32 for clouds whose index order is spatially coherent (mesh vertices in mesh order: the body and
- * garment queries of modules/mesh_encoder.py:452-464): a pre-pass writes the bounds of every 64-point block into `boxes`
- * (b * ceil(n/64) * 6 floats of scratch) and the search skips blocks that lie outside the largest still-open ball
+ * garment queries of modules/mesh_encoder.py:452-464): a pre-pass writes the bounds of every 16-point sub-block into `boxes`
+ * (b * ceil(n/16) * 6 floats of scratch) and the search skips sub-blocks that lie outside the largest still-open ball
  * (monotone fp32 bound: never skips a hit).  Same results as g4d_ball_query_msg_f32 for ANY cloud; faster only for
  * coherent ones (a few % slower for random order). */
 int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const float *radii, const int *nsamples, const float *new_xyz,
@@ -99,8 +99,8 @@ int g4d_ball_query_boxes_f32(int b, int n, int m, int nscales, const float *radi
 
 /* g4d_ball_query_msg_f32 for COHERENT query sets (64 consecutive queries close together: mesh vertices in mesh order) against an
  * index-coherent cloud, dense balls (far more hits than nsample): one LANE per query, the cloud's 64-point blocks visited in index
- * order by the whole wave, blocks culled against the bounding box of the wave's still-collecting queries (`boxes` = the same
- * b * ceil(n/64) * 6 floats of scratch as g4d_ball_query_boxes_f32).  `qsort`: optional g4d_ball_query_lanes_qsort_bytes(b, m)
+ * order by the whole wave, blocks culled against the bounding box of the wave's still-collecting queries (`boxes` =
+ * b * ceil(n/64) * 6 floats of scratch; the buffer of g4d_ball_query_boxes_f32 is large enough).  `qsort`: optional g4d_ball_query_lanes_qsort_bytes(b, m)
  * bytes of scratch -- when given, the queries are first counting-sorted into cells of half the largest radius, so that the 64
  * queries of a wave are compact WHATEVER order the caller's queries come in (NULL: the caller's order is used as is and had
  * better be coherent).  Same results as g4d_ball_query_msg_f32 for ANY input. */
