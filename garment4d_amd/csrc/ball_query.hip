@@ -246,6 +246,141 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
 }
 
+// Sub-block-culled ball query WITHOUT the LDS staging: once 16-point sub-blocks are culled a query visits a few percent of the
+// cloud, so staging every 1024-point stage through LDS (and the two barriers per stage that tie the block's waves together)
+// costs more than the visited points.  A wave owns QW queries and is on its own: lane l tests sub-block chunk*64 + l, the
+// surviving sub-blocks are read straight from global memory (192 contiguous bytes each: L1 / L2 hits -- a frame's cloud is
+// 83 KB), four per step in ascending order.  Same hit order, same rounding, same output as ball_query_kernel.
+template <int QW, int NS, int FM>
+__global__ void __launch_bounds__(256) ball_query_sub_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
+                                                            const float *__restrict__ xyz_all, const float *__restrict__ boxes_all) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * QW;
+    if (q0 >= m) return;  // no barrier in this kernel
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
+    float qx[QW], qy[QW], qz[QW];
+    int cnt[QW][NS], first[QW][NS];
+    int open = 0;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = min(q0 + i, m - 1);
+        qx[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 0])));
+        qy[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 1])));
+        qz[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(new_xyz[q * 3 + 2])));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cnt[i][s] = (q0 + i < m) ? 0 : a.nsample[s];
+            first[i][s] = 0;
+            open += (q0 + i < m) ? 1 : 0;
+        }
+    }
+    const int nsub = (n + 15) >> 4;
+    const float *boxes = boxes_all + (size_t)b * nsub * 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    // Cost model (measured, 240 x 4096 queries on 6890 points): ~4 steps and ~3.5 box chunks per query; the walk is bound by
+    // instruction issue (each wave64 VALU op takes 4 cycles), not by load latency -- keeping the chains of 2 or 4 queries of a wave
+    // in flight together (all point loads of a step issued before any is looked at) changed nothing (QW = 1: 597-690 us, QW = 2:
+    // 690-755, QW = 4: 704-920), so a wave owns ONE query and only the next chunk's boxes are prefetched.
+    float nb[6];
+    {
+        const float *bx = boxes + (size_t)min(lane, nsub - 1) * 6;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) nb[d] = bx[d];
+    }
+    for (int sb0 = 0; sb0 < nsub && open > 0; sb0 += 64) {
+        const int nss = min(64, nsub - sb0);
+        const float lox = nb[0], loy = nb[1], loz = nb[2], hix = nb[3], hiy = nb[4], hiz = nb[5];
+        if (sb0 + 64 < nsub) {
+            const float *bx = boxes + (size_t)min(sb0 + 64 + lane, nsub - 1) * 6;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) nb[d] = bx[d];
+        }
+        unsigned long long cand[QW];
+        float bd2[QW], r2open[QW];
+        unsigned long long anyc = 0ull;
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            r2open[i] = -1.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (cnt[i][s] < a.nsample[s]) r2open[i] = fmaxf(r2open[i], a.radius2[s]);
+            const float ex = fmaxf(fmaxf(lox - qx[i], qx[i] - hix), 0.f), ey = fmaxf(fmaxf(loy - qy[i], qy[i] - hiy), 0.f),
+                        ez = fmaxf(fmaxf(loz - qz[i], qz[i] - hiz), 0.f);
+            bd2[i] = dist2<FM>(ex, ey, ez);
+            cand[i] = __builtin_amdgcn_ballot_w64(lane < nss && bd2[i] < r2open[i]);  // r2open = -1: nothing passes
+            anyc |= cand[i];
+        }
+        while (anyc) {
+            float x[QW], y[QW], z[QW];
+            int k[QW];
+            bool live[QW], had[QW];
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {  // the four lowest surviving sub-blocks of every query (64 = none left); loads issued for all
+                unsigned long long c = cand[i];
+                had[i] = c != 0ull;
+                const int s0 = c ? __builtin_ctzll(c) : 64;
+                c &= c ? c - 1 : 0ull;
+                const int s1 = c ? __builtin_ctzll(c) : 64;
+                c &= c ? c - 1 : 0ull;
+                const int s2 = c ? __builtin_ctzll(c) : 64;
+                c &= c ? c - 1 : 0ull;
+                const int s3 = c ? __builtin_ctzll(c) : 64;
+                c &= c ? c - 1 : 0ull;
+                cand[i] = c;
+                const int mine = grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : s3));
+                const int kk = (sb0 + mine) * 16 + sub;
+                live[i] = mine < 64 && kk < n;
+                k[i] = live[i] ? kk : 0;
+                x[i] = xyz[k[i] * 3 + 0]; y[i] = xyz[k[i] * 3 + 1]; z[i] = xyz[k[i] * 3 + 2];
+            }
+            anyc = 0ull;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                if (had[i]) {  // wave-uniform
+                    const float dx = qx[i] - x[i], dy = qy[i] - y[i], dz = qz[i] - z[i];
+                    const float d2 = live[i] ? dist2<FM>(dx, dy, dz) : __builtin_inff();
+                    if (__builtin_amdgcn_ballot_w64(d2 < r2open[i]) != 0ull) {
+                        bool any_open = false, closed = false;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
+                                const bool hit = d2 < a.radius2[s];
+                                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                                if (mask != 0ull) {
+                                    if (cnt[i][s] == 0) first[i][s] = __builtin_amdgcn_readlane(k[i], __builtin_ctzll(mask));
+                                    const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                    if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k[i];
+                                    cnt[i][s] += __builtin_popcountll(mask);
+                                    if (cnt[i][s] >= a.nsample[s]) { --open; closed = true; }
+                                }
+                                any_open |= cnt[i][s] < a.nsample[s];
+                            }
+                        }
+                        if (!any_open) cand[i] = 0ull;
+                        else if (closed) {  // a scale filled: shrink the pruning radius, drop the sub-blocks it no longer reaches
+                            r2open[i] = -1.f;
+#pragma unroll
+                            for (int s = 0; s < NS; ++s)
+                                if (cnt[i][s] < a.nsample[s]) r2open[i] = fmaxf(r2open[i], a.radius2[s]);
+                            cand[i] &= __builtin_amdgcn_ballot_w64(bd2[i] < r2open[i]);
+                        }
+                    }
+                }
+                anyc |= cand[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QW; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (q0 + i < m && cnt[i][s] < a.nsample[s])
+                for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
+}
+
 // "Lanes = queries" ball query for SPATIALLY COHERENT query sets against an index-coherent cloud (the body / garment queries of
 // modules/mesh_encoder.py:452-464: 64 consecutive garment vertices form a compact patch, 64 consecutive body vertices a compact
 // block).  The dense regime -- balls holding 100-2000 points of which 8-32 are wanted -- is decided by early exit in index
@@ -339,6 +474,16 @@ __global__ void __launch_bounds__(256) ball_query_lanes_kernel(int n, int m, con
     }
 }
 
+template <int NS, int FM>
+void launch_bq_sub_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz, const float *boxes) {
+    (void)qw;
+    hipLaunchKernelGGL((ball_query_sub_kernel<1, NS, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+}
+template <int NS>
+void launch_bq_sub(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz, const float *boxes) {
+    G4D_WITH_FM(distance_contraction(), (launch_bq_sub_fm<NS, FM>(qw, grid, st, n, m, a, new_xyz, xyz, boxes)))
+}
+
 template <int NS, bool BOXES, int FM>
 static void launch_bq_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
                          const float *boxes) {
@@ -386,6 +531,18 @@ static int ball_query_msg_impl(int b, int n, int m, int nscales, const float *ra
         const int nblk = (n + 15) / 16;   // 16-point sub-blocks
         const long long total = (long long)b * nblk;
         hipLaunchKernelGGL(ball_boxes_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
+        static const int direct = [] { const char *e = getenv("G4D_BQ_SUB_DIRECT"); return e ? atoi(e) : 1; }();
+        if (direct) {
+            qw = 1;  // see the cost model in ball_query_sub_kernel
+            grid = dim3((m + 3) / 4, b);
+            switch (nscales) {
+                case 1: launch_bq_sub<1>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+                case 2: launch_bq_sub<2>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+                case 3: launch_bq_sub<3>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+                default: launch_bq_sub<4>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            }
+            return check_launch("g4d_ball_query_boxes_f32");
+        }
         switch (nscales) {
             case 1: launch_bq<1, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
             case 2: launch_bq<2, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
