@@ -36,7 +36,7 @@ typedef g4d_f32x2 f32x2;
 constexpr int kStage = 1024;  // points per LDS stage (SoA: 3 x 4 KB), double buffered; a multiple of 128 (two points per lane and step)
 
 // boxes: per (frame, G-point block) axis-aligned bounds [lo.xyz, hi.xyz]; G = 64 (one wave per block: the lanes kernel) or
-// 16 (one 16-lane row per sub-block: ball_query_kernel's BOXES variant)
+// 16 (one 16-lane row per sub-block: ball_query_sub_kernel)
 template <int G>
 __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long long total, const float *__restrict__ xyz_all,
                                                         float *__restrict__ boxes) {
@@ -69,9 +69,9 @@ __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long l
     }
 }
 
-template <int QW, int NS, bool BOXES, int FM>
+template <int QW, int NS, int FM>
 __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
-                                                        const float *__restrict__ xyz_all, const float *__restrict__ boxes_all) {
+                                                        const float *__restrict__ xyz_all) {
     __shared__ float sp[2][3][kStage];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -123,77 +123,6 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
         const bool more = base + kStage < n;
         if (more) load_stage(base + kStage);  // in flight while this stage is consumed
         const int cn = min(kStage, n - base);
-        if (BOXES) {
-            // Mesh-ordered clouds: consecutive indices are neighbours in space, so most of the cloud lies wholly outside a
-            // query's largest still-open ball.  The cloud is cut into SUB-BLOCKS of 16 consecutive points; lane l tests
-            // sub-block l of the stage (64 per 1024-point stage) against the query with the SAME fp32 expression (same
-            // contraction shape FM) as the point test: rounding is monotone, so box d2 <= d2 of every point inside the box
-            // and a sub-block holding a hit is never skipped.  The surviving sub-blocks are then visited four at a time in
-            // ascending order -- lanes 0-15 the lowest, 16-31 the next, ... -- so lane order is still index order and the
-            // ballot + mbcnt prefix still yields "the first nsample hits by index".  (Round 1 culled 64-point blocks: a
-            // quarter of the box tests, but ~2.5x as many point tests on config 4's body query.)
-            const int nsub = (n + 15) >> 4;
-            const int sb0 = base >> 4, nsub_stage = (cn + 15) >> 4;
-            const float *bx = boxes_all + ((size_t)b * nsub + sb0 + min(lane, nsub_stage - 1)) * 6;
-            const float lox = bx[0], loy = bx[1], loz = bx[2], hix = bx[3], hiy = bx[4], hiz = bx[5];
-            const int grp = lane >> 4, sub = lane & 15;
-#pragma unroll
-            for (int i = 0; i < QW; ++i) {
-                float r2open = -1.f;  // largest radius^2 among this query's scales that still collect
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (cnt[i][s] < a.nsample[s]) r2open = fmaxf(r2open, a.radius2[s]);
-                if (r2open < 0.f) continue;
-                const float ex = fmaxf(fmaxf(lox - qx[i], qx[i] - hix), 0.f), ey = fmaxf(fmaxf(loy - qy[i], qy[i] - hiy), 0.f),
-                            ez = fmaxf(fmaxf(loz - qz[i], qz[i] - hiz), 0.f);
-                const float bd2 = dist2<FM>(ex, ey, ez);
-                unsigned long long cand = __builtin_amdgcn_ballot_w64(lane < nsub_stage && bd2 < r2open);
-                while (cand) {
-                    // the four lowest surviving sub-blocks (64 = none left)
-                    const int s0 = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    const int s1 = cand ? __builtin_ctzll(cand) : 64;
-                    cand &= cand ? cand - 1 : 0ull;
-                    const int s2 = cand ? __builtin_ctzll(cand) : 64;
-                    cand &= cand ? cand - 1 : 0ull;
-                    const int s3 = cand ? __builtin_ctzll(cand) : 64;
-                    cand &= cand ? cand - 1 : 0ull;
-                    const int mine = grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : s3));
-                    const int c = mine * 16 + sub;                 // position inside the stage
-                    const bool live = mine < 64 && c < cn;
-                    const int cc = live ? c : 0;
-                    const int k = base + cc;
-                    const float x = sp[buf][0][cc], y = sp[buf][1][cc], z = sp[buf][2][cc];
-                    const float dx = qx[i] - x, dy = qy[i] - y, dz = qz[i] - z;
-                    const float d2 = live ? dist2<FM>(dx, dy, dz) : __builtin_inff();
-                    if (__builtin_amdgcn_ballot_w64(d2 < r2open) == 0ull) continue;
-                    bool any_open = false, closed = false;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        if (cnt[i][s] < a.nsample[s]) {  // wave-uniform
-                            const bool hit = d2 < a.radius2[s];
-                            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                            if (mask != 0ull) {
-                                if (cnt[i][s] == 0) first[i][s] = __builtin_amdgcn_readlane(k, __builtin_ctzll(mask));
-                                const int slot = cnt[i][s] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                if (hit && slot < a.nsample[s]) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + slot] = k;
-                                cnt[i][s] += __builtin_popcountll(mask);
-                                if (cnt[i][s] >= a.nsample[s]) { --open; closed = true; }
-                            }
-                            any_open |= cnt[i][s] < a.nsample[s];
-                        }
-                    }
-                    if (!any_open) break;
-                    if (closed) {  // a scale filled: shrink the pruning radius and drop the sub-blocks it no longer reaches
-                        r2open = -1.f;
-#pragma unroll
-                        for (int s = 0; s < NS; ++s)
-                            if (cnt[i][s] < a.nsample[s]) r2open = fmaxf(r2open, a.radius2[s]);
-                        cand &= __builtin_amdgcn_ballot_w64(bd2 < r2open);
-                    }
-                }
-            }
-        } else
         for (int c = 0; c < cn && open > 0; c += 128) {
             // two points per lane and step (c + lane, c + 64 + lane): the distance arithmetic runs on the packed fp32 pipe
             // (v_pk_add / v_pk_mul: same IEEE results per component, half the instructions); lanes past the end of the cloud
@@ -246,11 +175,21 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
 }
 
-// Sub-block-culled ball query WITHOUT the LDS staging: once 16-point sub-blocks are culled a query visits a few percent of the
-// cloud, so staging every 1024-point stage through LDS (and the two barriers per stage that tie the block's waves together)
-// costs more than the visited points.  A wave owns QW queries and is on its own: lane l tests sub-block chunk*64 + l, the
-// surviving sub-blocks are read straight from global memory (192 contiguous bytes each: L1 / L2 hits -- a frame's cloud is
-// 83 KB), four per step in ascending order.  Same hit order, same rounding, same output as ball_query_kernel.
+// Sub-block-culled ball query for index-coherent clouds (g4d_ball_query_boxes_f32: the body / garment queries of
+// modules/mesh_encoder.py:452-464, where consecutive vertex indices are neighbours in space, so most of the cloud lies wholly
+// outside a query's largest still-open ball).
+//   * The cloud is cut into SUB-BLOCKS of 16 consecutive points whose bounds a pre-pass wrote (ball_boxes_kernel<16>).  Lane l
+//     tests sub-block chunk*64 + l against the query with the SAME fp32 expression (same contraction shape FM) as the point test:
+//     rounding is monotone, so box d2 <= d2 of every point inside the box and a sub-block holding a hit is never skipped.
+//   * The surviving sub-blocks are visited four per step in ascending order -- lanes 0-15 the lowest, 16-31 the next, ... -- so lane
+//     order is still index order and the ballot + mbcnt prefix still yields "the first nsample hits by index".
+//   * When a scale fills, the pruning radius drops to the largest radius still collecting and the candidate mask is re-filtered.
+//   * No LDS staging, no barrier: a query visits a few percent of the cloud, so streaming every 1024-point stage through LDS (and
+//     the two barriers per stage that tie a workgroup's waves together) cost more than the visited points (800-880 us staged,
+//     580-690 us direct).  The survivors are read straight from global memory (192 contiguous bytes each: L1 / L2 hits -- a
+//     frame's cloud is 83 KB).
+// Same hit order, same rounding, same output as ball_query_kernel for ANY input (coherent or not: only the speed depends on it).
+// History: round 1 culled 64-point blocks inside the LDS-staged scan (1.3 ms on the same case, no better than the plain scan).
 template <int QW, int NS, int FM>
 __global__ void __launch_bounds__(256) ball_query_sub_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
                                                             const float *__restrict__ xyz_all, const float *__restrict__ boxes_all) {
@@ -475,27 +414,24 @@ __global__ void __launch_bounds__(256) ball_query_lanes_kernel(int n, int m, con
 }
 
 template <int NS, int FM>
-void launch_bq_sub_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz, const float *boxes) {
-    (void)qw;
+static void launch_bq_sub_fm(dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz, const float *boxes) {
     hipLaunchKernelGGL((ball_query_sub_kernel<1, NS, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
 }
 template <int NS>
-void launch_bq_sub(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz, const float *boxes) {
-    G4D_WITH_FM(distance_contraction(), (launch_bq_sub_fm<NS, FM>(qw, grid, st, n, m, a, new_xyz, xyz, boxes)))
+static void launch_bq_sub(dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz, const float *boxes) {
+    G4D_WITH_FM(distance_contraction(), (launch_bq_sub_fm<NS, FM>(grid, st, n, m, a, new_xyz, xyz, boxes)))
 }
 
-template <int NS, bool BOXES, int FM>
-static void launch_bq_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
-                         const float *boxes) {
-    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS, BOXES, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
-    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS, BOXES, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
-    else hipLaunchKernelGGL((ball_query_kernel<1, NS, BOXES, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz, boxes);
+template <int NS, int FM>
+static void launch_bq_fm(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz) {
+    if (qw == 4) hipLaunchKernelGGL((ball_query_kernel<4, NS, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
+    else if (qw == 2) hipLaunchKernelGGL((ball_query_kernel<2, NS, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
+    else hipLaunchKernelGGL((ball_query_kernel<1, NS, FM>), grid, dim3(256), 0, st, n, m, a, new_xyz, xyz);
 }
 
-template <int NS, bool BOXES>
-static void launch_bq(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz,
-                      const float *boxes) {
-    G4D_WITH_FM(distance_contraction(), (launch_bq_fm<NS, BOXES, FM>(qw, grid, st, n, m, a, new_xyz, xyz, boxes)))
+template <int NS>
+static void launch_bq(int qw, dim3 grid, hipStream_t st, int n, int m, const BqArgs &a, const float *new_xyz, const float *xyz) {
+    G4D_WITH_FM(distance_contraction(), (launch_bq_fm<NS, FM>(qw, grid, st, n, m, a, new_xyz, xyz)))
 }
 
 }  // namespace g4d
@@ -531,31 +467,20 @@ static int ball_query_msg_impl(int b, int n, int m, int nscales, const float *ra
         const int nblk = (n + 15) / 16;   // 16-point sub-blocks
         const long long total = (long long)b * nblk;
         hipLaunchKernelGGL(ball_boxes_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, n, nblk, total, xyz, boxes);
-        static const int direct = [] { const char *e = getenv("G4D_BQ_SUB_DIRECT"); return e ? atoi(e) : 1; }();
-        if (direct) {
-            qw = 1;  // see the cost model in ball_query_sub_kernel
-            grid = dim3((m + 3) / 4, b);
-            switch (nscales) {
-                case 1: launch_bq_sub<1>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-                case 2: launch_bq_sub<2>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-                case 3: launch_bq_sub<3>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-                default: launch_bq_sub<4>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-            }
-            return check_launch("g4d_ball_query_boxes_f32");
-        }
+        grid = dim3((m + 3) / 4, b);  // one query per wave: see the cost model in ball_query_sub_kernel
         switch (nscales) {
-            case 1: launch_bq<1, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-            case 2: launch_bq<2, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-            case 3: launch_bq<3, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
-            default: launch_bq<4, true>(qw, grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            case 1: launch_bq_sub<1>(grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            case 2: launch_bq_sub<2>(grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            case 3: launch_bq_sub<3>(grid, st, n, m, a, new_xyz, xyz, boxes); break;
+            default: launch_bq_sub<4>(grid, st, n, m, a, new_xyz, xyz, boxes); break;
         }
         return check_launch("g4d_ball_query_boxes_f32");
     }
     switch (nscales) {
-        case 1: launch_bq<1, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
-        case 2: launch_bq<2, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
-        case 3: launch_bq<3, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
-        default: launch_bq<4, false>(qw, grid, st, n, m, a, new_xyz, xyz, nullptr); break;
+        case 1: launch_bq<1>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        case 2: launch_bq<2>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        case 3: launch_bq<3>(qw, grid, st, n, m, a, new_xyz, xyz); break;
+        default: launch_bq<4>(qw, grid, st, n, m, a, new_xyz, xyz); break;
     }
     return check_launch("g4d_ball_query_msg_f32");
 }

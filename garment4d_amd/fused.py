@@ -335,10 +335,10 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
 # captured hipGraph the fork / join costs more than the overlap gains (single-batch latency 1.46 -> 1.57 ms, 16-batch throughput
 # 23.3k -> 10.8k frames/s: the runtime serialises graph branches through extra cross-stream dependencies); DESIGN.md section 5
 OVERLAP_SAMPLING = os.environ.get("G4D_OVERLAP_SAMPLING", "0") != "0"
-# coherent=True route.  Default: wave-per-query with 64-point block bounds (g4d_ball_query_boxes_f32), robust to the vertex numbering.
-# G4D_BQ_LANES=1: one LANE per query (g4d_ball_query_lanes_f32) -- measured on config 4's body query (983k queries x 6890 points,
-# scripts/time_body_query.py): 0.78 ms vs 1.33 ms when the queries of a wave sit at one height of a ring-ordered body (the
-# synthetic scene), but 2.0 ms vs 1.28 ms for a patch-ordered body and 4.1-4.6 ms for incoherent queries; cell-sorting the queries
+# coherent=True route.  Default: wave-per-query walk over 16-point sub-block bounds (g4d_ball_query_boxes_f32), robust to the vertex
+# numbering: 0.58-0.69 ms on config 4's body query (983k queries x 6890 points, scripts/time_body_query.py; plain scan 1.3-1.8 ms).
+# G4D_BQ_LANES=1: one LANE per query (g4d_ball_query_lanes_f32) -- 0.78 ms when the queries of a wave sit at one height of a ring-ordered body (the
+# synthetic scene), but 2.0 ms for a patch-ordered body and 4.1-4.6 ms for incoherent queries; cell-sorting the queries
 # first (G4D_BQ_LANES_SORT=1) makes waves compact but lets their lanes fill at different times: 2.2-2.7 ms.  Off by default.
 LANES_SORT = os.environ.get("G4D_BQ_LANES_SORT", "0") != "0"
 COHERENT_LANES = os.environ.get("G4D_BQ_LANES", "0") != "0"
