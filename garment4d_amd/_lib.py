@@ -48,6 +48,7 @@ SIGNATURES = {
     "g4d_transpose_f32": [_I, _I, _I, _vp, _vp, _vp],
     "g4d_interp_concat_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_spmm_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp],
+    "g4d_gcn_agg_linear_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp],
     "g4d_knn_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_knn_blend_weights_f32": [_I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_pos_encode_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp],

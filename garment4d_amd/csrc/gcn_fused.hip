@@ -1,0 +1,247 @@
+// Fused "aggregate, then the next layer's contraction" for the GCN stacks of the refinement loop
+// (/root/reference/modules/mesh_encoder.py:477-481 calling modules/pygcn/layers.py:35-55 four times per round).
+//
+// A GraphConvolution is  h = act(Ahat (X W) + b).  Chained, the aggregation of layer i and the contraction of layer i+1 are
+//     h_i = act(Ahat S_i + b_i)        (SpMM: reads S_i seven times through L2 -- once per neighbour -- writes h_i)
+//     S_{i+1} = h_i W_{i+1}            (reads h_i back, writes S_{i+1})
+// At 240 frames x 4096 vertices x 128 channels each tensor is 503 MB, and the two launches took 344 + 410 us.  This kernel does
+// both for a tile of 128 consecutive vertices of one frame, in the REFERENCE's operation order (aggregate the already contracted
+// rows, add the bias, activate, then contract with the next weight), so h_i never exists in HBM unless the caller asks for it
+// (`tap`: the third layer's output feeds the next round's attention):
+//   * Mesh numberings are local: the neighbours of 128 consecutive vertices lie in a WINDOW of a few hundred consecutive
+//     vertices (64 x 64 quad cylinder: 128 + 2 * 65).  The block finds the window from the CSR column indices of its rows and
+//     stages it in LDS, 32 channels at a time -- S_i is read ~2x instead of 7x.  A tile whose window exceeds kWin rows (an
+//     arbitrary numbering) gathers from global memory instead: same result, the speed of the old SpMM.
+//   * aggregation: thread = (row, 4 channels), fmaf over the row's CSR entries in CSR order, + bias, ReLU -- the exact
+//     arithmetic of spmm_rows_kernel, so h is bit-identical to the two-launch route; the 128 x 32 slice goes to LDS in fp32.
+//   * contraction: v_mfma_f32_16x16x4_f32, wave w owns output channels [32 w, 32 w + 32) x all 128 rows (16 accumulator
+//     tiles), A fragments from the LDS slice (ds_read_b128, 4 consecutive k per lane feeding 4 MFMAs), B fragments of the next
+//     weight pre-packed in fragment order (one 16-byte load per lane per 16 k) and read once per block.
+//     For a narrow next layer (Cout <= 16: the 128 -> 3 regressor) wave w owns rows [32 w, 32 w + 32) x one channel tile.
+// LDS: window slice 288 x 36 floats + A slice 128 x 36 floats + 2048 CSR entries = 76 KB -> two blocks per CU, one in its MFMA phase while the other
+// stages and aggregates.  Roofline: fp32 MFMA (2 * rows * 128 * Cout flop; 205 us at 983k rows, Cout = 128) over
+// HBM (rows * 128 * 4 B read + rows * Cout * 4 B written [+ the tap]).
+#include "g4d_common.h"
+
+namespace g4d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 128;   // rows (vertices) per block
+constexpr int kWin = 288;    // window rows staged in LDS
+constexpr int kLd = 36;      // LDS row stride in floats (32 channels + 4: b128 reads of 8 lanes x 8 rows spread over the banks)
+constexpr int kC = 128;      // support width (hidden_dim of the refinement GCNs)
+constexpr int kEnt = 2048;   // CSR entries of a tile kept in LDS (16 per row on average)
+
+struct GcnFusedArgs {
+    int vg, frames, tpf;     // tpf = tiles per frame
+    const float *S;          // (frames, vg, 128)
+    const int *rowptr, *colidx;
+    const float *vals, *bias;
+    int relu;
+    float *tap;              // (frames, vg, 128) or null: h itself
+    const float *Wp;         // next weight (Cout_pad x 128) in the fragment order of the LDS-resident MLP kernels: [16-channel tile][k-step of 16 (8)][lane = fq*16+fi][4 consecutive k]
+    int cout;                // real output channels (<= 16 * NT)
+    float *out;              // (frames, vg, cout)
+};
+
+// NT = channel tiles of the next layer: 8 (Cout = 128: wave owns 2 channel tiles x 8 row tiles) or 1 (Cout <= 16: wave owns
+// 2 row tiles x the one channel tile).
+// FAST: the tile's window fits kWin rows and its CSR entries fit kEnt -> window slices and the (column, value) pairs live in LDS, the
+// next slice's window rows are prefetched into registers while this slice is aggregated and contracted.  !FAST: any numbering, any
+// valence -- neighbour rows and CSR entries straight from global memory (the old SpMM's access pattern).
+template <int NT, bool FAST>
+__device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int r0, float *win, float *asl, int2 *ent, int lo, int wrows, int e0, int nent) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fi = lane & 15, fq = lane >> 4;
+    const int nrows = min(kTile, a.vg - r0);
+    const float *S = a.S + (size_t)f * a.vg * kC;
+    constexpr int NPRE = kWin / 32;   // window rows per thread and slice
+
+    // aggregation map: thread -> (row ar + 32 p, channels ac .. ac + 3 of the slice)
+    const int ar = t >> 3, ac = (t & 7) * 4;
+    int beg[4], len[4], maxlen = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = ar + 32 * p;
+        const bool ok = r < nrows;
+        const int b = ok ? a.rowptr[r0 + r] : 0, e = ok ? a.rowptr[r0 + r + 1] : 0;
+        beg[p] = b - (FAST ? e0 : 0);
+        len[p] = e - b;
+        maxlen = max(maxlen, len[p]);
+    }
+    if constexpr (FAST) {
+        for (int k = t; k < nent; k += 256) ent[k] = make_int2((a.colidx[e0 + k] - lo) * kLd, __float_as_int(a.vals[e0 + k]));
+    }
+    f32x4 pre[NPRE];
+    auto prefetch = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int r = ar + 32 * i;
+            pre[i] = r < wrows ? *reinterpret_cast<const f32x4 *>(S + (size_t)(lo + r) * kC + ks * 32 + ac) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if constexpr (FAST) prefetch(0);
+
+    constexpr int MT = NT == 8 ? 8 : 2;   // row tiles per wave
+    constexpr int NW = NT == 8 ? 2 : 1;   // channel tiles per wave
+    f32x4 acc[MT][NW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c0 = ks * 32;
+        // 1. the window slice (rows lo .. lo + wrows, channels c0 .. c0 + 31) goes from the prefetch registers to LDS
+        if constexpr (FAST) {
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int r = ar + 32 * i;
+                if (r < wrows) *reinterpret_cast<f32x4 *>(&win[r * kLd + ac]) = pre[i];
+            }
+        }
+        __syncthreads();   // window (and, first time, the CSR entries) visible; the previous slice's MFMAs are done with `asl`
+        if constexpr (FAST) {
+            if (ks < 3) prefetch(ks + 1);   // in flight during the aggregation and the MFMAs of this slice
+        }
+        // the slice's B fragments: in flight during the aggregation
+        f32x4 bf[2][NW];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const int nt = NT == 8 ? wave * 2 + n : 0;
+                bf[h2][n] = *reinterpret_cast<const f32x4 *>(a.Wp + ((size_t)(nt * 8 + ks * 2 + h2) * 64 + lane) * 4);
+            }
+        // 2. aggregate: h = act(sum_e vals[e] * S[col[e]] + bias), CSR order, fmaf -- spmm_rows_kernel's arithmetic.  The four rows
+        //    of a thread advance together: four independent chains of dependent LDS reads
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + c0 + ac) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 h[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) h[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < maxlen; ++j) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (j < len[p]) {
+                    float w;
+                    f32x4 x;
+                    if constexpr (FAST) {
+                        const int2 cv = ent[beg[p] + j];
+                        w = __int_as_float(cv.y);
+                        x = *reinterpret_cast<const f32x4 *>(&win[cv.x + ac]);
+                    } else {
+                        w = a.vals[beg[p] + j];
+                        x = *reinterpret_cast<const f32x4 *>(S + (size_t)a.colidx[beg[p] + j] * kC + c0 + ac);
+                    }
+                    h[p].x = __builtin_fmaf(w, x.x, h[p].x); h[p].y = __builtin_fmaf(w, x.y, h[p].y);
+                    h[p].z = __builtin_fmaf(w, x.z, h[p].z); h[p].w = __builtin_fmaf(w, x.w, h[p].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = ar + 32 * p;
+            f32x4 y = h[p] + bv;
+            if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+            if (r >= nrows) y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(&asl[r * kLd + ac]) = y;
+            if (a.tap && r < nrows) *reinterpret_cast<f32x4 *>(a.tap + ((size_t)f * a.vg + r0 + r) * kC + c0 + ac) = y;
+        }
+        __syncthreads();   // A slice visible; everybody is done reading `win`
+        // 3. contract the slice with the next weight
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int mt = NT == 8 ? m : wave * 2 + m;
+                const f32x4 af = *reinterpret_cast<const f32x4 *>(&asl[(mt * 16 + fi) * kLd + h2 * 16 + fq * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[h2][n][e], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    // store S_next: C/D layout of the 16x16 MFMA -- column = lane & 15, rows = (lane >> 4) * 4 + reg
+    float *out = a.out + ((size_t)f * a.vg + r0) * a.cout;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int mt = NT == 8 ? m : wave * 2 + m;
+            const int ch = (NT == 8 ? wave * 2 + n : 0) * 16 + fi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + fq * 4 + r;
+                if (row < nrows && ch < a.cout) out[(size_t)row * a.cout + ch] = acc[m][n][r];
+            }
+        }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) gcn_fused_kernel(const GcnFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float win[kWin * kLd];
+    __shared__ __attribute__((aligned(16))) float asl[kTile * kLd];
+    __shared__ int2 ent[kEnt];
+    __shared__ int s_lohi[2];
+    const int t = threadIdx.x, lane = t & 63;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD has its own L2, and the windows
+    // of neighbouring tiles overlap (the halo rows).  XCD x therefore walks a CONTIGUOUS range of the (frame, tile) list: the
+    // halo a tile shares with its predecessor is an L2 hit instead of a second HBM read.
+    const int total = a.tpf * a.frames;
+    const int per_xcd = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= total) return;   // block-uniform
+    const int f = logical / a.tpf;
+    const int r0 = (logical - f * a.tpf) * kTile;
+    const int nrows = min(kTile, a.vg - r0);
+    // window of the tile: [lo, hi) over the column indices of its rows (a contiguous CSR range)
+    if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; }
+    __syncthreads();
+    const int e0 = a.rowptr[r0], e1 = a.rowptr[r0 + nrows];
+    {
+        int lo = 0x7fffffff, hi = -1;
+        for (int e = e0 + t; e < e1; e += 256) {
+            const int c = a.colidx[e];
+            lo = min(lo, c);
+            hi = max(hi, c);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0 && hi >= 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
+    }
+    __syncthreads();
+    const int lo = s_lohi[0], hi = s_lohi[1] + 1;
+    if (e1 - e0 <= kEnt && hi - lo <= kWin && hi > lo)   // block-uniform
+        gcn_fused_tile<NT, true>(a, f, r0, win, asl, ent, lo, hi - lo, e0, e1 - e0);
+    else
+        gcn_fused_tile<NT, false>(a, f, r0, win, asl, ent, 0, 0, e0, e1 - e0);
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+
+extern "C" int g4d_gcn_agg_linear_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
+                                      const float *bias, int relu, float *tap, const float *Wp, int cout, float *out,
+                                      g4d_stream_t stream) {
+    G4D_REQUIRE(frames >= 0 && vg >= 0, "g4d_gcn_agg_linear_f32: bad sizes");
+    G4D_REQUIRE(c == kC, "g4d_gcn_agg_linear_f32: the support width must be %d (got %d)", kC, c);
+    G4D_REQUIRE(cout == 128 || (cout >= 1 && cout <= 16), "g4d_gcn_agg_linear_f32: Cout must be 128 or <= 16 (got %d)", cout);
+    if (frames == 0 || vg == 0) return G4D_OK;
+    G4D_REQUIRE(S && rowptr && colidx && vals && Wp && out, "g4d_gcn_agg_linear_f32: null pointer");
+    const int tpf = (vg + kTile - 1) / kTile;
+    G4D_REQUIRE((long long)tpf * frames < (1ll << 30), "g4d_gcn_agg_linear_f32: too many tiles");
+    GcnFusedArgs a = {vg, frames, tpf, S, rowptr, colidx, vals, bias, relu, tap, Wp, cout, out};
+    const int per_xcd = (tpf * frames + 7) / 8;
+    dim3 grid((unsigned)(per_xcd * 8));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (cout == 128) hipLaunchKernelGGL(gcn_fused_kernel<8>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gcn_fused_kernel<1>, grid, dim3(256), 0, st, a);
+    return check_launch("g4d_gcn_agg_linear_f32");
+}

@@ -6,12 +6,18 @@ construction as in modules/mesh_encoder.py:288-307).
 forward(input, adj):  out = adj @ (input @ W) + b  -- the reference's order, two HIP kernels per layer: the dense
 contraction on the matrix cores (g4d_linear_f32, point-major rows) and a batched CSR SpMM whose threads own 4
 channels of one (frame, vertex) row (g4d_spmm_rows_f32); the reference transposes X W to (N, B*F), runs torch.spmm
-and transposes back.  (A fused CSR-aggregate-then-contract kernel exists too, g4d_gcn_linear_f32; it redoes the
-aggregation per 64-channel tile and only pays for Fin <= 64; the stack kernel's CSR loader gathers each row tile once,
-but for the 128 -> 128 layers at 240 x 4096 rows it still measured 1.41 ms against 0.92 ms for linear + SpMM: the
-aggregation in the loader is a latency-bound gather in front of the MFMAs.)  Inference only: no autograd graph is built.
+and transposes back.
+
+gcn_stack_forward(layers, x, adj): the chained layers of the refinement regressors (mesh_encoder.py:477-481) in the same
+operation order, with the aggregation of layer i and the contraction of layer i+1 in ONE launch (g4d_gcn_agg_linear_f32,
+csrc/gcn_fused.hip): the activation between two layers stays in LDS (window of neighbouring vertex rows staged once per 128-row
+tile instead of one L2 read per neighbour).  240 x 4096 rows, 128 -> 128: 488 us against 344 (SpMM) + 404 (contraction); the
+323 -> 128 -> 128 -> 128 -> 3 stack 3.24 -> 2.20 ms (scripts/time_gcn_stack.py).  (An earlier fused kernel aggregating in the
+LOADER of the contraction, g4d_gcn_linear_f32, redoes the aggregation per 64-channel tile and was slower than two launches.)
+Inference only: no autograd graph is built.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -155,3 +161,64 @@ class GraphConvolution(torch.nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__} ({self.in_features} -> {self.out_features})"
+
+
+FUSE_STACK = os.environ.get("G4D_GCN_FUSED", "1") != "0"
+
+
+def gcn_stack_forward(layers, x, adj, relu_last=False, keep=()):
+    """h_0 = x;  h_{i+1} = layers[i](h_i, adj) with ReLU after every layer but the last (ReLU there iff relu_last) -- the regressor
+    loop of modules/mesh_encoder.py:477-481.  Returns [h_1, ..., h_n] with None for the intermediate activations nobody asked for
+    (`keep` = indices i whose output layers[i](...) must exist; the last always does).
+
+    Same operation order as chaining GraphConvolution.forward (contract, aggregate, bias, ReLU); what changes is where the
+    tensors live: the aggregation of layer i and the contraction of layer i+1 run in ONE launch (g4d_gcn_agg_linear_f32) whenever
+    layer i is 128 wide and layer i+1 is 128 or <= 16 wide, so h_i only reaches HBM when it is in `keep`."""
+    n = len(layers)
+    outs = [None] * n
+    if not (x.is_cuda and x.dtype == torch.float32):
+        raise RuntimeError("gcn_stack_forward: input must be a float32 HIP tensor")
+    if torch.is_grad_enabled() and (x.requires_grad or any(m.weight.requires_grad for m in layers)):
+        raise NotImplementedError("gcn_stack_forward is forward-only: call it under torch.no_grad()")
+
+    def fusable(i):   # aggregation of layer i + contraction of layer i + 1
+        return (FUSE_STACK and i + 1 < n and layers[i].out_features == 128
+                and (layers[i + 1].out_features == 128 or layers[i + 1].out_features <= 16))
+
+    if not any(fusable(i) for i in range(n)):
+        h = x
+        for i, m in enumerate(layers):
+            h = m(h, adj, False, relu=(i + 1 < n or relu_last))
+            outs[i] = h
+        return outs
+    xb = x.contiguous()
+    squeeze = xb.dim() == 2
+    if squeeze:
+        xb = xb.unsqueeze(0)
+    B, N, _ = xb.shape
+    rowptr, colidx, vals, nv = _to_csr(adj, xb.device)
+    assert nv == N, "adjacency size does not match the number of vertices"
+    stream = _lib.stream_ptr()
+    h, S = xb, None    # S = support of the CURRENT layer (h W_i), when the previous launch already contracted it
+    for i, m in enumerate(layers):
+        L_support, _, bias = m._packed()
+        relu = i + 1 < n or relu_last
+        if S is None:
+            S = linear(h.reshape(B * N, -1), L_support).view(B, N, -1)                 # layers.py:42
+        if fusable(i):
+            nxt = layers[i + 1]
+            Ln = nxt._packed()[0]
+            tap = torch.empty((B, N, 128), dtype=torch.float32, device=xb.device) if i in keep else None
+            S_next = torch.empty((B, N, nxt.out_features), dtype=torch.float32, device=xb.device)
+            _lib.call("g4d_gcn_agg_linear_f32", B, N, 128, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(),
+                      0 if bias is None else bias.data_ptr(), int(relu), 0 if tap is None else tap.data_ptr(), Ln.Wf.data_ptr(),
+                      nxt.out_features, S_next.data_ptr(), stream)                      # layers.py:46-55 of layer i, :42 of layer i+1
+            outs[i] = tap if tap is None or not squeeze else tap[0]
+            h, S = None, S_next
+        else:
+            out = torch.empty((B, N, m.out_features), dtype=torch.float32, device=xb.device)
+            _lib.call("g4d_spmm_rows_f32", B, N, m.out_features, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(),
+                      0 if bias is None else bias.data_ptr(), int(relu), out.data_ptr(), stream)
+            outs[i] = out[0] if squeeze else out
+            h, S = out, None
+    return outs

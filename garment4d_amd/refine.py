@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import _lib
 from . import dist as gdist
 from . import fused
-from .gcn import GraphConvolution
+from .gcn import GraphConvolution, gcn_stack_forward
 
 
 USE_PE_KERNEL = True   # tests flip this to cover the generic fused-stack route
@@ -211,14 +211,15 @@ class GarmentRefinementHead(nn.Module):
                 gdist.temporal_attention(lbs_iter_feat[-2], frame_ids, n_frames, T, self._qkv(qkvs[it - 1]), group, out=feat, col0=col,
                                          clip_range=clip_range, gathered=pending)
                 pending = None
-            h = feat
-            for i, m in enumerate(regress[it]):                                      # :477-481
-                h = m(h, adj, False, relu=(i != 3))
-                lbs_iter_feat.append(h)
-                if i == 2 and it + 1 < self.iteration and gdist.resolve_group(group) is not None:
-                    # the next round's attention needs this tensor from every rank: start the all-gather now, it overlaps the last
-                    # GCN layer and the next round's six ball queries + positional encoders, which do not depend on it
-                    pending = gdist.allgather_frames_async(h, n_frames, group)
+            # :477-481 -- four chained GraphConvolutions; only the third one's output (the next round's attention input) and the
+            # last one's are kept, the rest never leaves the fused aggregate + contract launches (gcn.gcn_stack_forward)
+            hs = gcn_stack_forward(regress[it], feat, adj, relu_last=False, keep=(2,))
+            lbs_iter_feat += hs
+            h = hs[-1]
+            if it + 1 < self.iteration and gdist.resolve_group(group) is not None:
+                # the next round's attention needs this tensor from every rank: start the all-gather now, it overlaps the next
+                # round's six ball queries + positional encoders, which do not depend on it
+                pending = gdist.allgather_frames_async(hs[2], n_frames, group)
             cur = (cur + h).contiguous()                                             # :482-483
             outs.append(cur)
         return outs

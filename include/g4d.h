@@ -242,6 +242,16 @@ int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float *X, int ldx
 int g4d_spmm_rows_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
                       const float *bias, int relu, float *out, g4d_stream_t stream);
 
+/* Aggregation of GCN layer i fused with the contraction of layer i+1 (modules/mesh_encoder.py:477-481: four chained
+ * GraphConvolutions per refinement round), in the reference's operation order:
+ *   h = act(Ahat . S + bias)   (S = X W_i already contracted, (frames,Vg,128) point-major; CSR Ahat; act = ReLU if relu)
+ *   out = h . W_next           ((frames,Vg,cout) point-major, cout == 128 or cout <= 16)
+ * h is written to `tap` ((frames,Vg,128)) when tap != NULL and never touches HBM otherwise.  h is bit-identical to
+ * g4d_spmm_rows_f32.  Wp = W_next^T padded to (ceil(cout/16)*16, 128), fragment order [16-channel tile][8 k-steps of 16][lane =
+ * 16*(k/4 mod 4) + channel mod 16][4 consecutive k].  c must be 128. */
+int g4d_gcn_agg_linear_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
+                           const float *bias, int relu, float *tap, const float *Wp, int cout, float *out, g4d_stream_t stream);
+
 /* max (is_max=1) / mean over S consecutive rows, any S: in (groups*S, ldi) -> out (groups, ldo) at col0. */
 int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0, int is_max,
                       g4d_stream_t stream);

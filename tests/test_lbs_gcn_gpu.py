@@ -137,6 +137,72 @@ def test_gcn_fused_csr_linear_entry_point():
     np.testing.assert_allclose(host(out), want, **TOL)
 
 
+def _regressor(first, seed):
+    torch.manual_seed(seed)
+    layers = [G.GraphConvolution(first, 128), G.GraphConvolution(128, 128), G.GraphConvolution(128, 128), G.GraphConvolution(128, 3)]
+    return [m.cuda() for m in layers]
+
+
+@pytest.mark.parametrize("rc,frames,numbering", [((64, 64), 3, "mesh"), ((20, 23), 2, "mesh"), ((20, 23), 2, "shuffled"), ((9, 7), 1, "mesh")])
+def test_gcn_stack_fused_vs_layer_by_layer_and_oracle(rc, frames, numbering, monkeypatch):
+    """gcn_stack_forward (aggregation of layer i + contraction of layer i+1 in one launch, csrc/gcn_fused.hip) against the chained
+    GraphConvolution.forward and the numpy restatement: mesh numbering (LDS window), a shuffled numbering (window too wide: global
+    gather), vertex counts that are not a multiple of the 128-row tile.  The kept activation (`keep`) is the SpMM's output bit for bit."""
+    verts, faces = syn.quad_cylinder(*rc)
+    Vg = verts.shape[0]
+    if numbering == "shuffled":
+        perm = np.random.default_rng(5).permutation(Vg)
+        faces = perm[faces]
+    adj = gcn_oracle.adjacency_from_faces(faces, Vg)
+    rng = np.random.default_rng(Vg)
+    x = rng.standard_normal((frames, Vg, 195)).astype(np.float32)
+    layers = _regressor(195, Vg)
+    with torch.no_grad():
+        got = G.gcn_stack_forward(layers, dev(x), adj, keep=(2,))
+        monkeypatch.setattr(G, "FUSE_STACK", False)
+        ref = G.gcn_stack_forward(layers, dev(x), adj, keep=(2,))
+    assert got[0] is None and got[1] is None and all(r is not None for r in ref)
+    assert torch.equal(got[2], ref[2]) or float((got[2] - ref[2]).abs().max()) <= 1e-5 * max(1.0, float(ref[2].abs().max()))
+    h = x
+    for i, m in enumerate(layers):
+        h = gcn_oracle.graph_convolution(h, host(m.weight), host(m.bias), adj)
+        if i < 3:
+            h = np.maximum(h, 0)
+        if i >= 2:
+            scale = max(1.0, float(np.abs(h).max()))
+            err = float(np.abs(host(got[i]) - h).max())
+            print(f"[parity] gcn stack {rc} {numbering}: layer {i} max_abs {err:.3g} (scale {scale:.3g}); fused vs layer-by-layer "
+                  f"{float((got[i] - ref[i]).abs().max()):.3g}")
+            assert err <= 1e-5 * scale
+
+
+def test_gcn_agg_linear_tap_is_bit_identical_to_spmm():
+    """The aggregation inside g4d_gcn_agg_linear_f32 uses spmm_rows_kernel's arithmetic: the tapped activation must EQUAL it."""
+    from garment4d_amd import _lib, fused
+    verts, faces = syn.quad_cylinder(31, 17)
+    Vg = verts.shape[0]
+    adj = gcn_oracle.adjacency_from_faces(faces, Vg)
+    rowptr, colidx, vals, _ = G._to_csr(adj, torch.device("cuda"))
+    g = torch.Generator().manual_seed(2)
+    S = torch.randn(2, Vg, 128, generator=g).cuda()
+    bias = torch.randn(128, generator=g).cuda()
+    Wn = (torch.randn(128, 128, generator=g) * 0.1).cuda()       # (in, out)
+    L = fused.PackedLayer(Wn.t().contiguous(), torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"), relu=False)
+    want_h = torch.empty_like(S)
+    _lib.call("g4d_spmm_rows_f32", 2, Vg, 128, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), bias.data_ptr(), 1,
+              want_h.data_ptr(), _lib.stream_ptr())
+    tap = torch.full_like(S, float("nan"))
+    out = torch.full((2, Vg, 128), float("nan"), device="cuda")
+    _lib.call("g4d_gcn_agg_linear_f32", 2, Vg, 128, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), bias.data_ptr(), 1,
+              tap.data_ptr(), L.Wf.data_ptr(), 128, out.data_ptr(), _lib.stream_ptr())
+    assert torch.equal(tap, want_h)
+    want = (want_h.double() @ Wn.double()).float()
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError, match="support width"):
+        _lib.call("g4d_gcn_agg_linear_f32", 2, Vg, 64, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), bias.data_ptr(), 1,
+                  0, L.Wf.data_ptr(), 128, out.data_ptr(), _lib.stream_ptr())
+
+
 @pytest.mark.parametrize("fused_path", [True, False])
 def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, monkeypatch):
     """Both lbs() routes -- the three-launch one (joints from betas via J_regressor's linearity, shape blend folded into the pose
