@@ -32,6 +32,7 @@ SIGNATURES = {
     "g4d_group_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_group_grad_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_three_nn_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],
+    "g4d_three_nn_grid_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_three_interp_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_three_interp_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_linear_f32": [_LL, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _I, _vp],

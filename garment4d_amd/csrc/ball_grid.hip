@@ -68,7 +68,7 @@ __device__ __forceinline__ float wave_max_all(float v) {
     return v;
 }
 
-__global__ void __launch_bounds__(kBuildThreads) ball_grid_build_kernel(int n, int cmax, float cell_req, const float *__restrict__ xyz_all,
+__global__ void __launch_bounds__(kBuildThreads) ball_grid_build_kernel(int n, int cmax, int budget, float cell_req, const float *__restrict__ xyz_all,
                                                                        unsigned char *__restrict__ ws_all, size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) int hist[];  // [cmax + 1], then 16 x 8 floats of reduction scratch
     float *red = reinterpret_cast<float *>(hist + cmax + 1);
@@ -102,7 +102,17 @@ __global__ void __launch_bounds__(kBuildThreads) ball_grid_build_kernel(int n, i
     if (!(ly <= hy)) { ly = 0.f; hy = 0.f; }
     if (!(lz <= hz)) { lz = 0.f; hz = 0.f; }
     // 2. grid: cell edge c >= kCellSlack * r_max, grown by 2^(1/3) until <= 1024 cells per axis and <= cmax cells in all
+    // cell_req <= 0: the finest grid that fits `budget` (<= cmax) cells (three_nn: no radius is given) -- start just below the edge that gives
+    // cmax cells over the box volume and let the loop grow it
     float c = fmaxf(cell_req, 1e-30f);
+    if (!(cell_req > 0.f)) {
+        const float ex = fmaxf(hx - lx, 0.f), ey = fmaxf(hy - ly, 0.f), ez = fmaxf(hz - lz, 0.f);
+        const float big = fmaxf(ex, fmaxf(ey, ez));
+        const float vol = fmaxf(ex, big * 1e-3f) * fmaxf(ey, big * 1e-3f) * fmaxf(ez, big * 1e-3f);
+        c = vol > 0.f && vol < INF ? 0.5f * cbrtf(vol / (float)budget) : 1e-30f;
+        c = fmaxf(c, big * (1.0f / 1023.0f));
+        if (!(c > 0.f && c < INF)) c = 1e-30f;
+    }
     int gx, gy, gz;
     float inv_c;
     for (int it = 0; it < 400; ++it) {
@@ -110,7 +120,7 @@ __global__ void __launch_bounds__(kBuildThreads) ball_grid_build_kernel(int n, i
         const float fx = floorf((hx - lx) * inv_c), fy = floorf((hy - ly) * inv_c), fz = floorf((hz - lz) * inv_c);
         if (fx < 1024.f && fy < 1024.f && fz < 1024.f) {  // also false for inf / NaN quotients
             gx = (int)fx + 1; gy = (int)fy + 1; gz = (int)fz + 1;
-            if ((long long)gx * gy * gz <= (long long)cmax) break;
+            if ((long long)gx * gy * gz <= (long long)budget) break;
         }
         c *= 1.2599211f;
         gx = gy = gz = 1;
@@ -339,13 +349,130 @@ __global__ void __launch_bounds__(256) ball_grid_query_kernel(int n, int m, int 
     }
 }
 
-int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st) {  // also used by ball_query.hip (query sorting)
+// ---- three nearest neighbours over the cell grid ------------------------------------------------------------------------------
+// three_nn_kernel_fast (/root/reference/modules/pointnet2/pointnet2/src/interpolate_gpu.cu:9-52) scans all m known points per
+// unknown point; the 3 nearest of a point on a surface sampled by m points sit within a few sample spacings.  The known points
+// are counting-sorted into the finest grid that fits the cell budget (ball_grid_build_kernel, cell_req <= 0); a lane owns one
+// unknown point and walks the 3 x 3 x 3 cells around its own cell (9 contiguous record ranges), keeping the 3 smallest
+// (d2, ORIGINAL index) pairs in lexicographic order -- the visiting order is not the index order, and the lexicographic top-3 is
+// exactly what the reference's ascending scan with strict `<` produces.  Every point outside the cube of radius R cells is
+// farther than R cell edges along some axis, so the result is final once the third distance is below (0.99 R edge)^2 (1 % covers
+// the rounding of the cell coordinates, 2.4e-4 cells, and of d2); otherwise the lane restarts on the 5 x 5 x 5 cube, then on the
+// whole record list -- also the route for a query that is not finite or lies more than a cell outside the box.  Same distance
+// expression as the scan (dist2<FM>): bit-identical output for any input.
+__device__ __forceinline__ void nn3_insert_lex(float d, int k, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3) {
+    const bool lt1 = d < b1 || (d == b1 && k < i1), lt2 = d < b2 || (d == b2 && k < i2), lt3 = d < b3 || (d == b3 && k < i3);
+    const float nb3 = lt2 ? b2 : (lt3 ? d : b3);
+    const int ni3 = lt2 ? i2 : (lt3 ? k : i3);
+    const float nb2 = lt1 ? b1 : (lt2 ? d : b2);
+    const int ni2 = lt1 ? i1 : (lt2 ? k : i2);
+    b1 = lt1 ? d : b1; i1 = lt1 ? k : i1;
+    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+}
+
+// STAGE: the cloud's records and cell table are copied into LDS first (known sets up to 2048 points: 40 KB) -- the walk is a chain
+// of dependent reads (cell bounds -> records), ~100 cycles each from LDS against ~1 us from L2.
+template <int FM, bool STAGE>
+__global__ void __launch_bounds__(256) three_nn_grid_kernel(int n, int m, const float *__restrict__ unknown_all,
+                                                           const unsigned char *__restrict__ ws_all, size_t ws_stride, int cmax,
+                                                           float *__restrict__ dist2_all, int *__restrict__ idx_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nn_smem[];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const unsigned char *ws = ws_all + (size_t)b * ws_stride;
+    const GridHdr h = *reinterpret_cast<const GridHdr *>(ws);
+    const int *cellstart = reinterpret_cast<const int *>(ws + kGridHdrBytes);
+    const float4 *rec = reinterpret_cast<const float4 *>(ws + kGridHdrBytes + ((((size_t)cmax + 1) * 4 + 63) & ~(size_t)63));
+    if constexpr (STAGE) {
+        float4 *srec = reinterpret_cast<float4 *>(nn_smem);
+        int *scell = reinterpret_cast<int *>(nn_smem + (size_t)m * 16);
+        for (int k = threadIdx.x; k < m; k += 256) srec[k] = rec[k];
+        for (int k = threadIdx.x; k <= h.ncells; k += 256) scell[k] = cellstart[k];
+        __syncthreads();
+        rec = srec;
+        cellstart = scell;
+    }
+    const float *u = unknown_all + ((size_t)b * n + min(p, n - 1)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float INF = __builtin_inff();
+    float b1 = INF, b2 = INF, b3 = INF;   // interpolate_gpu.cu:24-25: double 1e40 against a float d == a float compare against +inf
+    int i1 = 0, i2 = 0, i3 = 0;
+    auto visit = [&](int k0, int k1) {  // two records in flight per step
+        int k = k0;
+        for (; k + 1 < k1; k += 2) {
+            const float4 r0 = rec[k], r1 = rec[k + 1];
+            const float d0 = dist2<FM>(ux - r0.x, uy - r0.y, uz - r0.z);   // interpolate_gpu.cu:33 under the contraction contract
+            const float d1 = dist2<FM>(ux - r1.x, uy - r1.y, uz - r1.z);
+            nn3_insert_lex(d0, __float_as_int(r0.w), b1, b2, b3, i1, i2, i3);
+            nn3_insert_lex(d1, __float_as_int(r1.w), b1, b2, b3, i1, i2, i3);
+        }
+        if (k < k1) {
+            const float4 r0 = rec[k];
+            nn3_insert_lex(dist2<FM>(ux - r0.x, uy - r0.y, uz - r0.z), __float_as_int(r0.w), b1, b2, b3, i1, i2, i3);
+        }
+    };
+    const float fx = (ux - h.lox) * h.inv_c, fy = (uy - h.loy) * h.inv_c, fz = (uz - h.loz) * h.inv_c;
+    // the ring argument needs the query's real cell: finite and at most one cell outside the box (NaN fails every compare)
+    bool pending = true;
+    const bool local = fx > -1.f && fx < (float)h.gx + 1.f && fy > -1.f && fy < (float)h.gy + 1.f && fz > -1.f && fz < (float)h.gz + 1.f;
+    if (local) {
+        const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+        const float edge = h.inv_c > 0.f ? 1.0f / h.inv_c : INF;   // inv_c == 0: one cell holds everything
+        {   // R = 1: the bounds of the 9 rows first (independent reads), then the records
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.gx - 1);
+            int rs[9], re[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int y = cy + (q % 3) - 1, z = cz + (q / 3) - 1;
+                const bool ok = x0 <= x1 && y >= 0 && y < h.gy && z >= 0 && z < h.gz;
+                const int row = ok ? (z * h.gy + y) * h.gx : 0;
+                rs[q] = ok ? cellstart[row + x0] : 0;
+                re[q] = ok ? cellstart[row + x1 + 1] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) visit(rs[q], re[q]);
+            const float reach = edge * 0.99f;
+            pending = !(b3 < reach * reach);
+        }
+        if (pending) {  // R = 2 (rare: sparse neighbourhood): the whole 5 x 5 x 5 cube from scratch
+            b1 = b2 = b3 = INF; i1 = i2 = i3 = 0;
+            const int x0 = max(cx - 2, 0), x1 = min(cx + 2, h.gx - 1);
+            if (x0 <= x1) {
+                for (int dz = -2; dz <= 2; ++dz) {
+                    const int z = cz + dz;
+                    if (z < 0 || z >= h.gz) continue;
+                    for (int dy = -2; dy <= 2; ++dy) {
+                        const int y = cy + dy;
+                        if (y < 0 || y >= h.gy) continue;
+                        const int row = (z * h.gy + y) * h.gx;
+                        visit(cellstart[row + x0], cellstart[row + x1 + 1]);
+                    }
+                }
+            }
+            const float reach = 2.f * edge * 0.99f;
+            pending = !(b3 < reach * reach);
+        }
+    }
+    if (pending) {  // exact for anything: every record, lexicographic inserts
+        b1 = b2 = b3 = INF; i1 = i2 = i3 = 0;
+        visit(0, m);
+    }
+    if (p < n) {
+        float *d2 = dist2_all + ((size_t)b * n + p) * 3;
+        int *ix = idx_all + ((size_t)b * n + p) * 3;
+        d2[0] = b1; d2[1] = b2; d2[2] = b3;
+        ix[0] = i1; ix[1] = i2; ix[2] = i3;
+    }
+}
+
+int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st, int budget) {  // also used by ball_query.hip (query sorting)
     const int cmax = grid_cmax(n);
+    if (budget <= 0 || budget > cmax) budget = cmax;
     const size_t lds = ((size_t)cmax + 1) * 4 + 16 * 8 * 4;
     static unsigned long long attr = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(ball_grid_build_kernel), 160 * 1024 - 1024, attr, "g4d_ball_grid_build_f32"))
         return rc;
-    hipLaunchKernelGGL(ball_grid_build_kernel, dim3(b), dim3(kBuildThreads), lds, st, n, cmax, rmax * kCellSlack, xyz,
+    hipLaunchKernelGGL(ball_grid_build_kernel, dim3(b), dim3(kBuildThreads), lds, st, n, cmax, budget, rmax > 0.f ? rmax * kCellSlack : 0.f, xyz,
                        reinterpret_cast<unsigned char *>(ws), grid_cloud_bytes(n));
     return check_launch("g4d_ball_grid_build_f32");
 }
@@ -428,4 +555,33 @@ extern "C" int g4d_ball_query_grid_f32(int b, int n, int m, int nscales, const f
         if (rc != G4D_OK) return rc;
     }
     return g4d_ball_grid_query_f32(b, n, m, nscales, radii, nsamples, new_xyz, xyz, idx, grid, rmax, stream);
+}
+
+extern "C" int g4d_three_nn_grid_f32(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, void *grid,
+                                     g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0 && b <= 65535, "g4d_three_nn_grid_f32: bad sizes (b=%d n=%d m=%d)", b, n, m);
+    if ((long long)b * n == 0) return G4D_OK;
+    G4D_REQUIRE(unknown && dist2 && idx, "g4d_three_nn_grid_f32: null pointer");
+    if (m == 0) return g4d_three_nn_f32(b, n, m, unknown, known, dist2, idx, stream);
+    G4D_REQUIRE(known && grid, "g4d_three_nn_grid_f32: null pointer (grid scratch = g4d_ball_grid_bytes(b, m))");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // Cell budget = one cell per known point of the box volume (the finest grid the workspace holds).  Measured (MI355X, device time,
+    // build + search, scripts/time_three_nn.py): coarser cells only lose -- a lane's walk costs ~10x the scan's per candidate (its
+    // LDS reads are scattered, the scan's are wave broadcasts with a wave-uniform skip of the inserts), so the win has to come from
+    // visiting few candidates: 30 x 4096 <- 6890 (config 4's interpenetration search) 334 -> 205 us, 8 x 8192 <- 1024 43 -> 40-79 us
+    // (surface / volume cloud), 8 x 1024 <- 256 8 -> 55 us.  Callers therefore take this route from m = 4096 on.
+    static const int per_cell = [] { const char *e = getenv("G4D_NN_PER_CELL"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    if (const int rc = grid_build(b, m, 0.f, known, grid, st, m / per_cell > 8 ? m / per_cell : 8)) return rc;
+    dim3 g((unsigned)((n + 255) / 256), (unsigned)b);
+    const unsigned char *wsb = reinterpret_cast<const unsigned char *>(grid);
+    if (m <= 2048) {
+        const size_t lds = (size_t)m * 16 + ((size_t)grid_cmax(m) + 1) * 4;   // <= 40 KB
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((three_nn_grid_kernel<FM, true>), g, dim3(256), lds, st, n, m, unknown, wsb,
+                                                              grid_cloud_bytes(m), grid_cmax(m), dist2, idx))
+    } else {
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((three_nn_grid_kernel<FM, false>), g, dim3(256), 0, st, n, m, unknown, wsb,
+                                                              grid_cloud_bytes(m), grid_cmax(m), dist2, idx))
+    }
+    return check_launch("g4d_three_nn_grid_f32");
 }

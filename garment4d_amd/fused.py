@@ -509,6 +509,30 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
     return None, out
 
 
+THREE_NN_GRID_MIN_M = int(os.environ.get("G4D_NN_GRID_MIN_M", "4096"))  # known sets at least this large search the cell grid (csrc/ball_grid.hip); below, the scan wins
+
+
+def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None):
+    """Three nearest `known` (B,m,3) points of every `unknown` (B,n,3) point: (dist2 (B,n,3) squared, idx (B,n,3) int32).
+    grid=None: the cell-grid search from m = THREE_NN_GRID_MIN_M on, the scan below; True / False force a route (identical output)."""
+    B, n, _ = _chk(unknown).shape
+    m = _chk(known).shape[1]
+    dev = unknown.device
+    if dist2 is None:
+        dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
+    if nn_idx is None:
+        nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=dev)
+    if grid is None:
+        grid = m >= THREE_NN_GRID_MIN_M
+    if grid and m > 0 and B * n > 0:
+        ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B, m), 16), dtype=torch.uint8, device=dev)
+        _lib.call("g4d_three_nn_grid_f32", B, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), ws.data_ptr(),
+                  _lib.stream_ptr())
+    else:
+        _lib.call("g4d_three_nn_f32", B, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), _lib.stream_ptr())
+    return dist2, nn_idx
+
+
 def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
     """Fused PointnetFPModule.forward (pointnet2_modules.py:127-156), eval mode; all features point-major:
     unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout).
@@ -532,9 +556,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
         return out if head is None else (out, conv_stack_forward(head, out))
     m = known.shape[1]
     C2 = known_feats_pm.shape[2]
-    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
-    nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
-    _lib.call("g4d_three_nn_f32", B, n, m, unknown.data_ptr(), _chk(known).data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), stream)
+    dist2, nn_idx = three_nn(unknown, known)
 
     def first(L, pl, o, c0):
         _lib.call("g4d_interp_linear_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm),

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import fused
 from . import mesh_utils
 
 _vf = {}
@@ -18,9 +19,7 @@ def interpenetration_per_vertex(body_v, body_vn, garment_v):
     dev = body_v.device
     st = _lib.stream_ptr()
     g, b, n = garment_v.contiguous(), body_v.contiguous(), body_vn.contiguous()
-    dist = torch.empty((F_, Vg, 3), dtype=torch.float32, device=dev)
-    idx = torch.empty((F_, Vg, 3), dtype=torch.int32, device=dev)
-    _lib.call("g4d_three_nn_f32", F_, Vg, V, g.data_ptr(), b.data_ptr(), dist.data_ptr(), idx.data_ptr(), st)
+    _, idx = fused.three_nn(g, b)
     pen = torch.empty((F_, Vg), dtype=torch.float32, device=dev)
     _lib.call("g4d_interpenetration_f32", F_, Vg, V, g.data_ptr(), b.data_ptr(), n.data_ptr(), idx.data_ptr(), 3, pen.data_ptr(), st)
     return pen, idx[..., 0].long()

@@ -38,6 +38,7 @@ def _i(t, name):
 
 
 _GRID_MIN_N = 4096  # same threshold as fused.GRID_MIN_N
+_NN_GRID_MIN_M = 4096  # same threshold as fused.THREE_NN_GRID_MIN_M
 
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
@@ -84,8 +85,13 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
 
 
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
-    _lib.call("g4d_three_nn_f32", b, n, m, _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"),
-              _i(idx, "idx"), _lib.stream_ptr())
+    pu, pk, pd, pi = _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"), _i(idx, "idx")
+    if m >= _NN_GRID_MIN_M and b > 0 and n > 0:
+        # large known set: search the cell grid (csrc/ball_grid.hip), bit-identical output; scratch from torch's allocator
+        ws = torch.empty(_lib.lib().g4d_ball_grid_bytes(b, m), dtype=torch.uint8, device=known.device)
+        _lib.call("g4d_three_nn_grid_f32", b, n, m, pu, pk, pd, pi, ws.data_ptr(), _lib.stream_ptr())
+        return
+    _lib.call("g4d_three_nn_f32", b, n, m, pu, pk, pd, pi, _lib.stream_ptr())
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

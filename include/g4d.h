@@ -135,6 +135,11 @@ int g4d_group_grad_f32(int b, int c, int n, int npoints, int nsample, const floa
 int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                      g4d_stream_t stream);
 
+/* The same search over a cell grid of the known points (csrc/ball_grid.hip): bit-identical output, work per unknown point ~ the
+ * points of the 27 cells around it instead of m.  `grid`: g4d_ball_grid_bytes(b, m) bytes of device scratch (overwritten). */
+int g4d_three_nn_grid_f32(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, void *grid,
+                          g4d_stream_t stream);
+
 /* three_interpolate_kernel_launcher_fast (interpolate_gpu.h:18-21):
  * out[b,c,p] = sum_i weight[b,p,i] * points[b,c,idx[b,p,i]];  points (B,C,m) -> out (B,C,n). */
 int g4d_three_interp_f32(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,

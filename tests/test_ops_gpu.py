@@ -140,6 +140,43 @@ def test_three_nn_vs_oracle(B, n, m):
     np.testing.assert_allclose(host(d), wd, rtol=1e-6, atol=0)
 
 
+def _nn_cases():
+    rng = np.random.default_rng(17)
+    un = syn.unit_cloud(2, 700, seed=3)
+    cases = {
+        "volume": (syn.unit_cloud(2, 3000, seed=1), syn.unit_cloud(2, 1500, seed=2)),
+        "surface_with_duplicates_and_zero_padding": (syn.body_like_cloud(2, 2048, seed=4, dup_frac=0.0, zero_frac=0.0), syn.body_like_cloud(2, 900, seed=5)),
+        "large_known_set": (syn.unit_cloud(1, 1000, seed=6), syn.body_like_cloud(1, 5000, seed=7, dup_frac=0.1, zero_frac=0.0)),   # m > 2048: records stay in global memory
+        "queries_outside_the_box": ((un * 3.0 - 1.0).astype(np.float32), syn.unit_cloud(2, 600, seed=8)),
+        "fewer_than_three_known": (un, un[:, :2].copy()),
+        "one_known": (un, un[:, :1].copy()),
+        "all_known_identical": (un, np.repeat(un[:, :1], 40, 1)),
+        "known_on_a_line": (un, np.stack([np.linspace(0, 1, 300, dtype=np.float32)] * 3, -1)[None].repeat(2, 0)),
+    }
+    bad = syn.unit_cloud(2, 500, seed=9)
+    bad[0, 3] = np.nan; bad[0, 7, 1] = np.inf; bad[1, 11] = -np.inf
+    qbad = un.copy()
+    qbad[0, 5, 0] = np.nan; qbad[1, 6, 2] = np.inf
+    cases["non_finite_known_and_queries"] = (qbad, bad)
+    return cases
+
+
+@pytest.mark.parametrize("case", list(_nn_cases().keys()))
+def test_three_nn_cell_grid_route_is_bit_identical(case, contraction_mode):
+    """g4d_three_nn_grid_f32 (lane-per-query walk over the cell grid of the known points, csrc/ball_grid.hip) against the oracle and
+    the scan kernel: same indices, same squared distances, in every distance-contraction mode -- ties, sparse neighbourhoods (5^3
+    restart), queries outside the box and non-finite coordinates (full-scan route) included."""
+    from garment4d_amd import fused
+    un, kn = _nn_cases()[case]
+    wd, wi = K.three_nn(un, kn)
+    d0, i0 = fused.three_nn(dev(un), dev(kn), grid=False)
+    d1, i1 = fused.three_nn(dev(un), dev(kn), grid=True)
+    assert torch.equal(i0, i1), case
+    assert torch.equal(d0.view(torch.int32), d1.view(torch.int32)), case      # bit pattern: NaN-free by construction, inf == inf
+    assert np.array_equal(host(i1), wi), case
+    assert np.array_equal(np.sqrt(host(d1)), wd), case                        # the oracle returns distances, the C ABI their squares
+
+
 @pytest.mark.parametrize("B,C,N,P,S", [(2, 3, 1024, 256, 32), (2, 99, 1024, 256, 16), (1, 195, 256, 64, 64), (2, 7, 100, 13, 5)])
 def test_group_gather_interp_vs_oracle(B, C, N, P, S):
     rng = np.random.default_rng(C + N)
