@@ -60,6 +60,26 @@ def smoothing_operator(adj_old, coeff, iters, device):
 _SMOOTH_OPERATOR_MAX_VG = 8192   # dense operator up to 256 MB; larger meshes run the sparse steps
 
 
+_smooth_csr_cache = {}
+
+
+def _smoothing_csr(adj_old, device):
+    """(rowptr, colidx, vals, n, longest row) of D^-1 A - I on `device`, built once per adjacency object (scipy work + three H2D
+    copies: neither belongs in a forward that may be running under hipGraph capture)."""
+    key = (id(adj_old), str(device))
+    hit = _smooth_csr_cache.get(key)
+    if hit is not None and hit[0] is adj_old:
+        return hit[1]
+    import scipy.sparse as sp
+    adj = sp.csr_matrix(normalize(adj_old) - sp.eye(adj_old.shape[0]))
+    max_row = int(np.diff(adj.indptr).max()) if adj.shape[0] else 0
+    val = _to_csr(adj, device) + (max_row,)
+    if len(_smooth_csr_cache) > 8:
+        _smooth_csr_cache.clear()
+    _smooth_csr_cache[key] = (adj_old, val, adj)   # `adj` pinned: _to_csr caches by object identity
+    return val
+
+
 def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100, method=None):
     """100 Jacobi steps  W <- W + coeff * ((D^-1 A - I) . W)  over the garment mesh (:385-390).
     method "jacobi": the steps as written, one SpMM-axpy kernel each (ping-pong buffers).
@@ -72,11 +92,9 @@ def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100, method=None):
     import scipy.sparse as sp
     method = method or os.environ.get("G4D_SMOOTH") or "fused"
     if method == "fused":
-        adj = sp.csr_matrix(normalize(adj_old) - sp.eye(adj_old.shape[0]))
-        max_row = int(np.diff(adj.indptr).max()) if adj.shape[0] else 0
+        rowptr, colidx, vals, n, max_row = _smoothing_csr(adj_old, nn_W.device)
+        assert n == Vg
         if Vg <= 5104 and max_row <= 8:
-            rowptr, colidx, vals, n = _to_csr(adj, nn_W.device)
-            assert n == Vg
             x = nn_W.contiguous()
             out = torch.empty_like(x)
             _lib.call("g4d_jacobi_smooth_f32", F_, Vg, J, int(iters), float(coeff), max_row, x.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(),
@@ -88,9 +106,7 @@ def smooth_weights(nn_W, adj_old, coeff=0.1, iters=100, method=None):
         x = nn_W.permute(1, 0, 2).reshape(Vg, F_ * J)                      # vertex-major view of all frames / joints
         return torch.mm(M, x).view(Vg, F_, J).permute(1, 0, 2).contiguous()   # plain library GEMM
     assert method == "jacobi", method
-    import scipy.sparse as sp
-    adj = normalize(adj_old) - sp.eye(adj_old.shape[0])
-    rowptr, colidx, vals, n = _to_csr(sp.csr_matrix(adj), nn_W.device)
+    rowptr, colidx, vals, n, _ = _smoothing_csr(adj_old, nn_W.device)
     assert n == Vg
     a, b, spare = nn_W.contiguous(), torch.empty_like(nn_W), None   # the caller's tensor is read, never written
     st = _lib.stream_ptr()
