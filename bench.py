@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--input-pool-mb", type=float, default=320.0, help="distinct input clouds rotated through, in MB (0 = replay the "
                                                                        "same resident batches: MALL-warm inputs)")
     ap.add_argument("--no-lbs", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="bf16 = BASELINE config 3: shared-MLP operands in bf16 (fp32 accumulate); default fp32 = config 2")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
                                                        "exercising the multi-rank path on a box with fewer GPUs than ranks)")
@@ -428,7 +428,8 @@ def main():
             "metric": "point-cloud frames/s (FPS+ball_query+SA-MLP+LBS), B=8 N=8192",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
             "timed_seconds": dt, "ms_per_step": dt / total_steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 MLP operands / f32 accumulate, sampling, LBS", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16 MLP operands / f32 accumulate, sampling, LBS",
+                      "bf16x3": "f32 values; shared-MLP products as 6 bf16 x bf16 piece products of exact 3-way operand splits, f32 accumulate (fp32-accurate)"}[args.precision], "data": "synthetic",
             "latency_ms_single_stream": lat,
             "config": {"workload": "cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32"
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),

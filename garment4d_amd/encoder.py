@@ -73,7 +73,7 @@ class Pointnet2MSGSEG(nn.Module):
         `channel_major` (then converted to the reference's (B, C_l, N_l) at the boundary).
         precision="bf16" (BASELINE config 3) runs the shared MLPs with bf16 operands / fp32 accumulation; sampling,
         grouping, interpolation weights and all tensors crossing the API stay fp32."""
-        assert not self.training and precision in ("fp32", "bf16")
+        assert not self.training and precision in fused.PRECISIONS
         with fused.precision(precision):   # per-thread context, not a process global
             return self._forward_fused(pointcloud, channel_major)
 

@@ -38,7 +38,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu")
+    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -61,6 +61,23 @@ class PackedLayer:
         Wc16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 32)[..., kperm].permute(0, 2, 3, 1, 4).contiguous()
         self.W, self.Wf, self.Wf16, self.Wc16, self.scale, self.shift = W, Wf, Wf16, Wc16, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
+        self._kperm, self._x3 = kperm, None
+
+    def Wc16x3(self):
+        """The weight as three bf16 tensors in CHAIN order whose sum is the fp32 weight EXACTLY (hi = w & 0xffff0000,
+        mid = (w - hi) & 0xffff0000, lo = w - hi - mid; 8 + 8 + 8 significand bits) -- csrc/mlp_chain_bf16.hip, NSPL = 3."""
+        if self._x3 is None:
+            W = self.W
+            cpad, kpad = W.shape
+            mask = torch.tensor(-65536, dtype=torch.int32, device=W.device)   # 0xffff0000
+            hi = (W.view(torch.int32) & mask).view(torch.float32)
+            r = W - hi
+            mid = (r.view(torch.int32) & mask).view(torch.float32)
+            lo = r - mid
+            assert torch.equal(hi + mid + lo, W) and torch.equal(lo.to(torch.bfloat16).float(), lo)
+            self._x3 = tuple(p.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 32)[..., self._kperm].permute(0, 2, 3, 1, 4).contiguous()
+                             for p in (hi, mid, lo))
+        return self._x3
 
 
 def _fold(conv, bn):
@@ -172,6 +189,9 @@ _MAX_STACK_LDS = 150 * 1024
 import contextvars
 
 _PRECISION = contextvars.ContextVar("g4d_mlp_precision", default="fp32")
+# "bf16x3": fp32-ACCURATE contraction on the bf16 matrix cores (each fp32 operand split exactly into three bf16 pieces, six piece products
+# per product, fp32 accumulate) for the stacks the register-chain kernel covers; everything else runs the fp32 kernels
+PRECISIONS = ("fp32", "bf16", "bf16x3")
 
 
 def current_precision():
@@ -183,7 +203,7 @@ class precision:
     Every public entry point that takes `precision=` (encoder.forward_fused, the model forwards) is a thin wrapper of this."""
 
     def __init__(self, mode):
-        assert mode in ("fp32", "bf16")
+        assert mode in PRECISIONS
         self.mode = mode
 
     def __enter__(self):
@@ -271,6 +291,13 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
                   ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
                   out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
         return out
+    if current_precision() == "bf16x3" and chain_fits(layers, pool, S, mode):
+        W3 = (ctypes.c_void_p * (3 * n))(*[t.data_ptr() for L in layers for t in L.Wc16x3()])
+        _lib.call("g4d_mlp_chain_bf16x3", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
+                  n, ctypes.cast(W3, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
+                  ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
+                  out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
+        return out
     if _use_bf16(rows):
         W16 = PA(*[L.Wf16.data_ptr() for L in layers])
         _lib.call("g4d_mlp_stack_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
@@ -278,7 +305,7 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
                   ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
                   ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
         return out
-    if current_precision() == "fp32" and chain_fits(layers, pool, S, mode):
+    if current_precision() in ("fp32", "bf16x3") and chain_fits(layers, pool, S, mode):
         _lib.call("g4d_mlp_chain_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
                   n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
                   ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),

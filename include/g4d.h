@@ -241,6 +241,18 @@ int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float *X, int ldx
                        const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
                        float *tap_out, int tap_ld, g4d_stream_t stream);
 
+/* fp32-ACCURATE variant on the bf16 matrix cores ("bf16x3"): every fp32 operand is split exactly into three bf16 pieces
+ * (hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid) and a product is the sum of the six largest piece products,
+ * accumulated in fp32 -- error of the order of one fp32 rounding per product, six bf16 MFMAs instead of eight fp32 ones per
+ * 16 x 16 x 32 block (gfx950: 157 TFLOP/s fp32 MFMA against 2.5 PFLOP/s bf16).  Same arguments as g4d_mlp_chain_bf16 except
+ * W3: 3 * nlayers pointers, [3 l + 0 | 1 | 2] = the hi | mid | lo pieces of layer l, each bf16 in CHAIN order. */
+int g4d_mlp_chain_bf16x3(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                         const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                         int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int nlayers,
+                         const unsigned short *const *W3, const float *const *scale, const float *const *shift, const int *Kpad,
+                         const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
+                         float *tap_out, int tap_ld, g4d_stream_t stream);
+
 /* Batched SpMM of the GCN layer: out (frames,Vg,C) = Ahat (CSR) . S (frames,Vg,C) + bias (C, may be NULL), optional ReLU
  * (the caller's F.relu, modules/mesh_encoder.py:479-480, fused), all point-major (modules/pygcn/layers.py:44-55 without
  * the transposes).  GraphConvolution = g4d_linear_f32 then this. */

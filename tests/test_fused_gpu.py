@@ -258,3 +258,59 @@ def test_chain_bf16_kernel(widths, S, pool, monkeypatch, request_finalizers):
     scale = float(h.abs().max())
     err = float((out - h).abs().max())
     assert err <= 1.2e-2 * max(scale, 1.0), (err, scale)   # a bf16 ulp flip of a hidden activation (2^-8 relative) now and then
+
+
+@pytest.mark.parametrize("widths", [(3, 16, 16, 32), (3, 32, 32, 64), (99, 64, 64, 128), (195, 128, 128, 256), (67, 32, 32), (99, 128, 128), (40, 64),
+                                    (128, 7), (352, 256, 128)])
+@pytest.mark.parametrize("S,pool", [(16, 1), (64, 1), (4, 2), (1, 0)])
+def test_chain_bf16x3_kernel_is_fp32_accurate(widths, S, pool, monkeypatch, request_finalizers):
+    """precision "bf16x3" (csrc/mlp_chain_bf16.hip, NSPL = 3): every fp32 operand split exactly into three bf16 pieces, six piece
+    products per product on the bf16 matrix cores, fp32 accumulate.  Against a float64 evaluation of the same stack the error must
+    be of the fp32 kernels' order -- elementwise atol = rtol = 1e-5 of the tensor scale, the gate the fp32 route is held to -- and the
+    two routes must agree with each other to the same bound."""
+    g = torch.Generator().manual_seed(len(widths) * 10 + S)
+    S_ = max(S, 1)
+    B, N, P = 2, 400, 41 if S > 1 else 1500
+    C = widths[0] - 3
+    xyz = torch.rand(B, N, 3, generator=g).cuda()
+    new_xyz = torch.rand(B, P, 3, generator=g).cuda()
+    feats = torch.randn(B, N, max(C, 1), generator=g).cuda() if C > 0 else None
+    idx = torch.randint(0, N, (B, P, S_), generator=g, dtype=torch.int32).cuda()
+    Ws, layers = [], []
+    for i, (ci, co) in enumerate(zip(widths[:-1], widths[1:])):
+        W = torch.randn(co, ci, generator=g).cuda() * (1.5 / ci ** 0.5)
+        sc, sh = (torch.rand(co, generator=g) + 0.5).cuda(), torch.randn(co, generator=g).cuda() * 0.1
+        relu = i < len(widths) - 2 or pool != 0
+        Ws.append((W, sc, sh, relu))
+        layers.append(fused.PackedLayer(W, sc, sh, relu=relu))
+        pieces = layers[-1].Wc16x3()
+        assert len(pieces) == 3 and all(t.dtype == torch.bfloat16 for t in pieces)
+    rows = B * P * S_
+    assert fused.chain_fits(layers, pool, S_, 1)
+    outs = {}
+    for prec in ("fp32", "bf16x3"):
+        tok = fused._PRECISION.set(prec)
+        try:
+            out = torch.empty((rows // S_ if pool else rows, widths[-1]), device="cuda")
+            fused.mlp_stack(1, rows, widths[0], layers, out, pool=pool, S=S_, group=(N, P, max(C, 0), 1, xyz, new_xyz, feats, idx))
+            outs[prec] = out
+        finally:
+            fused._PRECISION.reset(tok)
+    bi = torch.arange(B, device="cuda")[:, None, None]
+    li = idx.long()
+    x = xyz[bi, li] - new_xyz[:, :, None, :]
+    if C > 0:
+        x = torch.cat([x, feats[bi, li]], -1)
+    h = x.reshape(rows, -1).double()
+    for W, sc, sh, relu in Ws:
+        h = (h @ W.double().T) * sc.double() + sh.double()
+        h = torch.relu(h) if relu else h
+    if pool:
+        h = h.view(-1, S_, h.shape[-1])
+        h = h.max(1)[0] if pool == 1 else h.mean(1)
+    scale = max(float(h.abs().max()), 1.0)
+    e32 = float((outs["fp32"].double() - h).abs().max())
+    ex3 = float((outs["bf16x3"].double() - h).abs().max())
+    print(f"[parity] chain {widths} S={S} pool={pool}: max_abs vs float64 -- fp32 MFMA {e32:.3g}, bf16x3 {ex3:.3g} (scale {scale:.3g})")
+    assert ex3 <= 1e-5 * scale, (ex3, scale)
+    assert ex3 <= max(4.0 * e32, 2e-6 * scale), (ex3, e32)     # no worse than the fp32 route beyond a small factor

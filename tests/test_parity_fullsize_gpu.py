@@ -57,6 +57,25 @@ def test_cfg2_encoder_full_size_vs_oracle(kind, contraction_mode):
     check(f"cfg2/{kind} sem_logits", logits, want_logits)
 
 
+def test_cfg2_encoder_full_size_bf16x3_split_vs_fp32_oracle():
+    """precision="bf16x3" (fp32-accurate contraction on the bf16 matrix cores: exact three-way operand splits, six piece products,
+    fp32 accumulate) at BASELINE config 2's real size against the SAME fp32 oracle and the SAME elementwise rtol = atol = 1e-5 gate as
+    the fp32 route; sampling / grouping indices stay bit-exact (they never touch the MLP precision)."""
+    B, N = 2, 8192
+    xyz = syn.body_like_cloud(B, N, seed=21)
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=5).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    want_logits, want_f, want_xyz = MO.encoder_forward(xyz, sd)
+    model = model.cuda()
+    with torch.no_grad():
+        _, logits, l_f, l_xyz = model.forward_fused(dev(xyz), channel_major=True, precision="bf16x3")
+    for lvl in range(1, 4):
+        assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl]), f"FPS-selected centroids of level {lvl}: not bit-exact"
+    for lvl in range(0, 4):
+        check(f"cfg2/bf16x3 l_features[{lvl}]", l_f[lvl], want_f[lvl])
+    check("cfg2/bf16x3 sem_logits", logits, want_logits)
+
+
 def test_cfg3_encoder_bf16_full_size_vs_bf16_oracle(monkeypatch):
     """BASELINE config 3 precision at N = 8192: bf16 MLP operands, fp32 accumulate; sampling stays bit-exact."""
     B, N = 1, 8192
