@@ -18,6 +18,7 @@ _LL = ctypes.c_longlong
 # name -> argtypes (stream last); every function returns int status (0 = ok)
 SIGNATURES = {
     "g4d_fps_f32": [_I, _I, _I, _vp, _vp, _vp, _vp],
+    "g4d_fps_gather_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_gather_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_gather_grad_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_ball_query_f32": [_I, _I, _I, _F, _I, _vp, _vp, _vp, _vp],

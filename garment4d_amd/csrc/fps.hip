@@ -93,7 +93,7 @@ __device__ __forceinline__ void wave_argmax(float best, int k, int bs, int log2b
 // points c + q*bs (q < Q).  Slot i = v*Q + q visits u = bitrev(v) so that tie-rank ascends with i.
 template <int W, int U, int Q, int FM>
 __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
-                                                        float *__restrict__ temp_all, int *__restrict__ idx_all) {
+                                                        float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
     constexpr int T = 64 * W, P = U * Q;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * 16);   // SoA copy of the cloud
@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
     const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     float *temp = temp_all + (size_t)blockIdx.x * n;
     int *idx = idx_all + (size_t)blockIdx.x * m;
+    float *nx = nx_all ? nx_all + (size_t)blockIdx.x * m * 3 : nullptr;   // optional: the selected points themselves (gather fused)
 
     float px[P], py[P], pz[P], md[P];
 #pragma unroll
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
     __syncthreads();
 
     float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+    if (t == 0 && nx) { nx[0] = x1; nx[1] = y1; nx[2] = z1; }
     const int wave = t >> 6;
     for (int j = 1; j < m; ++j) {
         float best = -1.f;
@@ -155,7 +157,10 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
             old = (int)(((rank & 0xffffu) << log2bs) | c);
         }
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
-        if (t == 0) idx[j] = old;
+        if (t == 0) {
+            idx[j] = old;
+            if (nx) { nx[j * 3 + 0] = x1; nx[j * 3 + 1] = y1; nx[j * 3 + 2] = z1; }
+        }
     }
     if (temp_all) {
 #pragma unroll
@@ -170,18 +175,21 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
 // memory), the same DPP + one-barrier reduction.  1024 threads; threads >= bs idle.
 template <int FM>
 __global__ void __launch_bounds__(1024) fps_generic_kernel(int n, int m, int bs, int log2bs, const float *__restrict__ xyz_all,
-                                                          float *__restrict__ temp_all, int *__restrict__ idx_all) {
+                                                          float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
     constexpr int W = 16;
     __shared__ FpsCand slots[2][W];
     const int t = threadIdx.x;
     const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     float *temp = temp_all + (size_t)blockIdx.x * n;
     int *idx = idx_all + (size_t)blockIdx.x * m;
+    float *nx = nx_all ? nx_all + (size_t)blockIdx.x * m * 3 : nullptr;
     if (t == 0) idx[0] = 0;
     int old = 0;
     const int wave = t >> 6;
-    for (int j = 1; j < m; ++j) {
+    for (int j = 1; j <= m; ++j) {   // the last pass only stores the coordinates of sample m - 1
         const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+        if (t == 0 && nx) { nx[(j - 1) * 3 + 0] = x1; nx[(j - 1) * 3 + 1] = y1; nx[(j - 1) * 3 + 2] = z1; }
+        if (j == m) break;
         float best = -1.f;
         int besti = 0;
         if (t < bs) {
@@ -236,29 +244,29 @@ static int ref_block_size(int work_size) {
 }
 
 template <int W, int U, int Q, int FM>
-static int launch_reg_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+static int launch_reg_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     const size_t lds = 2 * 16 * 16 + (size_t)n * 12;
     auto kern = fps_reg_kernel<W, U, Q, FM>;
     static unsigned long long attr_done = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32")) return rc;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, xyz, temp, idx, nx);
     return check_launch("g4d_fps_f32");
 }
 
 template <int W, int U, int Q>
-static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
-    G4D_WITH_FM(distance_contraction(), return (launch_reg_fm<W, U, Q, FM>(b, n, m, bs, log2bs, xyz, temp, idx, s)))
+static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
+    G4D_WITH_FM(distance_contraction(), return (launch_reg_fm<W, U, Q, FM>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s)))
     return G4D_OK;
 }
 
-int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s);  // fps_bucket.hip
+int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s);  // fps_bucket.hip
 
 
 static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|8|16|0(generic); unset = automatic (bucketed kernel for 2048 < n <= 8192)
 
 }  // namespace g4d
 
-extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, g4d_stream_t stream) {
+static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx, float *nx, g4d_stream_t stream) {
     using namespace g4d;
     G4D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "g4d_fps_f32: negative size (b=%d n=%d m=%d)", b, n, m);
     if (b == 0 || m == 0) return G4D_OK;  // sampling_gpu.cu:100  if (m <= 0) return;
@@ -277,11 +285,11 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
     // 4096 < n <= 8192: bucketed kernel with exact box pruning (fps_bucket.hip); G4D_FPS_BUCKET=0 turns it off
     static const int use_bucket = getenv("G4D_FPS_BUCKET") ? atoi(getenv("G4D_FPS_BUCKET")) : 1;  // 0 = off, 2 = also 2048 < n <= 4096
     if (use_bucket && force > 16 && n > (use_bucket >= 2 ? 2048 : 4096) && n <= 8192) {
-        const int rc = fps_bucket_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, s);
+        const int rc = fps_bucket_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
         if (rc >= 0) return rc;
     }
     const bool lds_ok = (size_t)n * 12 + 512 <= 150 * 1024;
-#define G4D_FPS_CASE(W, U, Q) return launch_reg<W, U, Q>(b, n, m, bs, log2bs, xyz, temp, idx, s)
+#define G4D_FPS_CASE(W, U, Q) return launch_reg<W, U, Q>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s)
     if (lds_ok && force != 0 && bs >= 64) {
         const int qp = q <= 1 ? 1 : q <= 2 ? 2 : q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : 0;
         // single wave: no barrier at all; preferred for small clouds
@@ -337,6 +345,15 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
     }
 #undef G4D_FPS_CASE
     G4D_REQUIRE(temp, "g4d_fps_f32: temp scratch (B,N) is required for this N (register-resident path covers 64 <= N <= 12800)");
-    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(fps_generic_kernel<FM>, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx))
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(fps_generic_kernel<FM>, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx, nx))
     return check_launch("g4d_fps_f32(generic)");
+}
+
+extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, g4d_stream_t stream) {
+    return fps_impl(b, n, m, xyz, temp, idx, nullptr, stream);
+}
+
+extern "C" int g4d_fps_gather_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, g4d_stream_t stream) {
+    G4D_REQUIRE(new_xyz || b == 0 || m == 0, "g4d_fps_gather_f32: new_xyz is NULL");
+    return fps_impl(b, n, m, xyz, temp, idx, new_xyz, stream);
 }

@@ -100,7 +100,7 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
 template <int W, int P, int FM>
 __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, const float *__restrict__ xyz_all,
-                                                           float *__restrict__ temp_all, int *__restrict__ idx_all) {
+                                                           float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
     constexpr int T = 64 * W, NPAD = T * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);         // [2][16] candidate keys
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
     const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     float *temp = temp_all ? temp_all + (size_t)blockIdx.x * n : nullptr;
     int *idx = idx_all + (size_t)blockIdx.x * m;
+    float *nx = nx_all ? nx_all + (size_t)blockIdx.x * m * 3 : nullptr;   // optional: the selected points themselves (gather fused)
     const float INF = __builtin_inff();
 
     // ---- A. Morton keys of the cloud -------------------------------------------------------------------------
@@ -201,6 +202,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
     __syncthreads();
 
     float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+    if (t == 0 && nx) { nx[0] = x1; nx[1] = y1; nx[2] = z1; }
     float gval = INF;          // global max of the min-distances (the last winner's value): nothing can exceed it
     float cval = -2.f;         // this wave's cached candidate (value, rank); refreshed only when one of its buckets was swept
     unsigned crank = 0xffffffffu;
@@ -275,7 +277,10 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
         const unsigned c = log2bs ? (__builtin_bitreverse32(rank >> 16) >> (32 - log2bs)) : 0u;
         const int old = (int)(((rank & 0xffffu) << log2bs) | c);
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
-        if (t == 0) idx[j] = old;
+        if (t == 0) {
+            idx[j] = old;
+            if (nx) { nx[j * 3 + 0] = x1; nx[j * 3 + 1] = y1; nx[j * 3 + 2] = z1; }
+        }
 #ifdef G4D_FPS_DEBUG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
 }
 
 template <int W, int P, int FM>
-static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
     const size_t lds = 1024 + body;
@@ -305,25 +310,25 @@ static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float
     // measured at N = 8192, M = 1024, B = 8 (scripts/time_fps.py): deal 1 / 2 / 4 / 8 -> 0.812 / 0.783 / 0.757 / 0.748 us per round
     static const int deal_env = getenv("G4D_FPS_DEAL") ? atoi(getenv("G4D_FPS_DEAL")) : 0;  // tuning hook: 1 | 2 | 4 | ... | P; 0 = P
     const int deal = (deal_env >= 1 && deal_env <= P && P % deal_env == 0) ? deal_env : P;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal, xyz, temp, idx);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal, xyz, temp, idx, nx);
     return check_launch("g4d_fps_f32(bucketed)");
 }
 
 template <int W, int P>
-static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
-    G4D_WITH_FM(distance_contraction(), return (launch_bucket_fm<W, P, FM>(b, n, m, bs, log2bs, xyz, temp, idx, s)))
+static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
+    G4D_WITH_FM(distance_contraction(), return (launch_bucket_fm<W, P, FM>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s)))
     return G4D_OK;
 }
 
 // Called by g4d_fps_f32 (fps.hip) for 2048 < n <= 8192.  Returns -1 when the shape is not covered.
-int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, hipStream_t s) {
+int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     static const int cfg = getenv("G4D_FPS_BUCKET_W") ? atoi(getenv("G4D_FPS_BUCKET_W")) : 16;  // tuning hook
     if (n > 4096 && n <= 8192) {
-        if (cfg == 8) return launch_bucket<8, 16>(b, n, m, bs, log2bs, xyz, temp, idx, s);
-        if (cfg == 4) return launch_bucket<4, 32>(b, n, m, bs, log2bs, xyz, temp, idx, s);
-        return launch_bucket<16, 8>(b, n, m, bs, log2bs, xyz, temp, idx, s);
+        if (cfg == 8) return launch_bucket<8, 16>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
+        if (cfg == 4) return launch_bucket<4, 32>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
+        return launch_bucket<16, 8>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
     }
-    if (n > 2048 && n <= 4096) return launch_bucket<16, 4>(b, n, m, bs, log2bs, xyz, temp, idx, s);
+    if (n > 2048 && n <= 4096) return launch_bucket<16, 4>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
     return -1;
 }
 

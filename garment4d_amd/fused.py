@@ -427,15 +427,11 @@ def fps_gather(xyz, npoint, sidx=None, new_xyz=None):
     stream = _lib.stream_ptr()
     if sidx is None:
         sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-    if 64 <= N <= 12800:  # register-resident FPS: no scratch tensor, no fill kernel
-        _lib.call("g4d_fps_f32", B, N, npoint, xyz.data_ptr(), 0, sidx.data_ptr(), stream)
-    else:
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        _lib.call("g4d_fps_f32", B, N, npoint, xyz.data_ptr(), temp.data_ptr(), sidx.data_ptr(), stream)
-    # gather of the 3 coordinates = GROUP loader with S=1 would do; the legacy kernel wants (B,3,N)
     if new_xyz is None:
         new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
-    _lib.call("g4d_gather_rows_f32", B, N, npoint, 3, xyz.data_ptr(), sidx.data_ptr(), new_xyz.data_ptr(), stream)
+    temp = None if 64 <= N <= 12800 else torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)   # register-resident FPS: no scratch
+    # the sampling kernel writes the selected coordinates as it goes (g4d_fps_gather_f32): no gather launch
+    _lib.call("g4d_fps_gather_f32", B, N, npoint, xyz.data_ptr(), _ptr(temp), sidx.data_ptr(), new_xyz.data_ptr(), stream)
     return new_xyz
 
 

@@ -64,6 +64,10 @@ int g4d_set_distance_contraction(int mode);
  * register-resident kernels then start from 1e10 themselves and skip the write-back). */
 int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, g4d_stream_t stream);
 
+/* The same sampling with the gather of the selected coordinates fused (pointnet2_modules.py:32-35 calls furthest_point_sample and
+ * then gather_operation on xyz): new_xyz (B,m,3) = xyz[b, idx[b,j], :], written by the sampling kernel as each sample is chosen. */
+int g4d_fps_gather_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, g4d_stream_t stream);
+
 /* gather_points_kernel_launcher_fast (sampling_gpu.h:9-13): out[b,c,j] = points[b,c,idx[b,j]].
  * points (B,C,N), idx (B,M), out (B,C,M). */
 int g4d_gather_f32(int b, int c, int n, int m, const float *points, const int *idx, float *out,

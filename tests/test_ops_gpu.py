@@ -140,6 +140,20 @@ def test_three_nn_vs_oracle(B, n, m):
     np.testing.assert_allclose(host(d), wd, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("N,M", [(40, 7), (256, 64), (1024, 256), (3000, 500), (4096, 1024), (8192, 1024), (20000, 300)])
+def test_fps_with_fused_gather_every_kernel_variant(N, M):
+    """g4d_fps_gather_f32: the sampling kernels (single wave, register-resident, bucketed, generic) also write the coordinates of each
+    sample as it is chosen; indices unchanged, new_xyz == xyz[idx] exactly."""
+    from garment4d_amd import fused
+    xyz = syn.body_like_cloud(3, N, seed=N)
+    x = dev(xyz)
+    sidx = torch.empty((3, M), dtype=torch.int32, device="cuda")
+    new_xyz = fused.fps_gather(x, M, sidx=sidx)
+    want_idx = K.fps(xyz, M)
+    assert np.array_equal(host(sidx), want_idx)
+    assert np.array_equal(host(new_xyz), np.take_along_axis(xyz, want_idx[..., None].astype(np.int64), 1))
+
+
 def _nn_cases():
     rng = np.random.default_rng(17)
     un = syn.unit_cloud(2, 700, seed=3)
