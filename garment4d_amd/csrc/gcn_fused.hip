@@ -18,20 +18,41 @@
 //     tiles), A fragments from the LDS slice (ds_read_b128, 4 consecutive k per lane feeding 4 MFMAs), B fragments of the next
 //     weight pre-packed in fragment order (one 16-byte load per lane per 16 k) and read once per block.
 //     For a narrow next layer (Cout <= 16: the 128 -> 3 regressor) wave w owns rows [32 w, 32 w + 32) x one channel tile.
-// LDS: window slice 288 x 36 floats + A slice 128 x 36 floats + 2048 CSR entries = 76 KB -> two blocks per CU, one in its MFMA phase while the other
-// stages and aggregates.  Roofline: fp32 MFMA (2 * rows * 128 * Cout flop; 205 us at 983k rows, Cout = 128) over
-// HBM (rows * 128 * 4 B read + rows * Cout * 4 B written [+ the tap]).
+// LDS: window slice 288 x 32 floats + A slice 128 x 36 floats + 128 x 8 padded CSR pairs = 63 KB -> two blocks per CU.
+// Roofline: fp32 MFMA (2 * rows * 128 * Cout flop; 205 us at 983k rows, Cout = 128) over HBM (rows * 128 * 4 B read + rows * Cout * 4 B
+// written [+ the tap]).  Measured phase split per tile (in-kernel stamps, scripts/dbg_gcn_phases.py, -DG4D_GCN_DEBUG): of ~83k cycles
+// only 19k are MFMA issue; 20k aggregation (LDS chains), 6k staging, 6k load issue, ~25k tile prologue / epilogue (dependent global
+// loads for the window bounds and the padded rows, output store) -- with two 4-wave blocks per CU these latencies are exposed.
+// What did NOT matter: the block mix per CU (3 blocks of 64 rows: same), a start stagger between co-resident blocks, LDS bank
+// conflicts of the window reads (stride 36 -> 32), the order of the loads against the in-order vmcnt.  Next: per-tile metadata
+// precomputed once per mesh (window bounds, padded rows) and a persistent block that prefetches the next TILE.
+#include <cstdlib>
+
 #include "g4d_common.h"
 
 namespace g4d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTile = 128;   // rows (vertices) per block
-constexpr int kWin = 288;    // window rows staged in LDS
-constexpr int kLd = 36;      // LDS row stride in floats (32 channels + 4: b128 reads of 8 lanes x 8 rows spread over the banks)
+// Tile geometry.  TILE = rows (vertices) per block; WIN = window rows staged in LDS.
+//   TILE 128 / WIN 288: 63 KB of LDS, two blocks per CU, window read amplification ~2x on a 64-wide grid mesh
+//   TILE  64 / WIN 224: 42 KB of LDS, three blocks per CU, amplification ~3x
+template <int TILE> struct Geo;
+template <> struct Geo<128> { static constexpr int kWin = 288; };
+template <> struct Geo<64> { static constexpr int kWin = 224; };
+constexpr int kEll = 8;      // CSR rows of a tile are kept in LDS padded to this many (column, weight) pairs (zero weights); longer rows: slow path
+constexpr int kLd = 36;      // A-slice row stride in floats (32 channels + 4: the MFMA fragment reads -- 16 rows, same k -- spread over the banks)
+constexpr int kLdW = 32;     // window row stride: the aggregation reads 8 lanes x 16 B of DIFFERENT rows per 16-lane LDS group ({row a: ch 0-15,
+                             // row b: 16-31, row c: 16-31, row d: 0-15}); neighbour columns of consecutive rows are consecutive, so a 32-float
+                             // stride alternates the bank halves and the group is conflict-free (stride 36: two-way conflicts, measured)
 constexpr int kC = 128;      // support width (hidden_dim of the refinement GCNs)
-constexpr int kEnt = 2048;   // CSR entries of a tile kept in LDS (16 per row on average)
+
+#ifdef G4D_GCN_DEBUG
+__device__ long long g_gcn_dbg[8 * 4096];  // per block (first 4096), wave 0: cycles per phase (scripts/dbg_gcn_phases.py)
+#define G4D_GSTAMP(i) { if (threadIdx.x == 0 && blockIdx.x < 4096) { const long long now_ = (long long)__builtin_readcyclecounter(); g_gcn_dbg[blockIdx.x * 8 + (i)] += now_ - dbg_last; dbg_last = now_; } }
+#else
+#define G4D_GSTAMP(i)
+#endif
 
 struct GcnFusedArgs {
     int vg, frames, tpf;     // tpf = tiles per frame
@@ -47,32 +68,58 @@ struct GcnFusedArgs {
 
 // NT = channel tiles of the next layer: 8 (Cout = 128: wave owns 2 channel tiles x 8 row tiles) or 1 (Cout <= 16: wave owns
 // 2 row tiles x the one channel tile).
-// FAST: the tile's window fits kWin rows and its CSR entries fit kEnt -> window slices and the (column, value) pairs live in LDS, the
+// FAST: the tile's window fits kWin rows and no row has more than kEll entries -> window slices and the padded (column, weight) rows live in LDS, the
 // next slice's window rows are prefetched into registers while this slice is aggregated and contracted.  !FAST: any numbering, any
 // valence -- neighbour rows and CSR entries straight from global memory (the old SpMM's access pattern).
-template <int NT, bool FAST>
-__device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int r0, float *win, float *asl, int2 *ent, int lo, int wrows, int e0, int nent) {
+template <int NT, int TILE, bool FAST>
+__device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int r0, float *win, float *asl, int2 *ent, int lo, int wrows, int e0, int ell) {
+#ifdef G4D_GCN_DEBUG
+    long long dbg_last = (long long)__builtin_readcyclecounter();
+#endif
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fi = lane & 15, fq = lane >> 4;
+    constexpr int kTile = TILE, kWin = Geo<TILE>::kWin, NP = TILE / 32;   // NP = rows per thread in the aggregation
     const int nrows = min(kTile, a.vg - r0);
     const float *S = a.S + (size_t)f * a.vg * kC;
     constexpr int NPRE = kWin / 32;   // window rows per thread and slice
 
     // aggregation map: thread -> (row ar + 32 p, channels ac .. ac + 3 of the slice)
     const int ar = t >> 3, ac = (t & 7) * 4;
-    int beg[4], len[4], maxlen = 0;
+    int beg[NP], len[NP], maxlen = 0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int r = ar + 32 * p;
         const bool ok = r < nrows;
         const int b = ok ? a.rowptr[r0 + r] : 0, e = ok ? a.rowptr[r0 + r + 1] : 0;
-        beg[p] = b - (FAST ? e0 : 0);
+        beg[p] = b;
         len[p] = e - b;
         maxlen = max(maxlen, len[p]);
     }
     if constexpr (FAST) {
-        for (int k = t; k < nent; k += 256) ent[k] = make_int2((a.colidx[e0 + k] - lo) * kLd, __float_as_int(a.vals[e0 + k]));
+        // the tile's CSR rows, padded to `ell` (column offset into `win`, weight) pairs each: the aggregation loop then has a
+        // block-uniform trip count and no per-entry predicate (a padded pair adds 0 * (the row's first neighbour) -- exactly
+        // nothing for finite activations).  Thread t fills pairs t, t + 256, ...
+        for (int k = t; k < kTile * kEll; k += 256) {
+            const int r = k / kEll, j = k - r * kEll;
+            int col = lo;
+            float w = 0.f;
+            if (r < nrows) {
+                const int b = a.rowptr[r0 + r], n = a.rowptr[r0 + r + 1] - b;
+                if (n > 0) {
+                    const int e = b + (j < n ? j : 0);
+                    col = a.colidx[e];
+                    w = j < n ? a.vals[e] : 0.f;
+                }
+            }
+            ent[k] = make_int2((col - lo) * kLdW, __float_as_int(w));
+        }
+        maxlen = ell;
+    } else {
+        // the longest row of the WAVE bounds the entry loop: a wave-uniform trip count (a per-lane one makes the loop divergent)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+        maxlen = __builtin_amdgcn_readfirstlane(maxlen);
     }
     f32x4 pre[NPRE];
     auto prefetch = [&](int ks) {
@@ -84,7 +131,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
     };
     if constexpr (FAST) prefetch(0);
 
-    constexpr int MT = NT == 8 ? 8 : 2;   // row tiles per wave
+    constexpr int MT = NT == 8 ? TILE / 16 : (TILE / 64 > 0 ? TILE / 64 : 1);   // row tiles per wave
     constexpr int NW = NT == 8 ? 2 : 1;   // channel tiles per wave
     f32x4 acc[MT][NW];
 #pragma unroll
@@ -92,6 +139,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    G4D_GSTAMP(0)   // tile prologue: row pointers, CSR entries to LDS, first prefetch issued
     for (int ks = 0; ks < 4; ++ks) {
         const int c0 = ks * 32;
         // 1. the window slice (rows lo .. lo + wrows, channels c0 .. c0 + 31) goes from the prefetch registers to LDS
@@ -99,14 +147,15 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
                 const int r = ar + 32 * i;
-                if (r < wrows) *reinterpret_cast<f32x4 *>(&win[r * kLd + ac]) = pre[i];
+                if (r < wrows) *reinterpret_cast<f32x4 *>(&win[r * kLdW + ac]) = pre[i];
             }
         }
         __syncthreads();   // window (and, first time, the CSR entries) visible; the previous slice's MFMAs are done with `asl`
-        if constexpr (FAST) {
-            if (ks < 3) prefetch(ks + 1);   // in flight during the aggregation and the MFMAs of this slice
-        }
-        // the slice's B fragments: in flight during the aggregation
+        G4D_GSTAMP(1)   // prefetched rows arrived + stored + barrier
+        // Issue ORDER matters: vector-memory loads retire in order (s_waitcnt vmcnt counts from the oldest), so whatever this slice
+        // itself waits for -- the B fragments, the bias -- must be requested BEFORE the next slice's window rows; behind them, the
+        // first use of `bv` would wait for the whole HBM round trip of the prefetch (measured: 6k cycles per slice in the aggregation
+        // phase, and the MFMAs started only after the prefetch had landed).
         f32x4 bf[2][NW];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
@@ -115,33 +164,62 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
                 const int nt = NT == 8 ? wave * 2 + n : 0;
                 bf[h2][n] = *reinterpret_cast<const f32x4 *>(a.Wp + ((size_t)(nt * 8 + ks * 2 + h2) * 64 + lane) * 4);
             }
-        // 2. aggregate: h = act(sum_e vals[e] * S[col[e]] + bias), CSR order, fmaf -- spmm_rows_kernel's arithmetic.  The four rows
-        //    of a thread advance together: four independent chains of dependent LDS reads
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + c0 + ac) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 h[4];
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FAST) {
+            if (ks < 3) prefetch(ks + 1);   // in flight during the aggregation and the MFMAs of this slice
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        G4D_GSTAMP(2)   // next prefetch + B fragments issued
+        f32x4 h[NP];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) h[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < maxlen; ++j) {
+        for (int p = 0; p < NP; ++p) h[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (FAST) {
+            // padded rows in LDS: per (row, entry) one 8-byte read, one address add, one 16-byte read, two packed FMAs; the pair of
+            // entry j + 1 is requested before entry j's row is read
+            int2 cvn[NP];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (j < len[p]) {
-                    float w;
-                    f32x4 x;
-                    if constexpr (FAST) {
-                        const int2 cv = ent[beg[p] + j];
-                        w = __int_as_float(cv.y);
-                        x = *reinterpret_cast<const f32x4 *>(&win[cv.x + ac]);
-                    } else {
-                        w = a.vals[beg[p] + j];
-                        x = *reinterpret_cast<const f32x4 *>(S + (size_t)a.colidx[beg[p] + j] * kC + c0 + ac);
-                    }
-                    h[p].x = __builtin_fmaf(w, x.x, h[p].x); h[p].y = __builtin_fmaf(w, x.y, h[p].y);
-                    h[p].z = __builtin_fmaf(w, x.z, h[p].z); h[p].w = __builtin_fmaf(w, x.w, h[p].w);
+            for (int p = 0; p < NP; ++p) cvn[p] = ent[(ar + 32 * p) * kEll];
+            for (int j = 0; j < maxlen; ++j) {
+                int2 cv[NP];
+                f32x4 x[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    cv[p] = cvn[p];
+                    x[p] = *reinterpret_cast<const f32x4 *>(&win[cv[p].x + ac]);
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) cvn[p] = ent[(ar + 32 * p) * kEll + min(j + 1, kEll - 1)];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float w = __int_as_float(cv[p].y);
+                    h[p].x = __builtin_fmaf(w, x[p].x, h[p].x); h[p].y = __builtin_fmaf(w, x[p].y, h[p].y);
+                    h[p].z = __builtin_fmaf(w, x[p].z, h[p].z); h[p].w = __builtin_fmaf(w, x[p].w, h[p].w);
+                }
+            }
+        } else {
+            // any numbering / valence: entries and neighbour rows straight from global memory, loads unconditional (a lane past the
+            // end of its row re-reads its first entry and discards the product) so that the NP rows of a thread advance together
+            for (int j = 0; j < maxlen; ++j) {
+                float w[NP];
+                f32x4 x[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int ee = len[p] > 0 ? beg[p] + (j < len[p] ? j : 0) : e0;   // e0: any valid entry
+                    w[p] = a.vals[ee];
+                    x[p] = *reinterpret_cast<const f32x4 *>(S + (size_t)a.colidx[ee] * kC + c0 + ac);
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    f32x4 n;
+                    n.x = __builtin_fmaf(w[p], x[p].x, h[p].x); n.y = __builtin_fmaf(w[p], x[p].y, h[p].y);
+                    n.z = __builtin_fmaf(w[p], x[p].z, h[p].z); n.w = __builtin_fmaf(w[p], x[p].w, h[p].w);
+                    h[p] = j < len[p] ? n : h[p];
                 }
             }
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int r = ar + 32 * p;
             f32x4 y = h[p] + bv;
             if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
@@ -149,13 +227,15 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
             *reinterpret_cast<f32x4 *>(&asl[r * kLd + ac]) = y;
             if (a.tap && r < nrows) *reinterpret_cast<f32x4 *>(a.tap + ((size_t)f * a.vg + r0 + r) * kC + c0 + ac) = y;
         }
+        G4D_GSTAMP(3)   // aggregation loop + stores
         __syncthreads();   // A slice visible; everybody is done reading `win`
+        G4D_GSTAMP(4)   // barrier
         // 3. contract the slice with the next weight
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int mt = NT == 8 ? m : wave * 2 + m;
+                const int mt = NT == 8 ? m : wave * MT + m;
                 const f32x4 af = *reinterpret_cast<const f32x4 *>(&asl[(mt * 16 + fi) * kLd + h2 * 16 + fq * 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -163,6 +243,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
                     for (int n = 0; n < NW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[h2][n][e], acc[m][n], 0, 0, 0);
             }
         }
+        G4D_GSTAMP(5)   // MFMAs issued
     }
     // store S_next: C/D layout of the 16x16 MFMA -- column = lane & 15, rows = (lane >> 4) * 4 + reg
     float *out = a.out + ((size_t)f * a.vg + r0) * a.cout;
@@ -170,7 +251,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            const int mt = NT == 8 ? m : wave * 2 + m;
+            const int mt = NT == 8 ? m : wave * MT + m;
             const int ch = (NT == 8 ? wave * 2 + n : 0) * 16 + fi;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -180,12 +261,13 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
         }
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256, 2) gcn_fused_kernel(const GcnFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float win[kWin * kLd];
+template <int NT, int TILE>
+__global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(const GcnFusedArgs a) {
+    constexpr int kTile = TILE, kWin = Geo<TILE>::kWin;
+    __shared__ __attribute__((aligned(16))) float win[kWin * kLdW];
     __shared__ __attribute__((aligned(16))) float asl[kTile * kLd];
-    __shared__ int2 ent[kEnt];
-    __shared__ int s_lohi[2];
+    __shared__ int2 ent[kTile * kEll];
+    __shared__ int s_lohi[3];   // window [lo, hi], longest row
     const int t = threadIdx.x, lane = t & 63;
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD has its own L2, and the windows
     // of neighbouring tiles overlap (the halo rows).  XCD x therefore walks a CONTIGUOUS range of the (frame, tile) list: the
@@ -198,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) gcn_fused_kernel(const GcnFusedArgs a)
     const int r0 = (logical - f * a.tpf) * kTile;
     const int nrows = min(kTile, a.vg - r0);
     // window of the tile: [lo, hi) over the column indices of its rows (a contiguous CSR range)
-    if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; }
+    if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; s_lohi[2] = 0; }
     __syncthreads();
     const int e0 = a.rowptr[r0], e1 = a.rowptr[r0 + nrows];
     {
@@ -214,13 +296,18 @@ __global__ void __launch_bounds__(256, 2) gcn_fused_kernel(const GcnFusedArgs a)
             hi = max(hi, __shfl_xor(hi, o));
         }
         if (lane == 0 && hi >= 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
+        int rl = t < nrows ? a.rowptr[r0 + t + 1] - a.rowptr[r0 + t] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rl = max(rl, __shfl_xor(rl, o));
+        if (lane == 0) atomicMax(&s_lohi[2], rl);
     }
     __syncthreads();
     const int lo = s_lohi[0], hi = s_lohi[1] + 1;
-    if (e1 - e0 <= kEnt && hi - lo <= kWin && hi > lo)   // block-uniform
-        gcn_fused_tile<NT, true>(a, f, r0, win, asl, ent, lo, hi - lo, e0, e1 - e0);
+    const int ell = s_lohi[2];
+    if (ell <= kEll && hi - lo <= kWin && hi > lo)   // block-uniform
+        gcn_fused_tile<NT, TILE, true>(a, f, r0, win, asl, ent, lo, hi - lo, e0, ell);
     else
-        gcn_fused_tile<NT, false>(a, f, r0, win, asl, ent, 0, 0, e0, e1 - e0);
+        gcn_fused_tile<NT, TILE, false>(a, f, r0, win, asl, ent, 0, 0, e0, ell);
 }
 
 }  // namespace g4d
@@ -235,13 +322,30 @@ extern "C" int g4d_gcn_agg_linear_f32(int frames, int vg, int c, const float *S,
     G4D_REQUIRE(cout == 128 || (cout >= 1 && cout <= 16), "g4d_gcn_agg_linear_f32: Cout must be 128 or <= 16 (got %d)", cout);
     if (frames == 0 || vg == 0) return G4D_OK;
     G4D_REQUIRE(S && rowptr && colidx && vals && Wp && out, "g4d_gcn_agg_linear_f32: null pointer");
-    const int tpf = (vg + kTile - 1) / kTile;
+    static const int tile = [] { const char *e = getenv("G4D_GCN_TILE"); return e && atoi(e) == 64 ? 64 : 128; }();   // measured: 2.12 ms (128) vs 2.20 ms (64) per 4-layer stack at 240 x 4096 rows
+    const int tpf = (vg + tile - 1) / tile;
     G4D_REQUIRE((long long)tpf * frames < (1ll << 30), "g4d_gcn_agg_linear_f32: too many tiles");
     GcnFusedArgs a = {vg, frames, tpf, S, rowptr, colidx, vals, bias, relu, tap, Wp, cout, out};
     const int per_xcd = (tpf * frames + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (cout == 128) hipLaunchKernelGGL(gcn_fused_kernel<8>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gcn_fused_kernel<1>, grid, dim3(256), 0, st, a);
+    if (tile == 128) {
+        if (cout == 128) hipLaunchKernelGGL((gcn_fused_kernel<8, 128>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gcn_fused_kernel<1, 128>), grid, dim3(256), 0, st, a);
+    } else {
+        if (cout == 128) hipLaunchKernelGGL((gcn_fused_kernel<8, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gcn_fused_kernel<1, 64>), grid, dim3(256), 0, st, a);
+    }
     return check_launch("g4d_gcn_agg_linear_f32");
 }
+
+#ifdef G4D_GCN_DEBUG
+extern "C" int g4d_gcn_debug_read(long long *host_out, int reset) {
+    const int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g4d::g_gcn_dbg), sizeof(long long) * 8 * 4096);
+    if (reset) {
+        static long long zeros[8 * 4096];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g4d::g_gcn_dbg), zeros, sizeof(zeros));
+    }
+    return rc;
+}
+#endif

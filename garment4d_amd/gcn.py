@@ -11,8 +11,8 @@ and transposes back.
 gcn_stack_forward(layers, x, adj): the chained layers of the refinement regressors (mesh_encoder.py:477-481) in the same
 operation order, with the aggregation of layer i and the contraction of layer i+1 in ONE launch (g4d_gcn_agg_linear_f32,
 csrc/gcn_fused.hip): the activation between two layers stays in LDS (window of neighbouring vertex rows staged once per 128-row
-tile instead of one L2 read per neighbour).  240 x 4096 rows, 128 -> 128: 488 us against 344 (SpMM) + 404 (contraction); the
-323 -> 128 -> 128 -> 128 -> 3 stack 3.24 -> 2.20 ms (scripts/time_gcn_stack.py).  (An earlier fused kernel aggregating in the
+tile instead of one L2 read per neighbour).  240 x 4096 rows, 128 -> 128: ~470 us against 344 (SpMM) + 404 (contraction); the
+323 -> 128 -> 128 -> 128 -> 3 stack 3.3 -> 2.12 ms (scripts/time_gcn_stack.py).  (An earlier fused kernel aggregating in the
 LOADER of the contraction, g4d_gcn_linear_f32, redoes the aggregation per 64-channel tile and was slower than two launches.)
 Inference only: no autograd graph is built.
 """
