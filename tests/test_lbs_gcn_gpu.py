@@ -176,6 +176,30 @@ def test_gcn_stack_fused_vs_layer_by_layer_and_oracle(rc, frames, numbering, mon
             assert err <= 1e-5 * scale
 
 
+def test_gcn_stack_fused_without_bias_and_with_long_rows():
+    """No bias (GraphConvolution(bias=False)) and a mesh with a high-valence vertex (a fan: one row longer than the 8 padded pairs
+    the LDS path holds -> that tile takes the global-memory route): fused stack == layer-by-layer stack."""
+    verts, faces = syn.quad_cylinder(12, 12)
+    Vg = verts.shape[0]
+    hub = np.array([[0, i, i + 1] for i in range(20, 60)], dtype=faces.dtype)       # vertex 0 connected to 41 others
+    faces = np.concatenate([faces[:, :3] if faces.shape[1] == 3 else np.concatenate([faces[:, [0, 1, 2]], faces[:, [0, 2, 3]]], 0), hub], 0)
+    adj = gcn_oracle.adjacency_from_faces(faces, Vg)
+    assert int(np.diff(adj.tocsr().indptr).max()) > 8
+    torch.manual_seed(3)
+    layers = [G.GraphConvolution(40, 128, bias=False).cuda(), G.GraphConvolution(128, 128, bias=False).cuda(), G.GraphConvolution(128, 3).cuda()]
+    x = torch.randn(2, Vg, 40, generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        got = G.gcn_stack_forward(layers, x, adj, keep=(0, 1))
+        prev = G.FUSE_STACK
+        G.FUSE_STACK = False
+        try:
+            ref = G.gcn_stack_forward(layers, x, adj, keep=(0, 1))
+        finally:
+            G.FUSE_STACK = prev
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])                 # kept activations: the SpMM's arithmetic
+    torch.testing.assert_close(got[2], ref[2], rtol=1e-5, atol=1e-5)
+
+
 def test_gcn_agg_linear_tap_is_bit_identical_to_spmm():
     """The aggregation inside g4d_gcn_agg_linear_f32 uses spmm_rows_kernel's arithmetic: the tapped activation must EQUAL it."""
     from garment4d_amd import _lib, fused
