@@ -96,6 +96,10 @@ def lib():
             raise G4DError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import "
                 f"__graft_entry__ as g; g.build()'` (or `make -C garment4d_amd/csrc`). There is no fallback path.")
+        # torch first: its wheel bundles a libamdhip64; loading ours before it would bring in /opt/rocm's copy as a SECOND HIP runtime
+        # in the process, and the library's launches would then run in a runtime that never saw torch's device / streams
+        # ("no ROCm-capable device is detected" from the first hipFuncSetAttribute)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
