@@ -194,6 +194,10 @@ __global__ void __launch_bounds__(256) transpose_kernel(int R, int Cc, const flo
 }
 
 static int launch_linear(int mode, const LinearArgs &a, hipStream_t s) {
+    if (mode == LOAD_DIRECT) {
+        int rc = G4D_OK;
+        if (gemm_stream_try(a, s, &rc)) return rc;   // tall, un-pooled, Cout a multiple of 128: the row-streaming GEMM
+    }
     const int nb = (a.Cout + BN - 1) / BN;
     // 32-row tiles when 64-row tiles would not even give two workgroups per CU (and no fused pooling is asked for)
     const bool small = a.pool == 0 && (long long)((a.rows + 63) / 64) * nb < 2 * 256;

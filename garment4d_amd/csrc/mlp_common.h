@@ -39,6 +39,9 @@ struct LinearArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// gemm_stream.hip: persistent row-streaming GEMM for tall DIRECT launches; returns false when the launch is not its kind
+bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc);
+
 template <int MODE>
 struct RowCtx {  // per-thread, per-row state reused across K chunks
     bool valid;
