@@ -97,7 +97,6 @@ __global__ void __launch_bounds__(GT, 2) gemm_stream_kernel(const LinearArgs a, 
                 if (!w_resident) load_w(nsc_i);
                 load_a(ntile, nsc_i);
             }
-#pragma unroll 2
             for (int kk = 0; kk < GK; kk += 16) {
                 const f32x4 bf = *reinterpret_cast<const f32x4 *>(&sW[(wave * 16 + fi) * GLD + kk + fq * 4]);
                 f32x4 af[8];
