@@ -71,6 +71,15 @@ inline int knn_shape(int mode) { return mode == 0 ? 0 : 2; }  // the accumulate 
         default: { constexpr int FM = 2; __VA_ARGS__; } break; \
     }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier: the compiler drains EVERY
+// outstanding memory operation in front of it (s_waitcnt vmcnt(0) lgkmcnt(0)), global loads and stores included.  In a kernel that
+// has global prefetches in flight across the barrier (operands of the next tile / slice) or has just issued its result stores, that
+// puts an HBM round trip on the critical path at every barrier.  Kernels whose waves exchange data through LDS only use this one:
+// the wave's own LDS operations are complete (lgkmcnt(0)) when it signals, global memory is left alone.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Raise a kernel's dynamic-LDS limit above the 64 KB default.  The attribute is PER DEVICE: `done` holds one bit per device
 // ordinal so that a process driving several GPUs sets it on each of them (idempotent, so a race between host threads is benign).
 inline int ensure_dynamic_lds(const void *kernel, int bytes, unsigned long long &done, const char *what) {

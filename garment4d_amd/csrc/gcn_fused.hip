@@ -150,7 +150,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
                 if (r < wrows) *reinterpret_cast<f32x4 *>(&win[r * kLdW + ac]) = pre[i];
             }
         }
-        __syncthreads();   // window (and, first time, the CSR entries) visible; the previous slice's MFMAs are done with `asl`
+        lds_barrier();   // window (and, first time, the CSR entries) visible; the previous slice's MFMAs are done with `asl`
         G4D_GSTAMP(1)   // prefetched rows arrived + stored + barrier
         // Issue ORDER matters: vector-memory loads retire in order (s_waitcnt vmcnt counts from the oldest), so whatever this slice
         // itself waits for -- the B fragments, the bias -- must be requested BEFORE the next slice's window rows; behind them, the
@@ -228,7 +228,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
             if (a.tap && r < nrows) *reinterpret_cast<f32x4 *>(a.tap + ((size_t)f * a.vg + r0 + r) * kC + c0 + ac) = y;
         }
         G4D_GSTAMP(3)   // aggregation loop + stores
-        __syncthreads();   // A slice visible; everybody is done reading `win`
+        lds_barrier();   // A slice visible; everybody is done reading `win`
         G4D_GSTAMP(4)   // barrier
         // 3. contract the slice with the next weight
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(cons
     const int nrows = min(kTile, a.vg - r0);
     // window of the tile: [lo, hi) over the column indices of its rows (a contiguous CSR range)
     if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; s_lohi[2] = 0; }
-    __syncthreads();
+    lds_barrier();
     const int e0 = a.rowptr[r0], e1 = a.rowptr[r0 + nrows];
     {
         int lo = 0x7fffffff, hi = -1;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(cons
         for (int o = 32; o > 0; o >>= 1) rl = max(rl, __shfl_xor(rl, o));
         if (lane == 0) atomicMax(&s_lohi[2], rl);
     }
-    __syncthreads();
+    lds_barrier();
     const int lo = s_lohi[0], hi = s_lohi[1] + 1;
     const int ell = s_lohi[2];
     if (ell <= kEll && hi - lo <= kWin && hi > lo)   // block-uniform

@@ -11,12 +11,14 @@
 //   * wave w owns all 128 rows x channels [16 w, 16 w + 16): 8 accumulator tiles, A fragments by ds_read_b128 (4 consecutive k per
 //     lane feeding 4 MFMAs, same k permutation on both operands -- the LDS-tiled kernel's order, so results are bit-identical to it);
 //   * 2 x 128 x 68 floats of LDS = 70 KB: two workgroups per CU.
-// Measured at 983k rows (scripts/time_gemm_stream.py): 128 -> 128 491 -> 389-439 us (73-83 TFLOP/s), 128 -> 384 1510 -> 1217-1300 us;
+// Measured at 983k rows (scripts/time_gemm_stream.py): 128 -> 128 491 -> 385-400 us (81-84 TFLOP/s), 128 -> 384 1510 -> 1210-1290 us;
 // with K = 195 / 323 (W re-streamed from L2 per tile and super-chunk, ragged tail) it LOSES to the register-chain kernel (842 / 1226 vs
 // 713 / 1093 us), so launch_linear takes this route only for Kpad <= 128.  What still separates it from the matrix pipe's 157: skipping
-// 3/4 of the MFMAs leaves 201 us (streaming 1 GB) and the MFMAs add their full 190 us on top -- the two do not overlap, because on gfx9
-// loads and stores share the in-order vmcnt counter and the wait for the prefetched operands at the top of a tile also waits for the
-// result stores issued just before it.
+// 3/4 of the MFMAs leaves 201 us -- the time to stream 1 GB at ~5 TB/s -- and the MFMAs add their 190 us on top.  Two things that
+// should have let them overlap and measured the same: (1) results leave through BUFFER stores with an out-of-range offset for idle
+// lanes, so the stores are unconditional, their count is static and the wait for the prefetched operands (loads and stores share
+// gfx9's in-order vmcnt) does not include them; (2) the barriers are LDS-only (lds_barrier(), g4d_common.h) -- __syncthreads() drains
+// every global load and store in flight.  Both are kept: they are the right shape, whatever else still serialises the two phases.
 #include <cstdlib>
 
 #include "mlp_common.h"
@@ -28,7 +30,8 @@ constexpr int GM = 128, GN = 128, GK = 64, GLD = GK + 4;
 constexpr int GT = 512;   // threads
 }  // namespace
 
-__global__ void __launch_bounds__(GT, 2) gemm_stream_kernel(const LinearArgs a, int ntiles) {
+template <bool BUF>
+__global__ void __launch_bounds__(GT, 2) gemm_stream_kernel(const LinearArgs a, int ntiles, unsigned out_bytes) {
     extern __shared__ __attribute__((aligned(16))) float gs_smem[];
     float *sA = gs_smem;
     float *sW = gs_smem + GM * GLD;
@@ -74,6 +77,7 @@ __global__ void __launch_bounds__(GT, 2) gemm_stream_kernel(const LinearArgs a, 
     const float sc_ = a.scale[ch], sh_ = a.shift[ch];
     const bool ch_ok = ch < a.Cout;
 
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)out_bytes, 0x00020000);
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     load_w(0);
@@ -84,11 +88,11 @@ __global__ void __launch_bounds__(GT, 2) gemm_stream_kernel(const LinearArgs a, 
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int sc = 0; sc < nsc; ++sc) {
-            __syncthreads();   // the previous super-chunk's MFMAs are done with sA / sW
+            lds_barrier();   // the previous super-chunk's MFMAs are done with sA / sW
             store_a();
             if (!w_in_lds) store_w();
             if (w_resident) w_in_lds = true;
-            __syncthreads();
+            lds_barrier();
             // the next super-chunk (or the next tile's first one): in flight during this super-chunk's MFMAs
             const bool last = sc + 1 == nsc;
             const int ntile = last ? tile + (int)gridDim.x : tile;
@@ -120,7 +124,14 @@ __global__ void __launch_bounds__(GT, 2) gemm_stream_kernel(const LinearArgs a, 
                 const int row = row0 + m * 16 + fq * 4 + r;
                 float y = __builtin_fmaf(acc[m][r], sc_, sh_);
                 if (a.relu) y = fmaxf(y, 0.f);
-                if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = y;
+                const bool ok = ch_ok && row < a.rows;
+                const size_t elem = (size_t)row * a.ldo + a.col0 + ch;
+                // BUFFER stores, out-of-range offset for the lanes with nothing to write: unconditional instructions, so the number of
+                // stores per tile is a compile-time constant and the wait for the next tile's operands (older than these stores;
+                // loads and stores share gfx9's in-order vmcnt) is vmcnt(32), not vmcnt(0) -- the write round trip of a tile's results
+                // no longer sits between its MFMAs and the next tile's
+                if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orsrc, ok ? (unsigned)(elem * 4) : 0x80000000u, 0, 0);
+                else if (ok) a.out[elem] = y;
             }
         tile += gridDim.x;
     }
@@ -134,7 +145,10 @@ bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc) {
     if (!enabled || a.pool != 0 || a.rows < min_rows || cpad % GN != 0 || a.Kpad > 128) return false;
     static unsigned long long attr = 0;
     const int lds = (GM + GN) * GLD * (int)sizeof(float);
-    *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_stream_kernel), lds, attr, "g4d_linear_f32(stream)");
+    static unsigned long long attr2 = 0;
+    *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_stream_kernel<true>), lds, attr, "g4d_linear_f32(stream)");
+    if (*rc) return true;
+    *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_stream_kernel<false>), lds, attr2, "g4d_linear_f32(stream)");
     if (*rc) return true;
     const int ntiles = (a.rows + GM - 1) / GM;
     int dev = 0, cus = 256;
@@ -142,7 +156,10 @@ bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc) {
     const int ncol = cpad / GN;
     int gx = 2 * cus / ncol > 0 ? 2 * cus / ncol : 1;   // two persistent workgroups per CU in total (70 KB of LDS each)
     if (gx > ntiles) gx = ntiles;
-    hipLaunchKernelGGL(gemm_stream_kernel, dim3((unsigned)gx, (unsigned)ncol), dim3(GT), lds, s, a, ntiles);
+    const unsigned long long ob = (unsigned long long)a.rows * a.ldo * sizeof(float);
+    static const int use_buf = [] { const char *e = getenv("G4D_GEMM_BUFFER_STORES"); return e ? atoi(e) : 1; }();
+    if (use_buf && ob < 0x7fffffffull) hipLaunchKernelGGL(gemm_stream_kernel<true>, dim3((unsigned)gx, (unsigned)ncol), dim3(GT), lds, s, a, ntiles, (unsigned)ob);
+    else hipLaunchKernelGGL(gemm_stream_kernel<false>, dim3((unsigned)gx, (unsigned)ncol), dim3(GT), lds, s, a, ntiles, 0u);
     *rc = check_launch("g4d_linear_f32(stream)");
     return true;
 }
