@@ -314,3 +314,35 @@ def test_chain_bf16x3_kernel_is_fp32_accurate(widths, S, pool, monkeypatch, requ
     print(f"[parity] chain {widths} S={S} pool={pool}: max_abs vs float64 -- fp32 MFMA {e32:.3g}, bf16x3 {ex3:.3g} (scale {scale:.3g})")
     assert ex3 <= 1e-5 * scale, (ex3, scale)
     assert ex3 <= max(4.0 * e32, 2e-6 * scale), (ex3, e32)     # no worse than the fp32 route beyond a small factor
+
+
+@pytest.mark.parametrize("rows,K,Cout,relu,col0,extra", [(65536, 128, 128, True, 0, 0), (70001, 128, 384, False, 0, 0), (65600, 96, 256, True, 5, 11),
+                                                         (131072, 70, 128, False, 0, 0)])
+def test_row_streaming_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra, monkeypatch):
+    """csrc/gemm_stream.hip (tall un-pooled contractions, K <= 128, Cout a multiple of 128: config 4's qkv projection) against the
+    LDS-tiled kernel it replaces there -- the same k order, so the results must be EQUAL -- and against float64: row counts that are
+    not a multiple of the 128-row tile, ragged K, an output window inside a wider matrix."""
+    g = torch.Generator().manual_seed(rows % 97)
+    x = torch.randn(rows, K, generator=g).cuda()
+    W = (torch.randn(Cout, K, generator=g) / K ** 0.5).cuda()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    L = fused.PackedLayer(W, sc, sh, relu=relu)
+    ldo = col0 + Cout + extra
+    outs = [torch.full((rows, ldo), 7.0, device="cuda") for _ in range(2)]
+
+    def run(stream_on, out):
+        monkeypatch.setattr(fused, "STREAM_GEMM", stream_on)
+        if stream_on:
+            fused.linear(x, L, out=out, col0=col0)
+        else:   # below the row threshold the library always takes the LDS-tiled kernel: run it in 32768-row slabs
+            for r0 in range(0, rows, 32768):
+                r1 = min(rows, r0 + 32768)
+                fused.linear(x[r0:r1], L, out=out[r0:r1], col0=col0)
+    run(False, outs[0])
+    run(True, outs[1])
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[1][:, :col0] == 7.0).all() and (outs[1][:, col0 + Cout:] == 7.0).all()
+    sel = torch.randint(0, rows, (2048,), generator=g).cuda()
+    ref = (x[sel].double() @ W.double().T) * sc.double() + sh.double()
+    ref = torch.relu(ref) if relu else ref
+    torch.testing.assert_close(outs[1][sel, col0:col0 + Cout].double(), ref, rtol=1e-5, atol=1e-5)
