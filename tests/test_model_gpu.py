@@ -291,3 +291,38 @@ def test_forward_clip_sharded_ranks_do_not_exchange():
     final = np.concatenate([ret[0]["final"], ret[1]["final"]], 0)
     np.testing.assert_allclose(coeff, ref["garment_PCA_coeff"].cpu().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(final, ref["iter_regressed_lbs_garment_v"][-1].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_whole_model_graph_replay_equals_eager_on_new_inputs():
+    """The whole temporal model captured as one hipGraph (scripts/time_model.py ... graph) and replayed on a clip the capture never saw:
+    every output equal to the eager forward, bit for bit -- no host-side decision inside forward() depends on the data."""
+    nbatch, T, N = 1, 3, 2048
+    scenes = [syn.garment_scene(nbatch, T, N, seed=s) for s in (31, 32)]
+    m = _model(scenes[0], "Tshirt", 64)
+    body = _body_model(scenes[0]["body"])
+    x_in = dev(scenes[0]["x"]).clone()
+    batch_in = {k: dev(v).clone() for k, v in scenes[0]["batch"].items()}
+    keys = ("sem_logits", "garment_PCA_coeff", "tpose_garment", "lbs_pred_garment_v")
+    stream = torch.cuda.Stream()
+    with torch.no_grad():
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                m(x_in, body, batch_in)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                out = m(x_in, body, batch_in)
+        for sc in (scenes[1], scenes[0]):
+            x_in.copy_(dev(sc["x"]))
+            for k, v in sc["batch"].items():
+                batch_in[k].copy_(dev(v))
+            graph.replay()
+            torch.cuda.synchronize()
+            got = {k: out[k].clone() for k in keys}
+            got_iter = [t.clone() for t in out["iter_regressed_lbs_garment_v"]]
+            want = m(dev(sc["x"]), body, {k: dev(v) for k, v in sc["batch"].items()})
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(got[k], want[k]), k
+            for r, (a, b) in enumerate(zip(got_iter, want["iter_regressed_lbs_garment_v"])):
+                assert torch.equal(a, b), f"refinement round {r}"
