@@ -113,14 +113,21 @@ def pack_conv_stack(stack):
             if isinstance(block, nn.Dropout):
                 continue
             conv = getattr(block, "conv", None)
-            assert conv is not None and conv.kernel_size in ((1,), (1, 1)), "fused path supports 1x1 conv blocks"
             names = [n for n, _ in block.named_children()]
-            assert names[0] == "conv", "fused path supports post-activation blocks (preact=False)"
-            assert "in" not in names, "instance norm is not supported on the fused path"
+            act = getattr(block, "activation", None)
+            # pytorch_utils.py:35-101 also builds pre-activation blocks, instance norm and arbitrary activations; the reference's models
+            # (pointnet2encoder.py, mesh_encoder.py) never do.  Those variants run on the op-by-op path (module.forward(): HIP grouping /
+            # sampling ops + torch layers), which supports everything the constructors accept -- say so instead of computing something else.
+            if conv is None or conv.kernel_size not in ((1,), (1, 1)):
+                raise NotImplementedError("fused path: 1x1 convolution blocks only; call the module's own forward() for this stack")
+            if names[0] != "conv":
+                raise NotImplementedError("fused path: post-activation blocks only (preact=False); call the module's own forward()")
+            if "in" in names:
+                raise NotImplementedError("fused path: instance norm needs per-sample statistics; call the module's own forward()")
+            if not (act is None or isinstance(act, nn.ReLU)):
+                raise NotImplementedError(f"fused path: ReLU or no activation only (got {type(act).__name__}); call the module's own forward()")
             bn = _unwrap_bn(block.bn) if "bn" in names else None
             scale, shift = _fold(conv, bn)
-            act = getattr(block, "activation", None)
-            assert act is None or isinstance(act, nn.ReLU), "fused path supports ReLU activations"
             w2 = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
             layers.append(PackedLayer(w2, scale, shift, relu=act is not None))
     stack._g4d_packed = (key, layers)

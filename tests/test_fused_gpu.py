@@ -346,3 +346,33 @@ def test_row_streaming_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, e
     ref = (x[sel].double() @ W.double().T) * sc.double() + sh.double()
     ref = torch.relu(ref) if relu else ref
     torch.testing.assert_close(outs[1][sel, col0:col0 + Cout].double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["instance_norm", "preact", "leaky_relu"])
+def test_shared_mlp_variants_run_op_by_op_and_are_refused_by_the_fused_path(variant):
+    """pytorch_utils.py:35-101 accepts instance norm, pre-activation blocks and arbitrary activations.  The fused kernels fold BN and
+    know ReLU only: they must REFUSE such a stack (NotImplementedError, never a silently different result), and the module's own
+    forward() -- HIP sampling / grouping ops + torch layers -- must still compute it: checked against the same torch layers applied on
+    the CPU to the oracle's grouped tensor."""
+    from garment4d_amd import pointnet2_modules as PM, pytorch_utils as pt
+    from oracle import modules_oracle as MO, pointnet2_oracle as K
+    torch.manual_seed(4)
+    xyz = syn.unit_cloud(2, 512, seed=8)
+    feats = np.random.default_rng(9).standard_normal((2, 5, 512)).astype(np.float32)
+    sa = PM.PointnetSAModule(npoint=64, radius=0.3, nsample=16, mlp=[5, 16, 32], use_xyz=True, bn=variant != "instance_norm",
+                             instance_norm=(variant == "instance_norm")).eval()   # the reference adds the instance norm only without BN (:51-52)
+    if variant == "preact":
+        sa.mlps[0] = pt.SharedMLP([8, 16, 32], bn=True, preact=True).eval()
+    elif variant == "leaky_relu":
+        sa.mlps[0] = pt.SharedMLP([8, 16, 32], bn=True, activation=torch.nn.LeakyReLU(0.1)).eval()
+    idx = K.fps(xyz, 64)
+    new_xyz = np.take_along_axis(xyz, idx[..., None].astype(np.int64), 1)
+    grouped = MO.query_and_group(0.3, 16, xyz, new_xyz, feats, use_xyz=True)            # (B, 3 + C, P, S)
+    with torch.no_grad():
+        want = sa.mlps[0](torch.from_numpy(grouped)).max(-1)[0]
+        sa = sa.cuda()
+        got_xyz, got = sa(dev(xyz), dev(feats))
+        assert np.array_equal(got_xyz.cpu().numpy(), new_xyz)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+        with pytest.raises(NotImplementedError):
+            fused.sa_forward(sa, dev(xyz), dev(feats).transpose(1, 2).contiguous())
