@@ -57,6 +57,24 @@ def test_cfg2_encoder_full_size_vs_oracle(kind, contraction_mode):
     check(f"cfg2/{kind} sem_logits", logits, want_logits)
 
 
+def test_encoder_at_the_real_config_size_6890_vs_oracle():
+    """cfgs/tshirt.yaml feeds N = 6890 points per frame, not BASELINE's 8192: the FPS tie-break block size becomes
+    4096 (two points per class for some classes, one for the others), the ball-query grid and every launch shape change."""
+    B, N = 2, 6890
+    xyz = syn.body_like_cloud(B, N, seed=33)
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=6).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    want_logits, want_f, want_xyz = MO.encoder_forward(xyz, sd)
+    model = model.cuda()
+    with torch.no_grad():
+        _, logits, l_f, l_xyz = model.forward_fused(dev(xyz), channel_major=True)
+    for lvl in range(1, 4):
+        assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl]), f"FPS-selected centroids of level {lvl}: not bit-exact"
+    for lvl in range(0, 4):
+        check(f"N=6890 l_features[{lvl}]", l_f[lvl], want_f[lvl])
+    check("N=6890 sem_logits", logits, want_logits)
+
+
 def test_cfg2_encoder_full_size_bf16x3_split_vs_fp32_oracle():
     """precision="bf16x3" (fp32-accurate contraction on the bf16 matrix cores: exact three-way operand splits, six piece products,
     fp32 accumulate) at BASELINE config 2's real size against the SAME fp32 oracle and the SAME elementwise rtol = atol = 1e-5 gate as
