@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
     float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * 16);   // SoA copy of the cloud
     float *sy = sx + n;
     float *sz = sy + n;
+    int *spick = reinterpret_cast<int *>(sz + n);                    // [m] the samples: written out once, after the loop
 
     const int t = threadIdx.x;
     const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
@@ -117,11 +118,10 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
         md[i] = ok ? (temp_all ? temp[k] : 1e10f) : -2.f;  // -2 never beats the scan's initial best (-1)
         if (ok) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
     }
-    if (t == 0) idx[0] = 0;
+    if (t == 0) spick[0] = 0;
     __syncthreads();
 
     float x1 = sx[0], y1 = sy[0], z1 = sz[0];
-    if (t == 0 && nx) { nx[0] = x1; nx[1] = y1; nx[2] = z1; }
     const int wave = t >> 6;
     for (int j = 1; j < m; ++j) {
         float best = -1.f;
@@ -157,10 +157,13 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
             old = (int)(((rank & 0xffffu) << log2bs) | c);
         }
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
-        if (t == 0) {
-            idx[j] = old;
-            if (nx) { nx[j * 3 + 0] = x1; nx[j * 3 + 1] = y1; nx[j * 3 + 2] = z1; }
-        }
+        if (t == 0) spick[j] = old;   // to LDS: a global store here would be drained (vmcnt(0)) by the next round's __syncthreads()
+    }
+    if constexpr (W > 1) __syncthreads();
+    for (int j = t; j < m; j += T) {
+        const int k = spick[j];
+        idx[j] = k;
+        if (nx) { nx[j * 3 + 0] = sx[k]; nx[j * 3 + 1] = sy[k]; nx[j * 3 + 2] = sz[k]; }
     }
     if (temp_all) {
 #pragma unroll
@@ -245,7 +248,7 @@ static int ref_block_size(int work_size) {
 
 template <int W, int U, int Q, int FM>
 static int launch_reg_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
-    const size_t lds = 2 * 16 * 16 + (size_t)n * 12;
+    const size_t lds = 2 * 16 * 16 + (size_t)n * 12 + (size_t)m * 4;
     auto kern = fps_reg_kernel<W, U, Q, FM>;
     static unsigned long long attr_done = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32")) return rc;
@@ -288,7 +291,7 @@ static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx
         const int rc = fps_bucket_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
         if (rc >= 0) return rc;
     }
-    const bool lds_ok = (size_t)n * 12 + 512 <= 150 * 1024;
+    const bool lds_ok = (size_t)n * 12 + (size_t)m * 4 + 512 <= 158 * 1024;   // SoA cloud + the pick list
 #define G4D_FPS_CASE(W, U, Q) return launch_reg<W, U, Q>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s)
     if (lds_ok && force != 0 && bs >= 64) {
         const int qp = q <= 1 ? 1 : q <= 2 ? 2 : q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : 0;

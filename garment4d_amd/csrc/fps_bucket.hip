@@ -99,7 +99,7 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
 template <int W, int P, int FM>
-__global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, const float *__restrict__ xyz_all,
+__global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
     constexpr int T = 64 * W, NPAD = T * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
     float *red = reinterpret_cast<float *>(smem_raw + 256);                                // [6][16] bbox partials
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem_raw + 1024);   // [NPAD] during the sort
     float *sx = reinterpret_cast<float *>(smem_raw + 1024);                                // SoA cloud afterwards
+    int *spick = reinterpret_cast<int *>(smem_raw + pick_off);                             // [m] the samples, written out once at the end
     float *sy = sx + n;
     float *sz = sy + n;
 
@@ -198,11 +199,10 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
         const float a3 = wave_max_f32(ok ? px[i] : -INF), a4 = wave_max_f32(ok ? py[i] : -INF), a5 = wave_max_f32(ok ? pz[i] : -INF);
         if (lane == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }
     }
-    if (t == 0) { idx[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
+    if (t == 0) { spick[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
     __syncthreads();
 
     float x1 = sx[0], y1 = sy[0], z1 = sz[0];
-    if (t == 0 && nx) { nx[0] = x1; nx[1] = y1; nx[2] = z1; }
     float gval = INF;          // global max of the min-distances (the last winner's value): nothing can exceed it
     float cval = -2.f;         // this wave's cached candidate (value, rank); refreshed only when one of its buckets was swept
     unsigned crank = 0xffffffffu;
@@ -277,14 +277,20 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
         const unsigned c = log2bs ? (__builtin_bitreverse32(rank >> 16) >> (32 - log2bs)) : 0u;
         const int old = (int)(((rank & 0xffffu) << log2bs) | c);
         x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
-        if (t == 0) {
-            idx[j] = old;
-            if (nx) { nx[j * 3 + 0] = x1; nx[j * 3 + 1] = y1; nx[j * 3 + 2] = z1; }
-        }
+        // The pick goes to LDS, not to global memory: __syncthreads() drains the wave's outstanding global stores (vmcnt(0)), so a
+        // store issued here would put its write round trip in front of wave 0's NEXT barrier arrival -- on the critical path of a
+        // round in which wave 0 has nothing else to do.  The list (and the gathered coordinates) is written once, after the loop.
+        if (t == 0) spick[j] = old;
 #ifdef G4D_FPS_DEBUG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         G4D_STAMP(3)
+    }
+    __syncthreads();
+    for (int j = t; j < m; j += T) {
+        const int k = spick[j];
+        idx[j] = k;
+        if (nx) { nx[j * 3 + 0] = sx[k]; nx[j * 3 + 1] = sy[k]; nx[j * 3 + 2] = sz[k]; }
     }
     if (temp) {
 #pragma unroll
@@ -303,14 +309,15 @@ template <int W, int P, int FM>
 static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
-    const size_t lds = 1024 + body;
+    const size_t pick_off = (1024 + body + 15) & ~(size_t)15;
+    const size_t lds = pick_off + (size_t)m * 4;
     auto kern = fps_bucket_kernel<W, P, FM>;
     static unsigned long long attr_done = 0;  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32(bucketed)")) return rc;
     // measured at N = 8192, M = 1024, B = 8 (scripts/time_fps.py): deal 1 / 2 / 4 / 8 -> 0.812 / 0.783 / 0.757 / 0.748 us per round
     static const int deal_env = getenv("G4D_FPS_DEAL") ? atoi(getenv("G4D_FPS_DEAL")) : 0;  // tuning hook: 1 | 2 | 4 | ... | P; 0 = P
     const int deal = (deal_env >= 1 && deal_env <= P && P % deal_env == 0) ? deal_env : P;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal, xyz, temp, idx, nx);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal, (int)pick_off, xyz, temp, idx, nx);
     return check_launch("g4d_fps_f32(bucketed)");
 }
 

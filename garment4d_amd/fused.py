@@ -440,7 +440,8 @@ def fps_gather(xyz, npoint, sidx=None, new_xyz=None):
         sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     if new_xyz is None:
         new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
-    temp = None if 64 <= N <= 12800 else torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)   # register-resident FPS: no scratch
+    reg = N >= 64 and N * 12 + npoint * 4 + 512 <= 158 * 1024 and N <= 12800   # register-resident FPS (cloud + pick list in LDS): no scratch
+    temp = None if reg else torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
     # the sampling kernel writes the selected coordinates as it goes (g4d_fps_gather_f32): no gather launch
     _lib.call("g4d_fps_gather_f32", B, N, npoint, xyz.data_ptr(), _ptr(temp), sidx.data_ptr(), new_xyz.data_ptr(), stream)
     return new_xyz
