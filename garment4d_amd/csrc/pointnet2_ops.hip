@@ -3,6 +3,8 @@
 // interpolate_gpu.cu:9-161}.  All HBM/L2-bound copies or scans: coalesced along the point axis, the index
 // row is read ONCE per thread and reused for a chunk of channels (the reference re-reads it per channel),
 // 64-bit offsets (the reference's int32 offsets wrap at 2^31 elements).
+#include <cstdlib>
+
 #include "g4d_common.h"
 
 namespace g4d {
@@ -137,6 +139,58 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
             d2[0] = b1; d2[1] = b2; d2[2] = b3;
             ix[0] = i1; ix[1] = i2; ix[2] = i3;
         }
+    }
+}
+
+// Variant for large unknown sets (n >= 4096: the last feature-propagation level): a wave owns 64 unknown points and scans ALL known
+// points in ascending index order (no slices, no merge -- the reference's own scan order, so plain strict `<` inserts), and every one of
+// the 4 candidates of a step has its OWN wave-uniform test.  Whether the ordered insert runs is decided per wave: with a running third
+// distance over K scanned points a candidate improves a lane with probability 3 / K, i.e. some lane of the wave with ~192 / K.  The
+// sliced kernel restarts K at every slice (256 points: an insert is needed at nearly every step, and all 4 candidates went through
+// it together: ~60 of the ~85 instructions per step); scanning the whole set lets K grow to m and the per-candidate tests skip
+// half of the inserts.
+template <int FM>
+__global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const float *__restrict__ unknown_all,
+                                                           const float *__restrict__ known_all, float *__restrict__ dist2_all,
+                                                           int *__restrict__ idx_all) {
+    __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const float *known = known_all + (size_t)b * m * 3;
+    const float *u = unknown_all + ((size_t)b * n + min(p, n - 1)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int base = 0; base < m; base += kNNChunk) {
+        const int cm = min(kNNChunk, m - base);
+        __syncthreads();
+        for (int j = threadIdx.x; j < kNNChunk; j += 256) {  // beyond the cloud: +inf coordinates, d = +inf, never inserted
+            const bool ok = j < cm;
+            const float *kp = known + (size_t)(base + (ok ? j : 0)) * 3;
+            const float inf = __builtin_inff();
+            skx[j] = ok ? kp[0] : inf; sky[j] = ok ? kp[1] : inf; skz[j] = ok ? kp[2] : inf;
+        }
+        __syncthreads();
+        const int jn = (cm + 3) & ~3;   // block-uniform trip count
+        for (int j = 0; j < jn; j += 4) {
+            const float4 kx = *reinterpret_cast<const float4 *>(&skx[j]), ky = *reinterpret_cast<const float4 *>(&sky[j]),
+                         kz = *reinterpret_cast<const float4 *>(&skz[j]);
+            const float d0 = dist2<FM>(ux - kx.x, uy - ky.x, uz - kz.x);   // interpolate_gpu.cu:33 under the contraction contract
+            const float d1 = dist2<FM>(ux - kx.y, uy - ky.y, uz - kz.y);
+            const float d2 = dist2<FM>(ux - kx.z, uy - ky.z, uz - kz.z);
+            const float d3 = dist2<FM>(ux - kx.w, uy - ky.w, uz - kz.w);
+            if (__builtin_amdgcn_ballot_w64(fminf(fminf(d0, d1), fminf(d2, d3)) < b3) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(d0 < b3) != 0ull) nn_insert(d0, base + j, b1, b2, b3, i1, i2, i3);
+            if (__builtin_amdgcn_ballot_w64(d1 < b3) != 0ull) nn_insert(d1, base + j + 1, b1, b2, b3, i1, i2, i3);
+            if (__builtin_amdgcn_ballot_w64(d2 < b3) != 0ull) nn_insert(d2, base + j + 2, b1, b2, b3, i1, i2, i3);
+            if (__builtin_amdgcn_ballot_w64(d3 < b3) != 0ull) nn_insert(d3, base + j + 3, b1, b2, b3, i1, i2, i3);
+        }
+    }
+    if (p < n) {
+        float *d2o = dist2_all + ((size_t)b * n + p) * 3;
+        int *ix = idx_all + ((size_t)b * n + p) * 3;
+        d2o[0] = b1; d2o[1] = b2; d2o[2] = b3;
+        ix[0] = i1; ix[1] = i2; ix[2] = i3;
     }
 }
 
@@ -334,6 +388,12 @@ extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const
     G4D_REQUIRE(b <= 65535, "g4d_three_nn_f32: b > 65535 not supported");
     if ((long long)b * n == 0) return G4D_OK;
     G4D_REQUIRE(unknown && dist2 && idx && (known || m == 0), "g4d_three_nn_f32: null pointer");
+    static const int wide_min_n = [] { const char *e = getenv("G4D_NN_WIDE_MIN_N"); return e ? atoi(e) : 4096; }();
+    if (n >= wide_min_n && m >= 256) {   // 64 queries per wave over the whole known set: see three_nn_wide_kernel
+        dim3 gridw((n + 255) / 256, b);
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx))
+        return check_launch("g4d_three_nn_f32");
+    }
     dim3 grid((n + 63) / 64, b);
     G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_kernel<FM>, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx))
     return check_launch("g4d_three_nn_f32");
