@@ -35,7 +35,7 @@ int distance_contraction() {
 }
 }  // namespace g4d
 
-extern "C" int g4d_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int g4d_version(void) { return 200; /* 0.2.0: round 2 (g4d_ball_query_boxes_f32 takes 16-point sub-block bounds; new entry points, see include/g4d.h) */ }
 extern "C" const char *g4d_last_error(void) { return g4d::g_err; }
 
 extern "C" int g4d_get_distance_contraction(void) { return g4d::distance_contraction(); }
