@@ -58,6 +58,8 @@ SIGNATURES = {
     "g4d_temporal_attention_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp],
     "g4d_interpenetration_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp],
     "g4d_mlp_chain_supported": [_I, _vp],
+    "g4d_sa_xyz_mlp3_supported": [_I, _I, _I, _I],
+    "g4d_sa_xyz_mlp3_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _I, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_mlp_chain_f32": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
                           _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,

@@ -1,0 +1,229 @@
+// Set-abstraction stack over xyz-only neighbourhoods: QueryAndGroup(use_xyz=True, features=None) -> SharedMLP [3, C1, C2, C3] -> pool
+// (/root/reference/modules/pointnet2/pointnet2/pointnet2_modules.py:40-53 with pointnet2_utils.py:242-265; the first level of
+// Pointnet2MSGSEG, pointnet2encoder.py:41-53: [3,16,16,32] over 16 samples and [3,32,32,64] over 32 samples of 1024 centres).
+//
+// The generic register-chain kernel (mlp_chain.hip) treats this like any stack: 32 rows per wave, every wave streams the weights from
+// L2 and pays a prologue / epilogue per 32 rows -- 4.7k cycles per wave around 0.8k cycles of MFMAs for the 16-wide stack.  These two
+// stacks are tiny (3.2k weights) and their rows are many (131k + 262k per 8 clouds), so here, like the positional encoders
+// (pos_encode.hip):
+//   * waves are persistent and autonomous (no LDS, no barrier); ALL weights, scales and shifts live in registers for the whole launch;
+//   * layer 1 (K = 3) runs on the VALU -- three FMAs per value instead of a K = 4-padded MFMA -- and is produced directly in the MFMA
+//     operand layout: lane (fi = l & 15, fq = l >> 4) holds channels {16 ks + 4 fq + e} of row fi of a 16-row tile;
+//   * layer 2 is evaluated TRANSPOSED (A = W2, B = h1): the accumulators come out as lane (row fi, channels 16 ct + 4 fq + r), i.e.
+//     already in the operand layout of the next layer -- affine + ReLU in place, no shuffle;
+//   * layer 3 in the normal orientation (A = h2, B = W3) gives lane (channel fi, rows 4 fq + r): the max / mean over the S rows of a
+//     neighbourhood is register maxima + two cross-lane steps, as in pos_encode.hip.
+// A pass = 32 rows (2 tiles): 96 MFMAs for [32, 32, 64].  Roofline: fp32 MFMA for the two contracted layers.
+#include <cstdlib>
+
+#include "g4d_common.h"
+
+namespace g4d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SaXyzArgs {
+    int n, p, S, logS, pool;          // pool: 1 max, 2 avg
+    long long rows;                   // b * p * S
+    const float *xyz, *new_xyz;
+    const int *idx;
+    const float *W1, *sc1, *sh1;      // W1 (C1, ldw1) row-major: columns 0..2 used
+    int ldw1;
+    const float *W2f, *sc2, *sh2;     // fragment order [tile][k-step of 16][lane = 16 fq + fi][4], kst2 / kst3 k-steps per tile (Kpad / 16)
+    const float *W3f, *sc3, *sh3;
+    int kst2, kst3;
+    float *out;
+    int ldo, col0;
+};
+
+struct __attribute__((packed, aligned(4))) F3s { float x, y, z; };
+__device__ __forceinline__ F3s ld3(const float *base, unsigned elem) {
+    return *reinterpret_cast<const F3s *>(reinterpret_cast<const char *>(base) + (elem << 2));
+}
+
+template <int C1, int C2, int C3>
+__global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
+    constexpr int T1 = C1 / 16, T2 = C2 / 16, T3 = C3 / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = lane & 15, fq = lane >> 4;
+    // ---- weights into registers, once per wave
+    float w1[T1][4][3], s1[T1][4], h1s[T1][4];
+#pragma unroll
+    for (int ks = 0; ks < T1; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = ks * 16 + fq * 4 + e;
+            w1[ks][e][0] = a.W1[c * a.ldw1 + 0]; w1[ks][e][1] = a.W1[c * a.ldw1 + 1]; w1[ks][e][2] = a.W1[c * a.ldw1 + 2];
+            s1[ks][e] = a.sc1[c]; h1s[ks][e] = a.sh1[c];
+        }
+    f32x4 w2[T2][T1], w3[T3][T2];
+#pragma unroll
+    for (int ct = 0; ct < T2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < T1; ++ks) w2[ct][ks] = *reinterpret_cast<const f32x4 *>(a.W2f + ((size_t)(ct * a.kst2 + ks) * 64 + lane) * 4);
+#pragma unroll
+    for (int ct = 0; ct < T3; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < T2; ++ks) w3[ct][ks] = *reinterpret_cast<const f32x4 *>(a.W3f + ((size_t)(ct * a.kst3 + ks) * 64 + lane) * 4);
+    f32x4 s2[T2], h2s[T2];   // channels 16 ct + 4 fq + r
+#pragma unroll
+    for (int ct = 0; ct < T2; ++ct) {
+        s2[ct] = *reinterpret_cast<const f32x4 *>(a.sc2 + ct * 16 + fq * 4);
+        h2s[ct] = *reinterpret_cast<const f32x4 *>(a.sh2 + ct * 16 + fq * 4);
+    }
+    float s3[T3], h3s[T3];   // channel 16 ct + fi
+#pragma unroll
+    for (int ct = 0; ct < T3; ++ct) { s3[ct] = a.sc3[ct * 16 + fi]; h3s[ct] = a.sh3[ct * 16 + fi]; }
+
+    const int rows = (int)a.rows;            // < 2^31 (launcher)
+    const int npass = (rows + 31) >> 5;      // 32 rows per pass; S >= 16 divides 32 or is a multiple of it
+    const bool is_max = a.pool == 1;
+    const float inv = is_max ? 1.f : 1.f / (float)a.S;
+    // Two-level software pipeline over the wave's passes (the gather is two dependent loads: index -> coordinates): while pass k is on
+    // the VALU / MFMA, the coordinates of pass k + 1 are in flight and so are the indices of pass k + 2.
+    struct Rows { F3s px[2], pq[2]; };
+    int ivn[2];
+    Rows cur, nxt;
+    auto load_idx = [&](int pass, int (&v)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) v[mt] = pass < npass ? a.idx[min(pass * 32 + mt * 16 + fi, rows - 1)] : 0;
+    };
+    const int nq = (int)(a.rows >> a.logS);
+    auto load_rows = [&](int pass, const int (&v)[2], Rows &rw) {
+        if (pass >= npass) return;   // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int qi = __builtin_amdgcn_readfirstlane(min((pass * 32 + mt * 16) >> a.logS, nq - 1));   // S >= 16: a tile belongs to one query
+            const int f = qi / a.p;
+            rw.px[mt] = ld3(a.xyz, (unsigned)(f * a.n + v[mt]) * 3u);
+            rw.pq[mt] = ld3(a.new_xyz, (unsigned)qi * 3u);
+        }
+    };
+    const int stride = gridDim.x * 4;
+    int pass = blockIdx.x * 4 + wave;
+    load_idx(pass, ivn);
+    load_rows(pass, ivn, cur);
+    load_idx(pass + stride, ivn);
+    for (; pass < npass; pass += stride) {
+        load_rows(pass + stride, ivn, nxt);       // level 2 of the next pass
+        load_idx(pass + 2 * stride, ivn);         // level 1 of the one after
+        const int row0 = pass * 32;
+        // ---- layer 1 on the VALU, in operand layout
+        f32x4 h1[2][T1];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float i0 = cur.px[mt].x - cur.pq[mt].x, i1 = cur.px[mt].y - cur.pq[mt].y, i2 = cur.px[mt].z - cur.pq[mt].z;   // pointnet2_utils.py:254
+#pragma unroll
+            for (int ks = 0; ks < T1; ++ks)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float acc = __builtin_fmaf(w1[ks][e][2], i2, __builtin_fmaf(w1[ks][e][1], i1, w1[ks][e][0] * i0));
+                    h1[mt][ks][e] = fmaxf(__builtin_fmaf(acc, s1[ks][e], h1s[ks][e]), 0.f);
+                }
+        }
+        cur = nxt;
+        // ---- layer 2, transposed: D[out channel 4 fq + r][row fi]
+        f32x4 h2[2][T2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < T2; ++ct) h2[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < T1; ++ks)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int ct = 0; ct < T2; ++ct)
+                        h2[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[ct][ks][e], h1[mt][ks][e], h2[mt][ct], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < T2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[mt][ct][r] = fmaxf(__builtin_fmaf(h2[mt][ct][r], s2[ct][r], h2s[ct][r]), 0.f);
+        // ---- layer 3, normal orientation: D[row 4 fq + r][channel fi]
+        f32x4 acc[2][T3];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < T3; ++ct) acc[mt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < T2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int ct = 0; ct < T3; ++ct)
+                        acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mt][ks][e], w3[ct][ks][e], acc[mt][ct], 0, 0, 0);
+        // ---- affine + ReLU + pool over the S rows of each neighbourhood
+#pragma unroll
+        for (int ct = 0; ct < T3; ++ct) {
+            float v[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(__builtin_fmaf(acc[mt][ct][r], s3[ct], h3s[ct]), 0.f);
+                float x = is_max ? fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])) : ((y[0] + y[1]) + (y[2] + y[3]));
+                const float x16 = __shfl_xor(x, 16);
+                x = is_max ? fmaxf(x, x16) : x + x16;
+                const float x32 = __shfl_xor(x, 32);
+                x = is_max ? fmaxf(x, x32) : x + x32;
+                v[mt] = x;      // the 16 rows of tile mt, in every lane
+            }
+            const int ch = ct * 16 + fi;
+            if (a.S == 16) {
+                if (lane < 16) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int first_row = row0 + mt * 16;
+                        if (first_row < rows) a.out[(size_t)(first_row >> 4) * a.ldo + a.col0 + ch] = v[mt] * inv;
+                    }
+                }
+            } else {   // S == 32: the two tiles of the pass are one neighbourhood
+                const float x = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];
+                if (lane < 16 && row0 < rows) a.out[(size_t)(row0 >> 5) * a.ldo + a.col0 + ch] = x * inv;
+            }
+        }
+    }
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+
+extern "C" int g4d_sa_xyz_mlp3_supported(int c1, int c2, int c3, int nsample) {
+    return ((c1 == 16 && c2 == 16 && c3 == 32) || (c1 == 32 && c2 == 32 && c3 == 64)) && (nsample == 16 || nsample == 32);
+}
+
+extern "C" int g4d_sa_xyz_mlp3_f32(int b, int n, int p, int nsample, const float *xyz, const float *new_xyz, const int *idx, int c1, int c2,
+                                   int c3, const float *W1, int ldw1, const float *scale1, const float *shift1, const float *W2_frag, int kpad2,
+                                   const float *scale2, const float *shift2, const float *W3_frag, int kpad3, const float *scale3, const float *shift3,
+                                   int pool, float *out, int ldo, int col0, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && n > 0 && p >= 0, "g4d_sa_xyz_mlp3_f32: bad sizes");
+    G4D_REQUIRE(g4d_sa_xyz_mlp3_supported(c1, c2, c3, nsample), "g4d_sa_xyz_mlp3_f32: widths %d-%d-%d over %d samples are not instantiated", c1, c2,
+                c3, nsample);
+    G4D_REQUIRE(pool == 1 || pool == 2, "g4d_sa_xyz_mlp3_f32: pool must be 1 (max) or 2 (avg)");
+    const long long rows = (long long)b * p * nsample;
+    if (rows == 0) return G4D_OK;
+    G4D_REQUIRE(xyz && new_xyz && idx && W1 && scale1 && shift1 && W2_frag && scale2 && shift2 && W3_frag && scale3 && shift3 && out && ldw1 >= 3,
+                "g4d_sa_xyz_mlp3_f32: null pointer");
+    G4D_REQUIRE(ldo >= col0 + c3 && col0 >= 0, "g4d_sa_xyz_mlp3_f32: output window out of range");
+    G4D_REQUIRE(rows < (1ll << 31) - 64 && (long long)b * n * 12 < (1ll << 32), "g4d_sa_xyz_mlp3_f32: needs rows < 2^31 and b*n*12 B < 4 GB");
+    SaXyzArgs a;
+    a.n = n; a.p = p; a.S = nsample; a.logS = nsample == 16 ? 4 : 5; a.pool = pool; a.rows = rows;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.W1 = W1; a.sc1 = scale1; a.sh1 = shift1; a.ldw1 = ldw1;
+    G4D_REQUIRE(kpad2 % 16 == 0 && kpad2 >= c1 && kpad3 % 16 == 0 && kpad3 >= c2, "g4d_sa_xyz_mlp3_f32: Kpad of layers 2 / 3 must be multiples of 16 covering c1 / c2");
+    a.W2f = W2_frag; a.sc2 = scale2; a.sh2 = shift2; a.W3f = W3_frag; a.sc3 = scale3; a.sh3 = shift3; a.kst2 = kpad2 / 16; a.kst3 = kpad3 / 16;
+    a.out = out; a.ldo = ldo; a.col0 = col0;
+    const long long npass = (rows + 31) / 32, want = (npass + 3) / 4;
+    static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+    const unsigned grid = (unsigned)(want < 256 * bpc ? want : 256 * bpc);   // persistent waves (2 per SIMD): the weights are loaded once per wave
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (c1 == 16) hipLaunchKernelGGL((sa_xyz_kernel<16, 16, 32>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sa_xyz_kernel<32, 32, 64>), dim3(grid), dim3(256), 0, st, a);
+    return check_launch("g4d_sa_xyz_mlp3_f32");
+}

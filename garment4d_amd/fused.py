@@ -486,6 +486,9 @@ def sampling_chain(xyz, npoints):
     return out
 
 
+USE_SA_XYZ = os.environ.get("G4D_SA_XYZ", "1") != "0"   # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
+
+
 def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
     """Fused PointnetSAModule(MSG).forward (pointnet2_modules.py:19-55), eval mode.
     xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major).
@@ -515,7 +518,15 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
                           _ptr(feats_pm), idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                           L.shift.data_ptr(), L.relu, pl, o.data_ptr(), o.shape[-1], c0, stream)
 
-            if USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
+            if (USE_SA_XYZ and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers)
+                    and B * N * 12 < 2 ** 32 and _lib.lib().g4d_sa_xyz_mlp3_supported(layers[0].Cout, layers[1].Cout, layers[2].Cout, S)):
+                # xyz-only 3-layer stack (the first level of the encoder): persistent waves, weights in registers, layer 1 on the VALU
+                L1, L2, L3 = layers
+                _lib.call("g4d_sa_xyz_mlp3_f32", B, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), L1.Cout, L2.Cout, L3.Cout,
+                          L1.W.data_ptr(), L1.Kpad, L1.scale.data_ptr(), L1.shift.data_ptr(), L2.Wf.data_ptr(), L2.Kpad, L2.scale.data_ptr(),
+                          L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), pool, out.data_ptr(),
+                          out.shape[-1], col0, stream)
+            elif USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
                 mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
                           group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))
             else:

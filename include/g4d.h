@@ -227,6 +227,17 @@ int g4d_mlp_wave_f32(int mode, long long rows, int K0, const float *X, int ldx, 
  * g4d_mlp_chain_supported() accepts (16-16-32, 32-32-64, 64-64-128, 128-128-256, 32-32, 64-64, 128-128, 128-64, single layers
  * up to 128, 128-64-32-16).  Same arguments as g4d_mlp_stack_f32 without the CSR loader (W in fragment order); pool over S
  * in {4,8,16,32,64}; tap_out (or NULL): hidden layer tap_layer is also written to HBM. */
+/* Set-abstraction stack over xyz-only neighbourhoods (QueryAndGroup(use_xyz=True, features=None) -> SharedMLP [3, c1, c2, c3] -> max / avg
+ * over the nsample rows; pointnet2_modules.py:40-53, the first level of Pointnet2MSGSEG): persistent waves, all weights in registers,
+ * layer 1 on the VALU.  (c1, c2, c3) in {(16,16,32), (32,32,64)}, nsample in {16, 32} (g4d_sa_xyz_mlp3_supported).  W1: (c1, ldw1) row-major,
+ * columns 0..2; W2_frag / W3_frag: fragment order [16-channel tile][kpad/16 k-steps][lane][4] (the Wf of the LDS-resident kernels);
+ * scale / shift: folded BatchNorm per channel, ReLU after every layer.  out (b*p, ldo) point-major at column col0. */
+int g4d_sa_xyz_mlp3_supported(int c1, int c2, int c3, int nsample);
+int g4d_sa_xyz_mlp3_f32(int b, int n, int p, int nsample, const float *xyz, const float *new_xyz, const int *idx, int c1, int c2, int c3,
+                        const float *W1, int ldw1, const float *scale1, const float *shift1, const float *W2_frag, int kpad2,
+                        const float *scale2, const float *shift2, const float *W3_frag, int kpad3, const float *scale3, const float *shift3,
+                        int pool, float *out, int ldo, int col0, g4d_stream_t stream);
+
 int g4d_mlp_chain_supported(int nlayers, const int *Cout);
 int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
                       const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,

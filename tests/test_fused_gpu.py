@@ -376,3 +376,36 @@ def test_shared_mlp_variants_run_op_by_op_and_are_refused_by_the_fused_path(vari
         torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
         with pytest.raises(NotImplementedError):
             fused.sa_forward(sa, dev(xyz), dev(feats).transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize("pool", ["max_pool", "avg_pool"])
+@pytest.mark.parametrize("B,N,P", [(1, 700, 33), (3, 2500, 257), (2, 6890, 512)])
+def test_sa_xyz_kernel_equals_chain_kernels_and_module(B, N, P, pool, monkeypatch):
+    """csrc/sa_xyz.hip (xyz-only 3-layer SA stacks: weights in registers, layer 1 on the VALU, transposed middle layer) against the
+    register-chain kernels on the same module, and against the op-by-op module: both supported stacks (16-16-32 at 16 samples,
+    32-32-64 at 32), both pooling modes, row counts that are not a multiple of the 128-row workgroup pass, several frames."""
+    torch.manual_seed(B * 1000 + P)
+    xyz = dev(syn.unit_cloud(B, N, seed=P))
+    sa = PM.PointnetSAModuleMSG(npoint=P, radii=[0.1, 0.2], nsamples=[16, 32], mlps=[[0, 16, 16, 32], [0, 32, 32, 64]], pool_method=pool).cuda()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    sa.eval()
+    lib = fused._lib.lib()
+    assert lib.g4d_sa_xyz_mlp3_supported(16, 16, 32, 16) and lib.g4d_sa_xyz_mlp3_supported(32, 32, 64, 32)
+    assert not lib.g4d_sa_xyz_mlp3_supported(64, 64, 128, 32) and not lib.g4d_sa_xyz_mlp3_supported(16, 16, 32, 8)
+    outs = {}
+    with torch.no_grad():
+        nx, want = sa(xyz, None)
+        for on in (True, False):
+            monkeypatch.setattr(fused, "USE_SA_XYZ", on)
+            nx2, outs[on] = fused.sa_forward(sa, xyz, None)
+            assert torch.equal(nx, nx2)
+    scale = max(float(want.abs().max()), 1.0)
+    assert float((outs[True] - outs[False]).abs().max()) <= 2e-6 * scale
+    close(fused.to_channel_major(outs[True]), want.cpu().numpy())
+    if N <= 700:   # the CPU oracle on the smallest case
+        from oracle import modules_oracle as MO
+        sd = {k: v.cpu().numpy() for k, v in sa.state_dict().items()}
+        _, f = MO.sa_module(xyz.cpu().numpy(), None, P, [0.1, 0.2], [16, 32], sd, pool=pool)
+        close(fused.to_channel_major(outs[True]), f)
