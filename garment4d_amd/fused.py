@@ -489,6 +489,34 @@ def sampling_chain(xyz, npoints):
 USE_SA_XYZ = os.environ.get("G4D_SA_XYZ", "1") != "0"   # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
 
 
+def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0):
+    """One scale of an SA level: gather idx (B,P,S) around new_xyz, the shared-MLP stack `layers`, pooling over S, into out[..., col0:].
+    Picks the kernel family (sa_xyz.hip / register chain / LDS stack / per layer)."""
+    B, N, _ = xyz.shape
+    P, S = idx.shape[1], idx.shape[2]
+    C = 0 if feats_pm is None else feats_pm.shape[2]
+    stream = _lib.stream_ptr()
+
+    def first(L, pl, o, c0):
+        _lib.call("g4d_group_linear_f32", B, N, P, S, C, use_xyz, xyz.data_ptr(), new_xyz.data_ptr(),
+                  _ptr(feats_pm), idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
+                  L.shift.data_ptr(), L.relu, pl, o.data_ptr(), o.shape[-1], c0, stream)
+
+    if (USE_SA_XYZ and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers)
+            and B * N * 12 < 2 ** 32 and _lib.lib().g4d_sa_xyz_mlp3_supported(layers[0].Cout, layers[1].Cout, layers[2].Cout, S)):
+        # xyz-only 3-layer stack (the first level of the encoder): persistent waves, weights in registers, layer 1 on the VALU
+        L1, L2, L3 = layers
+        _lib.call("g4d_sa_xyz_mlp3_f32", B, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), L1.Cout, L2.Cout, L3.Cout,
+                  L1.W.data_ptr(), L1.Kpad, L1.scale.data_ptr(), L1.shift.data_ptr(), L2.Wf.data_ptr(), L2.Kpad, L2.scale.data_ptr(),
+                  L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), pool, out.data_ptr(),
+                  out.shape[-1], col0, stream)
+    elif USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
+        mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
+                  group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))
+    else:
+        _run_stack(first, layers, B * P * S, S, pool, out, col0, xyz.device)
+
+
 def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
     """Fused PointnetSAModule(MSG).forward (pointnet2_modules.py:19-55), eval mode.
     xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major).
@@ -513,24 +541,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
             use_xyz = int(grouper.use_xyz)
             assert use_xyz or feats_pm is not None
 
-            def first(L, pl, o, c0, idx=idx, S=S, use_xyz=use_xyz):
-                _lib.call("g4d_group_linear_f32", B, N, P, S, C, use_xyz, xyz.data_ptr(), new_xyz.data_ptr(),
-                          _ptr(feats_pm), idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
-                          L.shift.data_ptr(), L.relu, pl, o.data_ptr(), o.shape[-1], c0, stream)
-
-            if (USE_SA_XYZ and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers)
-                    and B * N * 12 < 2 ** 32 and _lib.lib().g4d_sa_xyz_mlp3_supported(layers[0].Cout, layers[1].Cout, layers[2].Cout, S)):
-                # xyz-only 3-layer stack (the first level of the encoder): persistent waves, weights in registers, layer 1 on the VALU
-                L1, L2, L3 = layers
-                _lib.call("g4d_sa_xyz_mlp3_f32", B, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), L1.Cout, L2.Cout, L3.Cout,
-                          L1.W.data_ptr(), L1.Kpad, L1.scale.data_ptr(), L1.shift.data_ptr(), L2.Wf.data_ptr(), L2.Kpad, L2.scale.data_ptr(),
-                          L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), pool, out.data_ptr(),
-                          out.shape[-1], col0, stream)
-            elif USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
-                mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
-                          group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))
-            else:
-                _run_stack(first, layers, B * P * S, S, pool, out, col0, xyz.device)
+            sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0)
             col0 += layers[-1].Cout
         return new_xyz, out
     # GroupAll (pointnet2_utils.py:268-291): one group of all N points, raw coordinates

@@ -68,9 +68,8 @@ with torch.no_grad():
             rows = B * P * S
             fl = 2.0 * rows * sum(L.K * L.Cout for L in layers)
             items.append((f"SA{li+1} s{si} MLP {[L.Cout for L in layers]} rows {rows} [{fl/1e9:.2f} GF]",
-                          lambda rows=rows, C=C, layers=layers, out=out, col0=col0, S=S, n=n, P=P, x=x, nx=nx, f=f, idx=idx:
-                          fused.mlp_stack(1, rows, 3 + C, layers, out, col0=col0, pool=1, S=S, group=(n, P, C, 1, x, nx, f, idx)), fl))
-            fused.mlp_stack(1, rows, 3 + C, layers, out, col0=col0, pool=1, S=S, group=(n, P, C, 1, x, nx, f, idx))
+                          lambda layers=layers, out=out, col0=col0, x=x, nx=nx, f=f, idx=idx: fused.sa_scale_mlp(x, nx, f, idx, layers, 1, 1, out, col0), fl))
+            fused.sa_scale_mlp(x, nx, f, idx, layers, 1, 1, out, col0)
             col0 += layers[-1].Cout
         l_xyz.append(nx); l_f.append(out)
     feats = list(l_f)
