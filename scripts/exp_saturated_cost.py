@@ -38,11 +38,43 @@ def measure(fn):
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
             return best / (ns * REP) * 1e6
-        return run(1), run(NS)
+        if not KFPS:
+            return run(1), run(NS)
+        # third regime: the 16 copies next to KFPS level-1 FPS launches (8 clouds = 8 CUs each) that run for the whole measurement
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(KFPS):
+                with torch.cuda.stream(fps_streams[k]):
+                    fps_graphs[k].replay()
+            ends = []
+            for s in range(NS):
+                with torch.cuda.stream(streams[s]):
+                    graphs[s].replay()
+                    e = torch.cuda.Event(); e.record(); ends.append(e)
+            for e in ends:
+                e.synchronize()
+            best = min(best, time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        return run(1), run(NS), best / (NS * REP) * 1e6
 
 
 items = []
 xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=1)).to(dev)
+KFPS = int(os.environ.get("WITH_FPS", "0"))
+fps_streams = [torch.cuda.Stream(device=dev) for _ in range(KFPS)]
+fps_graphs = []
+with torch.no_grad():
+    for k in range(KFPS):
+        with torch.cuda.stream(fps_streams[k]):
+            fused.fps_gather(xyz, 1024)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=fps_streams[k]):
+            for _ in range(int(os.environ.get("FPS_REP", "14"))):
+                fused.fps_gather(xyz, 1024)
+        fps_graphs.append(g)
 with torch.no_grad():
     l_xyz, l_f = [xyz], [None]
     for li, sa in enumerate(model.SA_modules):
@@ -94,10 +126,13 @@ with torch.no_grad():
 tot_i = tot_s = 0.0
 for it in items:
     name, fn = it[0], it[1]
-    iso, sat = measure(fn)
+    res = measure(fn)
+    iso, sat = res[0], res[1]
     extra = f"  {it[2]/iso/1e6:5.1f} -> {it[2]/sat/1e6:5.1f} TF" if len(it) > 2 else ""
     if "three_nn +" in name:
         pass
+    if KFPS:
+        extra += f" | beside {KFPS} FPS launches {res[2]:7.1f} us (x{res[2]/sat:.2f})"
     print(f"{name:75s} isolated {iso:7.1f} us | saturated {sat:7.1f} us{extra}", flush=True)
     if "three_nn " not in name or "+ MLP" in name:
         tot_i += iso; tot_s += sat
