@@ -124,6 +124,8 @@ __device__ long long g_chain_dbg[8 * 4096];  // per wave (first 4096): 8 clock s
 //   * whether a k-step can use the 16-byte vector path is decided once per step for the whole wave (all 16 columns inside
 //     one source segment), not per lane: the k loop has ONE wave-uniform branch, the common body is base pointer + offset;
 //   * weights and inputs of step ks + 1 are requested before the MFMAs of step ks.
+//     (Requesting 2-4 steps ahead instead -- the widest stack runs one wave per SIMD -- costs 20-70 registers per instantiation and
+//     measured slower everywhere: 128-128-256 stack 49.2 -> 50.4 us alone, the 16-batch bench 27.3k -> 25.7k frames/s; round 2.)
 template <int MODE, int TOUT, int MT, bool LAST>
 __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLayer &L, int lane, int row0, f32x4 (&acc)[TOUT][MT]) {
     const int fi = lane & 15, fq = lane >> 4;
