@@ -116,9 +116,15 @@ def lib():
     return _lib
 
 
+_TRACE = os.environ.get("G4D_TRACE_CALLS", "0") != "0"   # debugging: every C-ABI call with its integer / float arguments on stderr
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point; non-zero status -> G4DError (the reference would exit(-1))."""
     L = lib()
+    if _TRACE:
+        import sys
+        print("g4d call", name, *[a for a in args if isinstance(a, (int, float)) and abs(a) < (1 << 31)], file=sys.stderr)
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise G4DError(f"{name} failed with status {rc}: {L.g4d_last_error().decode(errors='replace')}")
