@@ -258,6 +258,192 @@ __global__ void __launch_bounds__(256) lbs_skin_kernel(int V, int J, const float
     o[2] = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
 }
 
+
+// ---- lbs() in ONE launch ------------------------------------------------------------------------------------------------------
+// Workgroup = 64 vertices x up to 8 frames, 8 waves.  Wave w (1) requests its slice of the blend matrix rows for the tile -- every
+// row of [shapedirs^T ; posedirs] the tile needs is in flight at once, 12 bytes per lane and row -- then, while those loads fly,
+// (2) does frame w's per-frame work: Rodrigues, the joints from betas, the blend coefficients [betas | R - I] and the 23-step
+// kinematic chain, all wave-local in LDS (every workgroup repeats this per-frame work: ~3k cycles against a launch of its own);
+// (3) multiplies its slice into 8 frames x 3 coordinates of partial sums; (4) the slices meet in LDS and wave w skins frame w.
+// Against the three-launch route (rigid -> blend -> skin: 10 + 15 + 5 us alone) there is no v_posed / coefficient round trip and
+// the 17.9 MB of blend rows are requested up front instead of 4 dependent loads per lane at a time.
+namespace {
+constexpr int kOneKS = 8;     // k-slices = waves per workgroup
+constexpr int kOneRows = 28;  // blend rows per slice held in registers (8 x 28 = 224 >= 10 + 207)
+constexpr int kOneJ = 32;     // joints
+typedef float lbs_f4 __attribute__((ext_vector_type(4)));
+}  // namespace
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(64 * kOneKS) lbs_one_kernel(int B, int V, int J, int NB, int pose2rot, const float *__restrict__ betas,
+                                                              int betas_bstride, const float *__restrict__ pose,
+                                                              const float *__restrict__ v_template, const float *__restrict__ blend_dirs,
+                                                              const float *__restrict__ Jt, const float *__restrict__ Js,
+                                                              const int *__restrict__ parents, const float *__restrict__ weights,
+                                                              float *__restrict__ A_out, float *__restrict__ posed_joints,
+                                                              float *__restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) float one_smem[];
+    float *sC = one_smem;                                  // [kOneKS * kOneRows][kFB]  blend coefficients, zero beyond NC / nf
+    float *sR = sC + kOneKS * kOneRows * kFB;              // [kFB][kOneJ][9]
+    float *sJ = sR + kFB * kOneJ * 9;                      // [kFB][kOneJ][3]
+    float *sL = sJ + kFB * kOneJ * 3;                      // [kFB][kOneJ][12]   local transforms, later A (3x4)
+    float *sG = sL + kFB * kOneJ * 12;                     // [kFB][kOneJ][12]
+    float *sRed = sG + kFB * kOneJ * 12;                   // [kOneKS][kFB * 3][64]
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b0 = blockIdx.y * kFB, nf = min(kFB, B - b0);
+    const int NC = NB + (J - 1) * 9;
+    const size_t E = (size_t)V * 3;
+    const int v = blockIdx.x * 64 + l;
+    const int vc = min(v, V - 1);                          // lanes past the end read the last vertex and never write
+
+    // (1) this wave's blend rows: all requested now
+    float d[kOneRows][3];
+    const int k0 = w * kOneRows;
+#pragma unroll
+    for (int r = 0; r < kOneRows; ++r) {
+        const float *src = blend_dirs + (size_t)min(k0 + r, NC - 1) * E + (size_t)vc * 3;   // rows >= NC: coefficient 0
+        d[r][0] = src[0]; d[r][1] = src[1]; d[r][2] = src[2];
+    }
+    float wt[kOneJ];
+    {
+        const float *wp = weights + (size_t)vc * J;
+        if ((J & 3) == 0) {   // a lane's weight row is 16-byte aligned
+#pragma unroll
+            for (int j4 = 0; j4 < kOneJ / 4; ++j4) {
+                const lbs_f4 q = j4 * 4 < J ? *reinterpret_cast<const lbs_f4 *>(wp + j4 * 4) : (lbs_f4){0.f, 0.f, 0.f, 0.f};
+                wt[j4 * 4 + 0] = q.x; wt[j4 * 4 + 1] = q.y; wt[j4 * 4 + 2] = q.z; wt[j4 * 4 + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kOneJ; ++j) wt[j] = j < J ? wp[j] : 0.f;
+        }
+    }
+    const float t0 = v_template[(size_t)vc * 3 + 0], t1 = v_template[(size_t)vc * 3 + 1], t2 = v_template[(size_t)vc * 3 + 2];
+
+    // (2) frame w: rotations, joints, coefficients, chain (wave-local)
+    const int f = w;
+    for (int i = l; i < kOneRows * kFB; i += 64) sC[(size_t)w * kOneRows * kFB + i] = 0.f;   // 1/8 of the table each
+    lds_barrier();   // LDS only: __syncthreads() would wait for the loads above
+    float *R_ = sR + (size_t)f * kOneJ * 9, *J_ = sJ + (size_t)f * kOneJ * 3, *L_ = sL + (size_t)f * kOneJ * 12, *G_ = sG + (size_t)f * kOneJ * 12;
+    if (f < nf) {
+        const int b = b0 + f;
+        if (l < J) {
+            float R[9];
+            if (pose2rot) {
+                const float *pp = pose + ((size_t)b * J + l) * 3;
+                rodrigues(pp[0], pp[1], pp[2], R);
+            } else {
+                const float *pp = pose + ((size_t)b * J + l) * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R[k] = pp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R_[l * 9 + k] = R[k];
+            const float *be = betas + (size_t)b * betas_bstride;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {   // J_regressor (v_template + shapedirs beta) = Jt + Js beta  (lbs_rigid_kernel)
+                float acc = Jt[l * 3 + r];
+                for (int k = 0; k < NB; ++k) acc = fmaf(Js[(l * 3 + r) * NB + k], be[k], acc);
+                J_[l * 3 + r] = acc;
+            }
+            if (l > 0) {                    // lbs.py:217 / :222  (R[1:] - I)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sC[(size_t)(NB + (l - 1) * 9 + k) * kFB + f] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
+            }
+        }
+        if (l < NB) sC[(size_t)l * kFB + f] = betas[(size_t)b * betas_bstride + l];
+        wave_sync_lds();
+        if (l < J) {  // local transform [R | J - J_parent]  (lbs.py:390-396)
+            const int p = parents[l];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                L_[l * 12 + r * 4 + 0] = R_[l * 9 + r * 3 + 0];
+                L_[l * 12 + r * 4 + 1] = R_[l * 9 + r * 3 + 1];
+                L_[l * 12 + r * 4 + 2] = R_[l * 9 + r * 3 + 2];
+                L_[l * 12 + r * 4 + 3] = (l > 0) ? (J_[l * 3 + r] - J_[p * 3 + r]) : J_[l * 3 + r];
+            }
+        }
+        wave_sync_lds();
+        if (l < 12) G_[l] = L_[l];
+        wave_sync_lds();
+        for (int i = 1; i < J; ++i) {  // G_i = G_parent(i) . L_i   (lbs.py:399-405)
+            if (l < 12) {
+                const int p = parents[i], r = l >> 2, c = l & 3;
+                float acc = G_[p * 12 + r * 4 + 0] * L_[i * 12 + 0 * 4 + c];
+                acc = fmaf(G_[p * 12 + r * 4 + 1], L_[i * 12 + 1 * 4 + c], acc);
+                acc = fmaf(G_[p * 12 + r * 4 + 2], L_[i * 12 + 2 * 4 + c], acc);
+                if (c == 3) acc += G_[p * 12 + r * 4 + 3];
+                G_[i * 12 + l] = acc;
+            }
+            wave_sync_lds();
+        }
+        if (l < J) {  // A = G with the rest-pose joint removed (lbs.py:414-417); kept in L_ for the skinning below
+            const float jx = J_[l * 3 + 0], jy = J_[l * 3 + 1], jz = J_[l * 3 + 2];
+            float *Ag = (blockIdx.x == 0) ? A_out + ((size_t)b * J + l) * 16 : nullptr;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float g0 = G_[l * 12 + r * 4 + 0], g1 = G_[l * 12 + r * 4 + 1], g2 = G_[l * 12 + r * 4 + 2], g3 = G_[l * 12 + r * 4 + 3];
+                const float tr = g3 - fmaf(g2, jz, fmaf(g1, jy, g0 * jx));
+                if (Ag) { Ag[r * 4 + 0] = g0; Ag[r * 4 + 1] = g1; Ag[r * 4 + 2] = g2; Ag[r * 4 + 3] = tr; }
+                if (Ag && posed_joints) posed_joints[((size_t)b * J + l) * 3 + r] = g3;  // lbs.py:410
+                L_[l * 12 + r * 4 + 0] = g0; L_[l * 12 + r * 4 + 1] = g1; L_[l * 12 + r * 4 + 2] = g2; L_[l * 12 + r * 4 + 3] = tr;
+            }
+            if (Ag) { Ag[12] = 0.f; Ag[13] = 0.f; Ag[14] = 0.f; Ag[15] = 1.f; }
+        }
+    }
+    __syncthreads();   // coefficients of all frames complete; also drains this wave's outstanding loads, which are needed now
+
+    // (3) partial sums of this slice
+    float acc[kFB][3];
+#pragma unroll
+    for (int g = 0; g < kFB; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.f;
+#pragma unroll
+    for (int r = 0; r < kOneRows; ++r) {
+        const lbs_f4 c0 = *reinterpret_cast<const lbs_f4 *>(&sC[(size_t)(k0 + r) * kFB]), c1 = *reinterpret_cast<const lbs_f4 *>(&sC[(size_t)(k0 + r) * kFB + 4]);
+#pragma unroll
+        for (int g = 0; g < kFB; ++g) {
+            const float c = g < 4 ? c0[g] : c1[g - 4];
+            acc[g][0] = fmaf(c, d[r][0], acc[g][0]); acc[g][1] = fmaf(c, d[r][1], acc[g][1]); acc[g][2] = fmaf(c, d[r][2], acc[g][2]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < kFB; ++g)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sRed[((size_t)w * kFB * 3 + g * 3 + c) * 64 + l] = acc[g][c];
+    __syncthreads();
+
+    // (4) wave w finishes frame w: v_posed = v_template + sum of the slices (fixed order), then the skinning
+    if (f < nf && v < V) {
+        float vp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < kOneKS; ++sl)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[c] += sRed[((size_t)sl * kFB * 3 + f * 3 + c) * 64 + l];
+        const float x = vp[0] + t0, y = vp[1] + t1, z = vp[2] + t2;     // lbs.py:223-229
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < kOneJ; ++j) {
+            if (j < J) {
+                const lbs_f4 a0 = *reinterpret_cast<const lbs_f4 *>(&L_[j * 12]), a1 = *reinterpret_cast<const lbs_f4 *>(&L_[j * 12 + 4]),
+                             a2 = *reinterpret_cast<const lbs_f4 *>(&L_[j * 12 + 8]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { T[e] = fmaf(wt[j], a0[e], T[e]); T[4 + e] = fmaf(wt[j], a1[e], T[4 + e]); T[8 + e] = fmaf(wt[j], a2[e], T[8 + e]); }   // lbs.py:238
+            }
+        }
+        float *o = verts + ((size_t)(b0 + f) * V + v) * 3;
+        o[0] = fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3];  // lbs.py:244
+        o[1] = fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7];
+        o[2] = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
+    }
+}
+
 }  // namespace g4d
 
 using namespace g4d;
@@ -358,3 +544,22 @@ extern "C" int g4d_lbs_fused_f32(int b, int v, int j, int nb, int pose2rot, cons
     return check_launch("g4d_lbs_fused_f32");
 }
 
+// lbs() in one launch (lbs_one_kernel): same constants as g4d_lbs_fused_f32, no scratch.
+extern "C" int g4d_lbs_one_supported(int j, int nb) { return j > 0 && j <= kOneJ && nb >= 0 && nb + (j - 1) * 9 <= kOneKS * kOneRows; }
+extern "C" int g4d_lbs_one_f32(int b, int v, int j, int nb, int pose2rot, const float *betas, int betas_bstride, const float *pose,
+                               const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
+                               const int *parents, const float *lbs_weights, float *A_out, float *posed_joints, float *verts,
+                               g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && v > 0 && g4d_lbs_one_supported(j, nb), "g4d_lbs_one_f32: need V > 0, J <= 32 and NB + 9 (J - 1) <= 224 (use g4d_lbs_fused_f32)");
+    G4D_REQUIRE((b + kFB - 1) / kFB <= 65535, "g4d_lbs_one_f32: too many frames for one launch");
+    if (b == 0) return G4D_OK;
+    G4D_REQUIRE(betas && pose && v_template && blend_dirs && J_template && J_shapedirs && parents && lbs_weights && A_out && verts,
+                "g4d_lbs_one_f32: null pointer");
+    const int lds = (int)sizeof(float) * (kOneKS * kOneRows * kFB + kFB * kOneJ * (9 + 3 + 12 + 12) + kOneKS * kFB * 3 * 64);
+    static unsigned long long attr = 0;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(lbs_one_kernel), lds, attr, "g4d_lbs_one_f32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(lbs_one_kernel, dim3((v + 63) / 64, (b + kFB - 1) / kFB), dim3(64 * kOneKS), lds, G4D_S(stream), b, v, j, nb, pose2rot,
+                       betas, betas_bstride, pose, v_template, blend_dirs, J_template, J_shapedirs, parents, lbs_weights, A_out, posed_joints, verts);
+    return check_launch("g4d_lbs_one_f32");
+}

@@ -32,7 +32,13 @@ def _parents_i32(parents, device):
     return p
 
 
-USE_FUSED_LBS = True   # three-launch lbs() (g4d_lbs_fused_f32); False: the five-step path that follows lbs.py line by line
+import os
+
+USE_FUSED_LBS = True   # lbs() on the fused kernels; False: the five-step path that follows lbs.py line by line
+USE_ONE_LAUNCH = os.environ.get("G4D_LBS_ONE", "1") != "0"   # fused route: one launch (g4d_lbs_one_f32) instead of three (g4d_lbs_fused_f32)
+# ... up to this many frames.  Measured (scripts/time_lbs.py, V = 6890): 8 frames 28.2 -> 16.8 us, 16: 31.5 -> 19.7, 24: 34.5 -> 33.0,
+# 64: 57.6 -> 67.5, 240: 159 -> 212 (every 8-frame group re-reads the blend rows and repeats the per-frame chain in each workgroup)
+ONE_LAUNCH_MAX_B = int(os.environ.get("G4D_LBS_ONE_MAX_B", "16"))
 _const_cache = {}
 
 
@@ -171,6 +177,13 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     posed = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
     A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=dev)
     verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
+    if USE_FUSED_LBS and USE_ONE_LAUNCH and V > 0 and B <= ONE_LAUNCH_MAX_B and _lib.lib().g4d_lbs_one_supported(J, NB):
+        # one launch: blend rows requested up front, per-frame rigid chain computed by every workgroup while they are in flight
+        blend_dirs, Jt, Js = _model_constants(v_template, shapedirs, posedirs, J_regressor)
+        _lib.call("g4d_lbs_one_f32", B, V, J, NB, int(bool(pose2rot)), betas.data_ptr(), NB if betas.shape[0] == B else 0, pose.data_ptr(),
+                  v_template.data_ptr(), blend_dirs.data_ptr(), Jt.data_ptr(), Js.data_ptr(), _parents_i32(parents, dev).data_ptr(),
+                  lbs_weights.data_ptr(), A.data_ptr(), posed.data_ptr(), verts.data_ptr(), stream)
+        return verts, posed
     v_posed = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
     if USE_FUSED_LBS and NB <= 64:
         # three launches: the joints follow from betas through two model constants (J_regressor is linear), the shape blend rides

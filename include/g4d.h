@@ -344,6 +344,16 @@ int g4d_lbs_fused_f32(int b, int v, int j, int nb, int pose2rot, const float *be
                       const int *parents, const float *lbs_weights, float *coeff_scratch, float *A_out, float *posed_joints,
                       float *v_posed_scratch, float *verts, g4d_stream_t stream);
 
+/* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
+ * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
+ * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and
+ * NB + 9 (J - 1) <= 224 (g4d_lbs_one_supported; SMPL: 24 joints, 10 betas). */
+int g4d_lbs_one_supported(int j, int nb);
+int g4d_lbs_one_f32(int b, int v, int j, int nb, int pose2rot, const float *betas, int betas_bstride, const float *pose,
+                    const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
+                    const int *parents, const float *lbs_weights, float *A_out, float *posed_joints, float *verts,
+                    g4d_stream_t stream);
+
 /* ---- callers around the hot path ---------------------------------------------- */
 
 /* K nearest neighbours, K <= 256: for every query (B,P1,3) the K points of (B,P2,3) that are smallest under

@@ -227,11 +227,13 @@ def test_gcn_agg_linear_tap_is_bit_identical_to_spmm():
                   0, L.Wf.data_ptr(), 128, out.data_ptr(), _lib.stream_ptr())
 
 
-@pytest.mark.parametrize("fused_path", [True, False])
+@pytest.mark.parametrize("fused_path", ["one", "three", False])
 def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, monkeypatch):
-    """Both lbs() routes -- the three-launch one (joints from betas via J_regressor's linearity, shape blend folded into the pose
-    blend) and the five-step one that follows lbs.py line by line -- against the reference's outputs at full SMPL size."""
-    monkeypatch.setattr(L, "USE_FUSED_LBS", fused_path)
+    """All lbs() routes -- the one-launch kernel, the three-launch one (both: joints from betas via J_regressor's linearity, shape
+    blend folded into the pose blend) and the five-step one that follows lbs.py line by line -- against the reference's outputs at
+    full SMPL size."""
+    monkeypatch.setattr(L, "USE_FUSED_LBS", bool(fused_path))
+    monkeypatch.setattr(L, "USE_ONE_LAUNCH", fused_path == "one")
     g = golden_lbs
     P = syn.smpl_like_params(V=6890, J=24, num_betas=10, seed=40)
     betas, pose = syn.smpl_like_pose(2, seed=41)
@@ -274,3 +276,28 @@ def test_lbs_rejects_mismatched_shapes_before_touching_the_device():
         L.skin(d(P["lbs_weights"][:, :23]), A, torch.zeros((2, 200, 3), device="cuda"))
     with pytest.raises(RuntimeError, match="regressor"):
         L.vertices2jointsB(torch.zeros((2, 24, 199), device="cuda"), torch.zeros((2, 200, 3), device="cuda"))
+
+
+@pytest.mark.parametrize("B,V,J,NB,rot", [(1, 64, 24, 10, True), (8, 6890, 24, 10, True), (19, 1500, 24, 10, False), (9, 777, 25, 1, True),
+                                          (3, 130, 5, 16, True), (17, 63, 23, 3, False)])
+def test_lbs_one_launch_kernel_vs_three_launch_route_and_oracle(B, V, J, NB, rot, monkeypatch):
+    """g4d_lbs_one_f32 against g4d_lbs_fused_f32 (same constants, different summation order of the blend) and the numpy oracle:
+    frame counts that are not a multiple of the 8-frame group, vertex counts that are not a multiple of the 64-vertex tile, joint
+    counts up to the kernel's 32, a weight row that is not 16-byte aligned (J = 5, 23), rotation-matrix input."""
+    P = syn.smpl_like_params(V=V, J=J, num_betas=max(NB, 1), seed=B + V)
+    betas, pose = syn.smpl_like_pose(B, J=J, num_betas=max(NB, 1), seed=B + 1)
+    betas = np.ascontiguousarray(betas[:, :NB])
+    pose_in = pose if rot else lbs_oracle.batch_rodrigues(pose.reshape(-1, 3)).reshape(B, J, 3, 3)
+    args = [dev(P[k]) for k in ("v_template", "shapedirs", "posedirs", "J_regressor")] + [torch.from_numpy(P["parents"]), dev(P["lbs_weights"])]
+    outs = {}
+    monkeypatch.setattr(L, "ONE_LAUNCH_MAX_B", 1 << 30)
+    for one in (True, False):
+        monkeypatch.setattr(L, "USE_ONE_LAUNCH", one)
+        outs[one] = L.lbs(dev(betas), dev(np.ascontiguousarray(pose_in)), *args, pose2rot=rot)
+    assert L._lib.lib().g4d_lbs_one_supported(J, NB)
+    np.testing.assert_allclose(host(outs[True][0]), host(outs[False][0]), rtol=2e-6, atol=2e-6)
+    assert torch.equal(outs[True][1], outs[False][1])        # the rigid chain is the same code
+    wv, wj = lbs_oracle.lbs(betas, pose_in, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"],
+                            pose2rot=rot)
+    np.testing.assert_allclose(host(outs[True][0]), wv, **TOL)
+    np.testing.assert_allclose(host(outs[True][1]), wj, **TOL)
