@@ -45,7 +45,7 @@ __device__ __forceinline__ void finish_tile(const LinearArgs &a, int cout, int l
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float x = v[mt];
-                if constexpr (PS == 8) x = fmaxf(x, __shfl_xor(x, 16));
+                if constexpr (PS == 8) x = max_xor16(x);
                 const int first_row = row0 + mt * 16 + (PS == 8 ? (fq >> 1) * 8 : fq * 4);
                 const bool writer = PS == 8 ? (fq & 1) == 0 : true;
                 if (writer && ch_ok && first_row < a.rows) a.out[(size_t)(first_row / PS) * a.ldo + a.col0 + ch] = x;
@@ -53,8 +53,7 @@ __device__ __forceinline__ void finish_tile(const LinearArgs &a, int cout, int l
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {  // the 16 rows of a tile: across the four fq groups
-                v[mt] = fmaxf(v[mt], __shfl_xor(v[mt], 16));
-                v[mt] = fmaxf(v[mt], __shfl_xor(v[mt], 32));
+                v[mt] = max_xor32(max_xor16(v[mt]));
             }
             if constexpr (PS <= R) {
                 constexpr int TPG = PS / 16;  // tiles per group
@@ -86,7 +85,7 @@ __device__ __forceinline__ void finish_tile(const LinearArgs &a, int cout, int l
             for (int mt = 0; mt < MT; ++mt) {
                 float x = v[mt];
                 if (S == 8) {
-                    const float y = __shfl_xor(x, 16);
+                    const float y = lane_xor16(x);
                     x = is_max ? fmaxf(x, y) : x + y;
                 }
                 const int first_row = row0 + mt * 16 + (S == 8 ? (fq >> 1) * 8 : fq * 4);
@@ -97,9 +96,9 @@ __device__ __forceinline__ void finish_tile(const LinearArgs &a, int cout, int l
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const float y = __shfl_xor(v[mt], 16);
+            const float y = lane_xor16(v[mt]);
             v[mt] = is_max ? fmaxf(v[mt], y) : v[mt] + y;
-            const float z = __shfl_xor(v[mt], 32);
+            const float z = lane_xor32(v[mt]);
             v[mt] = is_max ? fmaxf(v[mt], z) : v[mt] + z;
         }
         if (S <= R) {

@@ -80,6 +80,31 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Exchanges between lanes l and l ^ 16 / l ^ 32 on gfx950's v_permlane16_swap / v_permlane32_swap (VALU) instead of __shfl_xor's
+// ds_bpermute (an LDS-pipe round trip + address arithmetic): the pooling epilogues of the MFMA kernels reduce across the four
+// 16-lane rows of the C/D layout.  swap(a, a) leaves {row 0, row 0, row 2, row 2} / {row 1, row 1, row 3, row 3} (16) or
+// {lower half twice} / {upper half twice} (32) in its two results (scripts/micro/permlane_swap.hip checks both against __shfl_xor).
+__device__ __forceinline__ float lane_xor16(float x) {
+    const unsigned a = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    return __uint_as_float((__lane_id() & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float x) {
+    const unsigned a = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return __uint_as_float((__lane_id() & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float max_xor16(float x) {   // max(x, x of lane ^ 16)
+    const unsigned a = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float x) {
+    const unsigned a = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // Raise a kernel's dynamic-LDS limit above the 64 KB default.  The attribute is PER DEVICE: `done` holds one bit per device
 // ordinal so that a process driving several GPUs sets it on each of them (idempotent, so a race between host threads is benign).
 inline int ensure_dynamic_lds(const void *kernel, int bytes, unsigned long long &done, const char *what) {

@@ -140,9 +140,9 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
         float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
                          : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
         // fold the four 16-lane groups (rows 0-3,4-7,8-11,12-15 of the tile)
-        const float y = __shfl_xor(x, 16);
+        const float y = lane_xor16(x);
         x = is_max ? fmaxf(x, y) : x + y;
-        const float z = __shfl_xor(x, 32);
+        const float z = lane_xor32(x);
         x = is_max ? fmaxf(x, z) : x + z;
         v[mt] = x;
     }

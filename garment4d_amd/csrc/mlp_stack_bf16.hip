@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(512) mlp_stack_bf16_kernel(const StackArgsH s)
                         float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
                                          : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
                         if (a.S == 8) {
-                            const float y = __shfl_xor(x, 16);
+                            const float y = lane_xor16(x);
                             x = is_max ? fmaxf(x, y) : x + y;
                         }
                         const int first_row = row0 + rh * 32 + mt * 16 + (a.S == 8 ? (fq >> 1) * 8 : fq * 4);
@@ -169,9 +169,9 @@ __global__ void __launch_bounds__(512) mlp_stack_bf16_kernel(const StackArgsH s)
                 for (int mt = 0; mt < 2; ++mt) {
                     float x = is_max ? fmaxf(fmaxf(acc[mt][0], acc[mt][1]), fmaxf(acc[mt][2], acc[mt][3]))
                                      : ((acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]));
-                    const float y = __shfl_xor(x, 16);
+                    const float y = lane_xor16(x);
                     x = is_max ? fmaxf(x, y) : x + y;
-                    const float z = __shfl_xor(x, 32);
+                    const float z = lane_xor32(x);
                     x = is_max ? fmaxf(x, z) : x + z;
                     v[mt] = x;
                 }

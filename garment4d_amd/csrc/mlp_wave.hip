@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256, 3) mlp_wave_kernel(const WaveArgs s) {
                             float x = is_max ? fmaxf(fmaxf(acc[mt][ct][0], acc[mt][ct][1]), fmaxf(acc[mt][ct][2], acc[mt][ct][3]))
                                              : ((acc[mt][ct][0] + acc[mt][ct][1]) + (acc[mt][ct][2] + acc[mt][ct][3]));
                             if (a.S == 8) {
-                                const float y = __shfl_xor(x, 16);
+                                const float y = lane_xor16(x);
                                 x = is_max ? fmaxf(x, y) : x + y;
                             }
                             const int first_row = row0 + mt * 16 + (a.S == 8 ? (fq >> 1) * 8 : fq * 4);
@@ -179,9 +179,9 @@ __global__ void __launch_bounds__(256, 3) mlp_wave_kernel(const WaveArgs s) {
                     for (int mt = 0; mt < 4; ++mt) {
                         float x = is_max ? fmaxf(fmaxf(acc[mt][ct][0], acc[mt][ct][1]), fmaxf(acc[mt][ct][2], acc[mt][ct][3]))
                                          : ((acc[mt][ct][0] + acc[mt][ct][1]) + (acc[mt][ct][2] + acc[mt][ct][3]));
-                        const float y = __shfl_xor(x, 16);
+                        const float y = lane_xor16(x);
                         x = is_max ? fmaxf(x, y) : x + y;
-                        const float z = __shfl_xor(x, 32);
+                        const float z = lane_xor32(x);
                         x = is_max ? fmaxf(x, z) : x + z;
                         v[mt] = x;
                     }

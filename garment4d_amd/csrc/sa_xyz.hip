@@ -168,9 +168,9 @@ __global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = fmaxf(__builtin_fmaf(acc[mt][ct][r], s3[ct], h3s[ct]), 0.f);
                 float x = is_max ? fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])) : ((y[0] + y[1]) + (y[2] + y[3]));
-                const float x16 = __shfl_xor(x, 16);
+                const float x16 = lane_xor16(x);
                 x = is_max ? fmaxf(x, x16) : x + x16;
-                const float x32 = __shfl_xor(x, 32);
+                const float x32 = lane_xor32(x);
                 x = is_max ? fmaxf(x, x32) : x + x32;
                 v[mt] = x;      // the 16 rows of tile mt, in every lane
             }
