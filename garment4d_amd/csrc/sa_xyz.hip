@@ -86,11 +86,14 @@ __global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
     Rows cur, nxt;
     auto load_idx = [&](int pass, int (&v)[2]) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) v[mt] = pass < npass ? a.idx[min(pass * 32 + mt * 16 + fi, rows - 1)] : 0;
+        for (int mt = 0; mt < 2; ++mt) v[mt] = a.idx[min(min(pass, npass - 1) * 32 + mt * 16 + fi, rows - 1)];   // unconditional (see load_rows)
     };
     const int nq = (int)(a.rows >> a.logS);
     auto load_rows = [&](int pass, const int (&v)[2], Rows &rw) {
-        if (pass >= npass) return;   // wave-uniform
+        // No `if (pass < npass)` around these loads: past the end the last pass is read again and never used.  A conditional block
+        // makes the number of loads in flight unknown at the join, and the wait for the CURRENT pass's rows (older than these)
+        // becomes s_waitcnt vmcnt(0) -- i.e. the prefetch just issued is waited for on the spot.
+        pass = min(pass, npass - 1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int qi = __builtin_amdgcn_readfirstlane(min((pass * 32 + mt * 16) >> a.logS, nq - 1));   // S >= 16: a tile belongs to one query
