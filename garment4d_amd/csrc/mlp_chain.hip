@@ -124,6 +124,12 @@ __device__ long long g_chain_dbg[8 * 4096];  // per wave (first 4096): 8 clock s
 //   * whether a k-step can use the 16-byte vector path is decided once per step for the whole wave (all 16 columns inside
 //     one source segment), not per lane: the k loop has ONE wave-uniform branch, the common body is base pointer + offset;
 //   * weights and inputs of step ks + 1 are requested before the MFMAs of step ks.
+//     (Spreading the requests BETWEEN the MFMAs of a step -- one weight fragment per channel tile, two buffer sets alternating so
+//     that the double buffer needs no copies -- measured the same within noise: 128-128-256 stack 48.9 -> 48.5 us alone but 0.58 ->
+//     0.565 of peak inside bench.py's harness, 16-batch bench +0.5 %.  With no loads at all in this loop the phase still takes 35.3k
+//     cycles for 26.6k of MFMA issue at one wave per SIMD: what is left is the wave's start-up chain (kernel arguments -> neighbour
+//     index -> row address -> first gather, each a dependent round trip) and the two element-wise seam steps, which only more waves
+//     per SIMD or a persistent tile loop can hide.  Round 2.)
 //     (Requesting 2-4 steps ahead instead -- the widest stack runs one wave per SIMD -- costs 20-70 registers per instantiation and
 //     measured slower everywhere: 128-128-256 stack 49.2 -> 50.4 us alone, the 16-batch bench 27.3k -> 25.7k frames/s; round 2.)
 template <int MODE, int TOUT, int MT, bool LAST>

@@ -1,5 +1,6 @@
 """Phase split of the widest chain launch (SA3 scale 1) from in-kernel cycle stamps.  Needs the debug library:
-G4D_LIB_PATH=garment4d_amd/lib/libg4d_hip_dbg.so python scripts/dbg_chain_phases.py"""
+G4D_LIB_PATH=garment4d_amd/lib/libg4d_hip_dbg.so python scripts/dbg_chain_phases.py
+(build: hipcc <csrc/Makefile FLAGS> -DG4D_CHAIN_DEBUG -c mlp_chain.hip, linked with the other objects of garment4d_amd/lib/obj)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,5 +30,3 @@ for name, mlp, Nn, P, S, C in (("SA3 s1 [195,128,128,256]", model.SA_modules[2].
     ph = np.diff(a[:, :5], axis=1)
     print(f"{name}: waves {nw}; start spread {np.percentile(a[:,0]-t0,[0,50,100])}; end spread {np.percentile(a[:,4]-t0,[0,50,100])}")
     print("   median cycles per phase  first layer | middle layer | epilogue of it + last-layer preload | last layer incl. its per-tile epilogue :", np.median(ph, axis=0), " total", np.median(a[:, 4] - a[:, 0]))
-    print("   inside the first phase: start->ctx ready", np.median(a[:, 5] - a[:, 0]), "| ->preloads issued", np.median(a[:, 6] - a[:, 5]),
-          "| ->first PD steps done", np.median(a[:, 7] - a[:, 6]), "| ->loop end", np.median(a[:, 1] - a[:, 7]))
