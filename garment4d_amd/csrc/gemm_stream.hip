@@ -18,7 +18,12 @@
 // should have let them overlap and measured the same: (1) results leave through BUFFER stores with an out-of-range offset for idle
 // lanes, so the stores are unconditional, their count is static and the wait for the prefetched operands (loads and stores share
 // gfx9's in-order vmcnt) does not include them; (2) the barriers are LDS-only (lds_barrier(), g4d_common.h) -- __syncthreads() drains
-// every global load and store in flight.  Both are kept: they are the right shape, whatever else still serialises the two phases.
+// every global load and store in flight.  Both are kept: they are the right shape.  What still serialises the two phases (ISA, round 2):
+// the compiler's own wait in front of the LDS stores of a tile's first super-chunk is `s_waitcnt vmcnt(3..0)` -- it does not credit the
+// 32 result stores issued after the operand loads, so the write round trip of tile t still sits in front of tile t + 1.  A variant with
+// every load unconditional (clamped rows / tiles, K templated, 32 no-op stores in the prologue so that every path into that wait carries
+// the same 32 younger stores) got the same waits from hipcc and the same 365-380 us at 128 -> 128; only hand-placed waits around
+// asm loads (or LDS-direct loads) would change it.
 #include <cstdlib>
 
 #include "mlp_common.h"
