@@ -170,6 +170,13 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
                                 f2 = *reinterpret_cast<const f32x4u *>(pa2[mt] + k0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b[mt][e] = ctx[mt].w0 * f0[e] + ctx[mt].w1 * f1[e] + ctx[mt].w2 * f2[e];
+                    if (a.pre_scale) {   // wave-uniform: the known rows are a pre-contracted table, the layer's affine + ReLU happen here
+                        const f32x4 ps = *reinterpret_cast<const f32x4 *>(a.pre_scale + k0), pf = *reinterpret_cast<const f32x4 *>(a.pre_shift + k0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b[mt][e] = fmaxf(__builtin_fmaf(b[mt][e], ps[e], pf[e]), 0.f);
+                        if (a.in_tap && row0 + mt * 16 + fi < a.rows)
+                            *reinterpret_cast<f32x4 *>(a.in_tap + (size_t)(row0 + mt * 16 + fi) * a.in_tap_ld + k0) = b[mt];
+                    }
                 } else {
                     b[mt] = *reinterpret_cast<const f32x4u *>(pa[mt] + k0);
                 }
@@ -363,17 +370,19 @@ extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
         case 16080000:                                              // 256-128 (the middle feature-propagation level)
         case 1000000: case 2000000: case 4000000: case 8000000:     // single layers up to 128
         case 8040201:                                               // 128-64-32-(<=16): last FP level + segmentation head
+        case 4020100:                                               // 64-32-(<=16): the head alone, behind a pre-contracted first layer
             return 1;
         default: return 0;
     }
 }
 
-extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
-                                 const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
-                                 int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
-                                 int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
-                                 const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
-                                 int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
+static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                          const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                          int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
+                          int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
+                          const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
+                          int tap_layer, float *tap_out, int tap_ld, const float *pre_scale, const float *pre_shift, float *in_tap,
+                          int in_tap_ld, g4d_stream_t stream) {
     G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP || mode == LOAD_INTERP, "g4d_mlp_chain_f32: mode must be 0 (direct), 1 (group) or 2 (interp)");
     G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
     if (rows == 0) return G4D_OK;
@@ -388,6 +397,12 @@ extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *
     s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
     s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
     G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
+    if (pre_scale) {
+        G4D_REQUIRE(mode == LOAD_INTERP && C1 == 0 && C2 % 16 == 0 && K0 == C2 && pre_shift, "g4d_mlp_chain_table_f32: needs the interpolating loader, "
+                    "no skip features and a table width that is a multiple of 16");
+        G4D_REQUIRE(!in_tap || (in_tap_ld >= C2 && in_tap_ld % 4 == 0 && (reinterpret_cast<size_t>(in_tap) & 15) == 0), "g4d_mlp_chain_table_f32: bad input tap");
+        s.in.pre_scale = pre_scale; s.in.pre_shift = pre_shift; s.in.in_tap = in_tap; s.in.in_tap_ld = in_tap_ld;
+    }
     for (int l = 0; l < nlayers; ++l) {
         G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 16 == 0 && Cout[l] > 0, "g4d_mlp_chain_f32: bad layer %d", l);
         G4D_REQUIRE(Kpad[l] >= (l == 0 ? K0 : Cout[l - 1]), "g4d_mlp_chain_f32: Kpad of layer %d too small", l);
@@ -422,8 +437,37 @@ extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *
         case 2000000: G4D_CHAIN(2, 0, 0, 0)
         case 4000000: G4D_CHAIN(4, 0, 0, 0)
         case 8000000: G4D_CHAIN(8, 0, 0, 0)
+        case 4020100: G4D_CHAIN(4, 2, 1, 0)
         default: G4D_CHAIN(8, 4, 2, 1)
     }
 #undef G4D_CHAIN
     return check_launch("g4d_mlp_chain_f32");
+}
+
+extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                                 const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                                 int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
+                                 int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
+                                 const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
+                                 int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
+    return chain_f32_impl(mode, rows, K0, X, ldx, N, P, S, C, use_xyz, xyz, new_xyz, feats, idx, n, m, C2, C1, known_feats, skip, dist2, nn_idx,
+                          nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer, tap_out, tap_ld, nullptr, nullptr, nullptr,
+                          0, stream);
+}
+
+// Feature propagation without skip features, first layer pre-contracted (pointnet2_modules.py:127-156): the conv of the first
+// SharedMLP layer is linear and three_interpolate is a weighted sum of three known rows, so
+//   conv(sum_i w_i f_i) = sum_i w_i conv(f_i):
+// `table` (B*m, C2) = known features already multiplied by the first layer's weight (m rows per cloud instead of n), and the layer
+// itself shrinks to  h = relu(interp(table) * pre_scale + pre_shift)  inside the loader -- no MFMA work for it.  h is written to
+// `in_tap` (the FP module's output when its MLP has one layer); `layers` are the REMAINING layers (e.g. the segmentation head).
+extern "C" int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx,
+                                       const float *pre_scale, const float *pre_shift, float *in_tap, int in_tap_ld, int nlayers,
+                                       const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
+                                       const int *Cout, const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out,
+                                       int tap_ld, g4d_stream_t stream) {
+    G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift, "g4d_mlp_chain_table_f32: null pointer");
+    return chain_f32_impl(LOAD_INTERP, rows, C2, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, C2, 0, table, nullptr, dist2,
+                          nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, pre_scale, pre_shift,
+                          in_tap, in_tap_ld, stream);
 }

@@ -35,6 +35,11 @@ struct LinearArgs {
     const int *rowptr, *colidx;
     const float *vals;
     int Vg;
+    // INTERP over a pre-contracted table (register-chain kernel only): the loader's row becomes relu(row * pre_scale + pre_shift)
+    // and, when in_tap is set, is also written to in_tap[row * in_tap_ld + column]
+    const float *pre_scale, *pre_shift;
+    float *in_tap;
+    int in_tap_ld;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

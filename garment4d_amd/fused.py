@@ -13,6 +13,7 @@ layout -- are produced only at the API boundary (`to_channel_major`).  Torch is 
 parameter packing only; every FLOP of the forward runs in libg4d_hip.so.  Train-mode BatchNorm needs batch
 statistics over the grouped tensor and stays on the op-by-op path (pointnet2_modules.py).
 """
+import ctypes
 import os
 
 import torch
@@ -38,7 +39,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3")
+    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3", "_raw")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -61,7 +62,14 @@ class PackedLayer:
         Wc16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 32)[..., kperm].permute(0, 2, 3, 1, 4).contiguous()
         self.W, self.Wf, self.Wf16, self.Wc16, self.scale, self.shift = W, Wf, Wf16, Wc16, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
-        self._kperm, self._x3 = kperm, None
+        self._kperm, self._x3, self._raw = kperm, None, None
+
+    def raw(self):
+        """The same contraction without the affine and the ReLU (scale 1, shift 0): the table side of a pre-contracted layer."""
+        if self._raw is None:
+            dev = self.W.device
+            self._raw = PackedLayer(self.W[:self.Cout, :self.K], torch.ones(self.Cout, device=dev), torch.zeros(self.Cout, device=dev), relu=False)
+        return self._raw
 
     def Wc16x3(self):
         """The weight as three bf16 tensors in CHAIN order whose sum is the fp32 weight EXACTLY (hi = w & 0xffff0000,
@@ -590,6 +598,9 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None):
     return dist2, nn_idx
 
 
+FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
+
+
 def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
     """Fused PointnetFPModule.forward (pointnet2_modules.py:127-156), eval mode; all features point-major:
     unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout).
@@ -620,6 +631,28 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
                   dist2.data_ptr(), nn_idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                   L.shift.data_ptr(), L.relu, o.data_ptr(), o.shape[-1], c0, stream)
 
+    if (FP_TABLE and C1 == 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN
+            and B * m < B * n):
+        # No skip features: conv(sum_i w_i f_i) = sum_i w_i conv(f_i), so the first layer's contraction runs over the m KNOWN rows
+        # (table) instead of the n interpolated ones, and the layer itself becomes relu(interp(table) * scale + shift) in the loader.
+        rest = layers[1:] + (pack_conv_stack(head) if head is not None else [])
+        if rest and _lib.lib().g4d_mlp_chain_supported(len(rest), (ctypes.c_int * len(rest))(*[L.Cout for L in rest])):
+            L0 = layers[0]
+            table = linear(known_feats_pm.view(B * m, C2), L0.raw())
+            nl = len(layers)
+            final = torch.empty((B, n, rest[-1].Cout), dtype=torch.float32, device=unknown.device) if head is not None else out
+            PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
+            tap_layer, tap_t = -1, None
+            if head is not None and nl > 1:
+                tap_layer, tap_t = nl - 2, out.view(B * n, -1)      # the FP output is a hidden layer of `rest`
+            in_tap = out.view(B * n, -1) if (head is not None and nl == 1) else None     # ... or the loader's own output
+            _lib.call("g4d_mlp_chain_table_f32", B * n, n, m, L0.Cout, table.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(),
+                      L0.scale.data_ptr(), L0.shift.data_ptr(), _ptr(in_tap), 0 if in_tap is None else in_tap.shape[-1], len(rest),
+                      ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p),
+                      ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p),
+                      ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p),
+                      final.view(B * n, -1).data_ptr(), final.shape[-1], 0, tap_layer, _ptr(tap_t), 0 if tap_t is None else tap_t.shape[-1], stream)
+            return (out, final) if head is not None else out
     if head is not None:
         # FP stack + FC head in one launch; the FP output is tapped to HBM (it is returned to the caller too)
         hl = pack_conv_stack(head)

@@ -344,6 +344,19 @@ int g4d_lbs_fused_f32(int b, int v, int j, int nb, int pose2rot, const float *be
                       const int *parents, const float *lbs_weights, float *coeff_scratch, float *A_out, float *posed_joints,
                       float *v_posed_scratch, float *verts, g4d_stream_t stream);
 
+/* Feature propagation WITHOUT skip features with its first layer pre-contracted (pointnet2_modules.py:127-156, the last FP level of
+ * Pointnet2MSGSEG + the segmentation head): conv(sum_i w_i f_i) = sum_i w_i conv(f_i), so `table` (B*m, C2) holds the known
+ * features already multiplied by the first layer's weight (g4d_linear_f32 with scale 1 / shift 0 / no ReLU over m rows per cloud
+ * instead of n) and the layer itself is  h = relu(three_interpolate(table) * pre_scale + pre_shift)  inside the loader of the
+ * register-chain kernel.  h is written to in_tap (rows x in_tap_ld, NULL: not kept); W / scale / shift / Kpad / Cout / relu describe
+ * the REMAINING layers (fragment-order weights as for g4d_mlp_chain_f32; widths per g4d_mlp_chain_supported); tap_layer / tap_out as
+ * there.  C2 must be a multiple of 16. */
+int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx,
+                            const float *pre_scale, const float *pre_shift, float *in_tap, int in_tap_ld, int nlayers,
+                            const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
+                            const int *Cout, const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
+                            g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

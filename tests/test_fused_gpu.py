@@ -409,3 +409,45 @@ def test_sa_xyz_kernel_equals_chain_kernels_and_module(B, N, P, pool, monkeypatc
         sd = {k: v.cpu().numpy() for k, v in sa.state_dict().items()}
         _, f = MO.sa_module(xyz.cpu().numpy(), None, P, [0.1, 0.2], [16, 32], sd, pool=pool)
         close(fused.to_channel_major(outs[True]), f)
+
+
+@pytest.mark.parametrize("mlp,head_widths", [([128, 128], (64, 32, 7)), ([128, 128], None), ([64, 128, 64], (32,)), ([128, 128, 128, 64], None),
+                                             ([96, 64], (64, 64))])
+@pytest.mark.parametrize("B,n,m", [(2, 3000, 333), (8, 8192, 1024), (1, 100, 7)])
+def test_fp_without_skip_on_the_pre_contracted_table(mlp, head_widths, B, n, m, monkeypatch):
+    """FP levels without skip features run their first layer over the m KNOWN rows (conv(sum w_i f_i) = sum w_i conv(f_i)) and the
+    register-chain kernel interpolates the table (g4d_mlp_chain_table_f32): against the op-by-op module, the fused path without the
+    table, and the oracle -- with and without a head behind it, one or several FP layers, the benched size, row counts that are
+    not a multiple of the wave tile."""
+    from garment4d_amd import pytorch_utils as pt_utils
+    torch.manual_seed(B * 1000 + n + len(mlp))
+    unknown = dev(syn.unit_cloud(B, n, seed=n))
+    known = unknown[:, :m].contiguous() + 0.01 * torch.randn(B, m, 3, device="cuda")
+    kf = torch.randn(B, mlp[0], m, device="cuda")
+    fp = PM.PointnetFPModule(mlp=list(mlp)).cuda()
+    head = None
+    if head_widths is not None:
+        chans = [mlp[-1]] + list(head_widths)
+        head = torch.nn.Sequential(*[pt_utils.Conv1d(chans[i], chans[i + 1], bn=i < len(chans) - 2, activation=torch.nn.ReLU(inplace=True) if i < len(chans) - 2 else None)
+                                     for i in range(len(chans) - 1)]).cuda()
+    for mod in list(fp.modules()) + (list(head.modules()) if head is not None else []):
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5); mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.1)
+    fp.eval()
+    if head is not None:
+        head.eval()
+    outs = {}
+    with torch.no_grad():
+        want = fp(unknown, known, None, kf)
+        want_head = head(want) if head is not None else None
+        for table in (True, False):
+            monkeypatch.setattr(fused, "FP_TABLE", table)
+            outs[table] = fused.fp_forward(fp, unknown, known, None, fused.to_point_major(kf), head=head)
+    got, ref = outs[True], outs[False]
+    if head is None:
+        got, ref = (got,), (ref,)
+    np.testing.assert_allclose(fused.to_channel_major(got[0]).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if head is not None:
+        np.testing.assert_allclose(got[1].transpose(1, 2).cpu().numpy(), want_head.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-5, atol=1e-5)
