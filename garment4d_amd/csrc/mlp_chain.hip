@@ -151,14 +151,28 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         pa1[mt] = pa2[mt] = pb[mt] = nullptr;
-        if constexpr (MODE == LOAD_GROUP) pa[mt] = (a.feats ? a.feats : a.xyz) + ctx[mt].pt_base * a.C - (a.use_xyz ? 3 : 0);  // xyz-only stacks never take the fast path
+        if constexpr (MODE == LOAD_GROUP) {
+            if (a.tab) pa[mt] = a.tab + ctx[mt].pt_base * a.tab_ld;   // pre-contracted table: the whole row is "features"
+            else pa[mt] = (a.feats ? a.feats : a.xyz) + ctx[mt].pt_base * a.C - (a.use_xyz ? 3 : 0);  // xyz-only stacks never take the fast path
+        }
         else if constexpr (MODE == LOAD_DIRECT) pa[mt] = a.X + (size_t)rowc[mt] * a.ldx;
         else { pa[mt] = a.known_feats + ctx[mt].k0; pa1[mt] = a.known_feats + ctx[mt].k1; pa2[mt] = a.known_feats + ctx[mt].k2;
                pb[mt] = a.skip + ctx[mt].sk - a.C2; }
     }
-    if constexpr (MODE == LOAD_GROUP) { a_lo = a.use_xyz ? 3 : 0; a_hi = a.K; }
+    if constexpr (MODE == LOAD_GROUP) { a_lo = (a.use_xyz && !a.tab) ? 3 : 0; a_hi = a.K; }
     else if constexpr (MODE == LOAD_DIRECT) { a_lo = 0; a_hi = a.K; }
     else { a_lo = 0; a_hi = a.C2; b_lo = a.C2; b_hi = a.K; }
+    float gdx[MT], gdy[MT], gdz[MT];   // table mode: x_j - q of the row (pointnet2_utils.py:254), multiplied by the xyz columns of the weight below
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        gdx[mt] = gdy[mt] = gdz[mt] = 0.f;
+        if constexpr (MODE == LOAD_GROUP) {
+            if (a.tab) {
+                const float *pp = a.xyz + ctx[mt].pt_base * 3;
+                gdx[mt] = pp[0] - ctx[mt].cx; gdy[mt] = pp[1] - ctx[mt].cy; gdz[mt] = pp[2] - ctx[mt].cz;
+            }
+        }
+    }
     auto load_b = [&](int ks, f32x4 (&b)[MT]) {
         const int c0 = ks * 16;                       // wave-uniform: the step's 16 columns are [c0, c0 + 16)
         const int k0 = c0 + fq * 4;                   // this lane's 4 consecutive columns
@@ -179,6 +193,18 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
                     }
                 } else {
                     b[mt] = *reinterpret_cast<const f32x4u *>(pa[mt] + k0);
+                    if constexpr (MODE == LOAD_GROUP) {
+                        if (a.tab) {   // wave-uniform: W [x_j - q ; f_j] = Wx (x_j - q) + (Wf f_j): the second term is the table row
+                            const f32x4 wx = *reinterpret_cast<const f32x4 *>(a.tab_wx + k0), wy = *reinterpret_cast<const f32x4 *>(a.tab_wx + a.K + k0),
+                                        wz = *reinterpret_cast<const f32x4 *>(a.tab_wx + 2 * a.K + k0);
+                            const f32x4 ps = *reinterpret_cast<const f32x4 *>(a.pre_scale + k0), pf = *reinterpret_cast<const f32x4 *>(a.pre_shift + k0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = b[mt][e] + __builtin_fmaf(wz[e], gdz[mt], __builtin_fmaf(wy[e], gdy[mt], wx[e] * gdx[mt]));
+                                b[mt][e] = fmaxf(__builtin_fmaf(v, ps[e], pf[e]), 0.f);
+                            }
+                        }
+                    }
                 }
             }
         } else if (MODE == LOAD_INTERP && c0 >= b_lo && c0 + 16 <= b_hi) {   // wave-uniform fast path, segment B
@@ -371,6 +397,7 @@ extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
         case 1000000: case 2000000: case 4000000: case 8000000:     // single layers up to 128
         case 8040201:                                               // 128-64-32-(<=16): last FP level + segmentation head
         case 4020100:                                               // 64-32-(<=16): the head alone, behind a pre-contracted first layer
+        case 2040000: case 4080000: case 8160000:                   // 32-64, 64-128, 128-256: SA stacks behind a pre-contracted first layer
             return 1;
         default: return 0;
     }
@@ -382,7 +409,7 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
                           int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
                           const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
                           int tap_layer, float *tap_out, int tap_ld, const float *pre_scale, const float *pre_shift, float *in_tap,
-                          int in_tap_ld, g4d_stream_t stream) {
+                          int in_tap_ld, const float *tab, int tab_ld, const float *tab_wx, g4d_stream_t stream) {
     G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP || mode == LOAD_INTERP, "g4d_mlp_chain_f32: mode must be 0 (direct), 1 (group) or 2 (interp)");
     G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
     if (rows == 0) return G4D_OK;
@@ -397,7 +424,12 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
     s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
     s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
     G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
-    if (pre_scale) {
+    if (tab) {
+        G4D_REQUIRE(mode == LOAD_GROUP && K0 % 16 == 0 && tab_ld >= K0 && tab_ld % 4 == 0 && (reinterpret_cast<size_t>(tab) & 15) == 0 && tab_wx && pre_scale &&
+                    pre_shift && xyz && new_xyz && idx, "g4d_mlp_chain_group_table_f32: needs a 16-byte aligned table whose width is a multiple of 16, the xyz "
+                    "weights, the affine and the grouping inputs");
+        s.in.tab = tab; s.in.tab_ld = tab_ld; s.in.tab_wx = tab_wx; s.in.pre_scale = pre_scale; s.in.pre_shift = pre_shift;
+    } else if (pre_scale) {
         G4D_REQUIRE(mode == LOAD_INTERP && C1 == 0 && C2 % 16 == 0 && K0 == C2 && pre_shift, "g4d_mlp_chain_table_f32: needs the interpolating loader, "
                     "no skip features and a table width that is a multiple of 16");
         G4D_REQUIRE(!in_tap || (in_tap_ld >= C2 && in_tap_ld % 4 == 0 && (reinterpret_cast<size_t>(in_tap) & 15) == 0), "g4d_mlp_chain_table_f32: bad input tap");
@@ -438,6 +470,9 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
         case 4000000: G4D_CHAIN(4, 0, 0, 0)
         case 8000000: G4D_CHAIN(8, 0, 0, 0)
         case 4020100: G4D_CHAIN(4, 2, 1, 0)
+        case 2040000: G4D_CHAIN(2, 4, 0, 0)
+        case 4080000: G4D_CHAIN(4, 8, 0, 0)
+        case 8160000: G4D_CHAIN(8, 16, 0, 0)
         default: G4D_CHAIN(8, 4, 2, 1)
     }
 #undef G4D_CHAIN
@@ -452,7 +487,7 @@ extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *
                                  int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
     return chain_f32_impl(mode, rows, K0, X, ldx, N, P, S, C, use_xyz, xyz, new_xyz, feats, idx, n, m, C2, C1, known_feats, skip, dist2, nn_idx,
                           nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer, tap_out, tap_ld, nullptr, nullptr, nullptr,
-                          0, stream);
+                          0, nullptr, 0, nullptr, stream);
 }
 
 // Feature propagation without skip features, first layer pre-contracted (pointnet2_modules.py:127-156): the conv of the first
@@ -469,5 +504,21 @@ extern "C" int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, con
     G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift, "g4d_mlp_chain_table_f32: null pointer");
     return chain_f32_impl(LOAD_INTERP, rows, C2, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, C2, 0, table, nullptr, dist2,
                           nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, pre_scale, pre_shift,
-                          in_tap, in_tap_ld, stream);
+                          in_tap, in_tap_ld, nullptr, 0, nullptr, stream);
+}
+
+// Set abstraction with the feature part of its first layer pre-contracted (pointnet2_utils.py:232-265 + the first SharedMLP layer):
+//   W [x_j - q ; f_j] = Wx (x_j - q) + Wf f_j,   and Wf f_j depends on the SOURCE point j only
+// -- `table` row j (stride tab_ld, Kt columns used) = Wf f_j, computed once per level over the N source points instead of once per
+// (centroid, sample) pair; tab_wx = Wx transposed, [3][Kt]; the layer itself is relu((table[j] + Wx (x_j - q)) * pre_scale + pre_shift)
+// inside the loader.  W / scale / ... describe the REMAINING layers; pooling as in g4d_mlp_chain_f32.
+extern "C" int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx,
+                                             const float *table, int tab_ld, int Kt, const float *tab_wx, const float *pre_scale,
+                                             const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
+                                             const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool,
+                                             float *out, int ldo, int col0, g4d_stream_t stream) {
+    G4D_REQUIRE(table && Kt > 0, "g4d_mlp_chain_group_table_f32: null table");
+    return chain_f32_impl(LOAD_GROUP, rows, Kt, nullptr, 0, N, P, S, 0, 1, xyz, new_xyz, nullptr, idx, 0, 0, 0, 0, nullptr, nullptr, nullptr,
+                          nullptr, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, -1, nullptr, 0, pre_scale, pre_shift, nullptr, 0,
+                          table, tab_ld, tab_wx, stream);
 }

@@ -40,6 +40,10 @@ struct LinearArgs {
     const float *pre_scale, *pre_shift;
     float *in_tap;
     int in_tap_ld;
+    // GROUP over a pre-contracted table (register-chain kernel only): row j of `tab` (stride tab_ld) holds the feature part of the
+    // first layer for source point j; the loader's row is relu((tab[j] + tab_wx . (x_j - q)) * pre_scale + pre_shift), tab_wx = [3][K]
+    const float *tab, *tab_wx;
+    int tab_ld;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -258,7 +258,8 @@ def stack_fits(layers, pool, S, rows=None):
 
 
 USE_CHAIN = os.environ.get("G4D_MLP_CHAIN", "1") != "0"
-_CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (16, 8), (1,), (2,), (4,), (8,), (8, 4, 2, 1)}
+_CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (16, 8), (1,), (2,), (4,), (8,), (8, 4, 2, 1),
+                (4, 2, 1), (2, 4), (4, 8), (8, 16)}
 
 
 def chain_fits(layers, pool, S, mode):
@@ -497,13 +498,58 @@ def sampling_chain(xyz, npoints):
 USE_SA_XYZ = os.environ.get("G4D_SA_XYZ", "1") != "0"   # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
 
 
-def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0):
+SA_TABLE = os.environ.get("G4D_SA_TABLE", "1") != "0"   # SA levels with features: feature part of the first layer pre-contracted per source point
+
+
+def sa_table_fits(layers, C, use_xyz, pool, S, table_rows, grouped_rows):
+    """The first layer of this scale can run as a per-source-point table (g4d_mlp_chain_group_table_f32)."""
+    if not (SA_TABLE and USE_CHAIN and C > 0 and use_xyz and len(layers) >= 2 and current_precision() == "fp32" and table_rows < grouped_rows):
+        return False
+    L0, rest = layers[0], layers[1:]
+    return bool(L0.relu and L0.Cout % 16 == 0 and L0.K == 3 + C and chain_fits(rest, pool, S, 1))
+
+
+def sa_level_table(sa, packed, feats_pm, scales):
+    """(table (B*N, sum of the first-layer widths of `scales`), [(column offset, Wx^T (3, Cout1))]): ONE contraction of the level's
+    features with the feature columns of every listed scale's first layer -- Wf f_j for every source point j."""
+    key = tuple(id(packed[k][0]) for k in scales)
+    hit = getattr(sa, "_g4d_sa_table", None)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            Wf = torch.cat([packed[k][0].W[:packed[k][0].Cout, 3:packed[k][0].K] for k in scales], 0).contiguous()
+            cat = PackedLayer(Wf, torch.ones(Wf.shape[0], device=Wf.device), torch.zeros(Wf.shape[0], device=Wf.device), relu=False)
+            wx = [packed[k][0].W[:packed[k][0].Cout, :3].t().contiguous() for k in scales]
+        hit = (key, cat, wx, [packed[k][0] for k in scales])   # the first layers are kept alive: their ids are the key
+        sa._g4d_sa_table = hit
+    _, cat, wx, _ = hit
+    B, N, C = feats_pm.shape
+    table = linear(feats_pm.view(B * N, C), cat)
+    offs, c0 = [], 0
+    for k, w in zip(scales, wx):
+        offs.append((c0, w))
+        c0 += packed[k][0].Cout
+    return table, offs
+
+
+def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=None):
     """One scale of an SA level: gather idx (B,P,S) around new_xyz, the shared-MLP stack `layers`, pooling over S, into out[..., col0:].
-    Picks the kernel family (sa_xyz.hip / register chain / LDS stack / per layer)."""
+    Picks the kernel family (sa_xyz.hip / register chain / LDS stack / per layer).  table = (tensor (B*N, ld), column offset, Wx^T):
+    the feature part of the first layer already contracted per source point (sa_level_table)."""
     B, N, _ = xyz.shape
     P, S = idx.shape[1], idx.shape[2]
     C = 0 if feats_pm is None else feats_pm.shape[2]
     stream = _lib.stream_ptr()
+    if table is not None:
+        tab, c0, wxT = table
+        L0, rest = layers[0], layers[1:]
+        PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
+        _lib.call("g4d_mlp_chain_group_table_f32", B * P * S, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
+                  tab.data_ptr() + 4 * c0, tab.shape[-1], L0.Cout, wxT.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), len(rest),
+                  ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p),
+                  ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p),
+                  ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p),
+                  pool, out.data_ptr(), out.shape[-1], col0, stream)
+        return
 
     def first(L, pl, o, c0):
         _lib.call("g4d_group_linear_f32", B, N, P, S, C, use_xyz, xyz.data_ptr(), new_xyz.data_ptr(),
@@ -544,12 +590,19 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
         out = torch.empty((B, P, ctot), dtype=torch.float32, device=xyz.device)
         col0 = 0
         idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, grid=grid)
-        for grouper, layers, idx in zip(sa.groupers, packed, idxs):
+        # scales whose first layer runs as a per-source-point table: one contraction of the level's features for all of them
+        tab_scales = [k for k, (g, layers) in enumerate(zip(sa.groupers, packed))
+                      if sa_table_fits(layers, C, int(g.use_xyz), pool, g.nsample, B * N, B * P * g.nsample)]
+        table, toffs = sa_level_table(sa, packed, feats_pm, tab_scales) if tab_scales else (None, [])
+        for k, (grouper, layers, idx) in enumerate(zip(sa.groupers, packed, idxs)):
             S = grouper.nsample
             use_xyz = int(grouper.use_xyz)
             assert use_xyz or feats_pm is not None
-
-            sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0)
+            tb = None
+            if k in tab_scales:
+                c0, wxT = toffs[tab_scales.index(k)]
+                tb = (table, c0, wxT)
+            sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=tb)
             col0 += layers[-1].Cout
         return new_xyz, out
     # GroupAll (pointnet2_utils.py:268-291): one group of all N points, raw coordinates

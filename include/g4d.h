@@ -357,6 +357,19 @@ int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, const float *t
                             const int *Cout, const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
                             g4d_stream_t stream);
 
+/* Set abstraction with the FEATURE part of its first layer pre-contracted (pointnet2_utils.py:232-265 + the first SharedMLP layer):
+ *   W [x_j - q ; f_j] = Wx (x_j - q) + Wf f_j,   and Wf f_j depends on the source point j only.
+ * `table` row j (row stride tab_ld floats, Kt columns used, Kt a multiple of 16, 16-byte aligned) = Wf f_j for source point j of the
+ * level -- one g4d_linear_f32 over the B*N source points (scale 1, shift 0, no ReLU) instead of B*P*S grouped rows; tab_wx (3, Kt) =
+ * Wx transposed.  The layer itself becomes relu((table[j] + Wx (x_j - q)) * pre_scale + pre_shift) inside the loader of the
+ * register-chain kernel; W / scale / shift / Kpad / Cout / relu describe the REMAINING layers (widths per g4d_mlp_chain_supported),
+ * pool / out / ldo / col0 as g4d_mlp_chain_f32.  rows = B*P*S. */
+int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx,
+                                  const float *table, int tab_ld, int Kt, const float *tab_wx, const float *pre_scale,
+                                  const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
+                                  const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
+                                  int ldo, int col0, g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

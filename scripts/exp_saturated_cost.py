@@ -94,14 +94,22 @@ with torch.no_grad():
         P = sa.npoint
         out = torch.empty((B, P, sum(fused.pack_conv_stack(m)[-1].Cout for m in sa.mlps)), device=dev)
         col0 = 0
+        packed = [fused.pack_conv_stack(mm) for mm in sa.mlps]
+        tab_scales = [k for k, (g, L_) in enumerate(zip(sa.groupers, packed)) if fused.sa_table_fits(L_, C, 1, 1, g.nsample, B * n, B * P * g.nsample)]
+        table, toffs = (None, [])
+        if tab_scales:
+            items.append((f"SA{li+1} first-layer table ({n} source points x {C} -> {sum(packed[k][0].Cout for k in tab_scales)})",
+                          lambda sa=sa, packed=packed, f=f, tab_scales=tab_scales: fused.sa_level_table(sa, packed, f, tab_scales)))
+            table, toffs = fused.sa_level_table(sa, packed, f, tab_scales)
         for si, (g, mlp, idx) in enumerate(zip(sa.groupers, sa.mlps, idxs)):
             layers = fused.pack_conv_stack(mlp)
+            tb = (table, *toffs[tab_scales.index(si)]) if si in tab_scales else None
             S = g.nsample
             rows = B * P * S
             fl = 2.0 * rows * sum(L.K * L.Cout for L in layers)
             items.append((f"SA{li+1} s{si} MLP {[L.Cout for L in layers]} rows {rows} [{fl/1e9:.2f} GF]",
-                          lambda layers=layers, out=out, col0=col0, x=x, nx=nx, f=f, idx=idx: fused.sa_scale_mlp(x, nx, f, idx, layers, 1, 1, out, col0), fl))
-            fused.sa_scale_mlp(x, nx, f, idx, layers, 1, 1, out, col0)
+                          lambda layers=layers, out=out, col0=col0, x=x, nx=nx, f=f, idx=idx, tb=tb: fused.sa_scale_mlp(x, nx, f, idx, layers, 1, 1, out, col0, table=tb), fl))
+            fused.sa_scale_mlp(x, nx, f, idx, layers, 1, 1, out, col0, table=tb)
             col0 += layers[-1].Cout
         l_xyz.append(nx); l_f.append(out)
     feats = list(l_f)
