@@ -259,7 +259,7 @@ def stack_fits(layers, pool, S, rows=None):
 
 USE_CHAIN = os.environ.get("G4D_MLP_CHAIN", "1") != "0"
 _CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (16, 8), (1,), (2,), (4,), (8,), (8, 4, 2, 1),
-                (4, 2, 1), (2, 4), (4, 8), (8, 16)}
+                (4, 2, 1), (2, 4), (4, 8), (8, 16), (16,)}
 
 
 def chain_fits(layers, pool, S, mode):
