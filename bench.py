@@ -126,16 +126,19 @@ def kernel_rooflines(model, cloud):
     from garment4d_amd import fused
     res = {}
 
-    def timed(fn, iters=10):
+    def timed(fn, iters=10, reps=6):
+        """seconds per launch: `reps` launches back to back between each event pair -- with one launch per pair the interval also
+        holds the host's enqueue latency of that launch (4-6 us through ctypes), which rocprofv3's kernel durations do not"""
         fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for a, b in evs:
             a.record()
-            fn()
+            for _ in range(reps):
+                fn()
             b.record()
         torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3  # seconds
+        return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3 / reps  # seconds
 
     # 1. FPS level 1 (8192 -> 1024): the dominant kernel by summed GPU time.  One launch = B clouds, one workgroup per cloud,
     #    1023 strictly dependent rounds: LATENCY-bound (SURVEY 8d regime 1).  Algorithmic bytes = xyz in + idx out (the fused
@@ -155,10 +158,16 @@ def kernel_rooflines(model, cloud):
                   "rounds_per_s_per_cloud": 1023 / t,
                   "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
                           "neither HBM nor MFMA limits it (frac is against HBM only because the contract wants a number) -- DESIGN.md section 5"}
-    # 2. heaviest MFMA launch of a step: SA3 scale 1, [195 -> 128 -> 128 -> 256] over B*64*64 grouped rows + max pool, one
-    #    register-chain launch (csrc/mlp_chain.hip).  Algorithmic flops = 2 * rows * sum(K_l * C_l), un-padded.
+    # 2. heaviest MFMA launch of a step: SA3 scale 1, [195 -> 128 -> 128 -> 256] over B*64*64 grouped rows + max pool.  The path the
+    #    encoder takes (fused.sa_forward): the feature part of the first layer is contracted once per SOURCE point (a table over the
+    #    B*256 points of the level, shared by both scales), and one register-chain launch (csrc/mlp_chain.hip, table loader) runs
+    #    relu(affine(table[j] + Wx (x_j - q))) -> 128 -> 256 + max.  `achieved` / `frac` = the MFMA flops that launch EXECUTES over its
+    #    duration (matrix-pipe utilisation); `algorithmic` = the layer stack as the reference computes it (2 * rows * sum K_l C_l,
+    #    un-padded) over the launch + its share of the table launch; `full_chain` = the same stack on the three-layer chain kernel
+    #    (G4D_SA_TABLE=0), the kernel this object described before round 2's table route.
     sa3 = model.SA_modules[2]
-    layers = fused.pack_conv_stack(sa3.mlps[1])
+    packed = [fused.pack_conv_stack(mm) for mm in sa3.mlps]
+    layers = packed[1]
     Bc, Nn, P, S, C = B_CLOUDS, 256, 64, 64, 192
     g = torch.Generator(device="cpu").manual_seed(0)
     xyz3 = torch.rand(Bc, Nn, 3, generator=g).to(cloud.device)
@@ -167,15 +176,36 @@ def kernel_rooflines(model, cloud):
     idx3 = torch.randint(0, Nn, (Bc, P, S), generator=g, dtype=torch.int32).to(cloud.device)
     out3 = torch.empty(Bc * P, layers[-1].Cout, device=cloud.device)
     rows = Bc * P * S
-    t = timed(lambda: fused.mlp_stack(1, rows, 3 + C, layers, out3, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
-    flops = 2.0 * rows * sum(L.K * L.Cout for L in layers)
-    tr = pmc_traffic("mlp_chain_kernel<1, 8, 8, 16")
-    res["mlp"] = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", "bound": "mfma",
-                  "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                  "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
-                  "traffic_source": None if tr is None else tr["source"], "avg_launch_us": t * 1e6,
-                  "note": "isolated launch on an idle chip; inside the 16-batch bench the same launch runs concurrently with others"}
+    flops_alg = 2.0 * rows * sum(L.K * L.Cout for L in layers)
+    t_full = timed(lambda: fused.mlp_stack(1, rows, 3 + C, layers, out3, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
+    full = {"kernel": "mlp_chain_kernel<GROUP,8,8,16>", "avg_launch_us": t_full * 1e6, "achieved": flops_alg / t_full / 1e12,
+            "frac": flops_alg / t_full / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    scales = [k for k, (gr, L_) in enumerate(zip(sa3.groupers, packed)) if fused.sa_table_fits(L_, C, 1, 1, gr.nsample, Bc * Nn, Bc * P * gr.nsample)]
+    if 1 in scales:
+        t_tab = timed(lambda: fused.sa_level_table(sa3, packed, f3, scales))
+        table, toffs = fused.sa_level_table(sa3, packed, f3, scales)
+        tb = (table, *toffs[scales.index(1)])
+        t = timed(lambda: fused.sa_scale_mlp(xyz3, new3, f3, idx3, layers, 1, 1, out3.view(Bc, P, -1), 0, table=tb))
+        flops_exec = 2.0 * rows * sum(L.K * L.Cout for L in layers[1:])
+        share = layers[0].Cout / float(sum(packed[k][0].Cout for k in scales))
+        tr = pmc_traffic("mlp_chain_kernel<1, 8, 16")
+        res["mlp"] = {"kernel": "mlp_chain_kernel<GROUP,8,16>, table loader (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64; "
+                                "feature part of the first layer pre-contracted per source point)", "bound": "mfma",
+                      "achieved": flops_exec / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": flops_exec / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "executed_flops": flops_exec,
+                      "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
+                      "traffic_source": None if tr is None else tr["source"], "avg_launch_us": t * 1e6,
+                      "algorithmic": {"flops": flops_alg, "table_launch_us": t_tab * 1e6, "table_share": share,
+                                      "tflops_equivalent": flops_alg / (t + share * t_tab) / 1e12,
+                                      "frac_equivalent": flops_alg / (t + share * t_tab) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                      "full_chain": full,
+                      "note": "isolated launches on an idle chip; inside the 16-batch bench the same launch runs concurrently with others"}
+    else:
+        tr = pmc_traffic("mlp_chain_kernel<1, 8, 8, 16")
+        res["mlp"] = dict(full, kernel=full["kernel"] + " (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", bound="mfma",
+                          peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
+                          traffic_source=None if tr is None else tr["source"],
+                          note="isolated launch on an idle chip; inside the 16-batch bench the same launch runs concurrently with others")
     return res
 
 
