@@ -502,7 +502,10 @@ SA_TABLE = os.environ.get("G4D_SA_TABLE", "1") != "0"   # SA levels with feature
 
 
 def sa_table_fits(layers, C, use_xyz, pool, S, table_rows, grouped_rows):
-    """The first layer of this scale can run as a per-source-point table (g4d_mlp_chain_group_table_f32)."""
+    """The first layer of this scale can run as a per-source-point table (g4d_mlp_chain_group_table_f32).  fp32 only: with bf16
+    operands (BASELINE config 3) the first layer is cheap on the bf16 matrix cores and the table launch + the fp32 loader arithmetic
+    cost more than they save (measured with table loaders in mlp_chain_bf16.hip: 38.0k -> 36.0k frames/s; bf16x3 27.9k -> 28.3k), and
+    the result would no longer be what a bf16-operand evaluation of the reference's layer gives -- not kept."""
     if not (SA_TABLE and USE_CHAIN and C > 0 and use_xyz and len(layers) >= 2 and current_precision() == "fp32" and table_rows < grouped_rows):
         return False
     L0, rest = layers[0], layers[1:]
