@@ -445,13 +445,18 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
     const int key = chain_key(nlayers, Cout);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // rows per wave (16 * MT).  Measured on the cfg2 stacks (scripts/time_stacks.py, G4D_CHAIN_MT sweep): 32 rows per wave win
-    // once the launch still has >= 2048 waves (each weight fragment load then feeds 8 MFMAs), and for the 128-wide stack already
-    // at 1024 waves (its weight traffic dominates); 16 rows per wave otherwise (small launches need the waves); 64 rows per
-    // wave never won.
+    // once the launch still has >= 2048 waves (each weight fragment load then feeds 8 MFMAs); 16 rows per wave otherwise (small
+    // launches need the waves); 64 rows per wave never won.  The widest stacks (128-wide first layer) at 1024 waves -- SA3 scale 1 of
+    // cfg2 -- are 6 % faster ALONE with 32 rows per wave (37.5 vs 40.1 us behind the table loader), but that instantiation holds 378
+    // registers: one wave per SIMD and none on a CU that hosts a sampling workgroup; with 16 batches in flight the 16-row one (212
+    // registers, two per SIMD, one beside the FPS waves) gives 30.2k instead of 29.8k frames/s, so it is the default
+    // (G4D_CHAIN_MT2_MIN_WAVES_WIDE=1024 restores the other choice).
     const long long waves32 = (rows + 31) / 32;
     static const int mt_env = getenv("G4D_CHAIN_MT") ? atoi(getenv("G4D_CHAIN_MT")) : 0;  // tuning hook: 1 | 2
     const bool wide = key >= 8000000;
-    const int mt = mt_env ? (mt_env >= 2 ? 2 : 1) : ((waves32 >= 2048 || (wide && waves32 >= 1024)) ? 2 : 1);
+    static const long long mt2_min = getenv("G4D_CHAIN_MT2_MIN_WAVES") ? atoll(getenv("G4D_CHAIN_MT2_MIN_WAVES")) : 2048;      // tuning hooks
+    static const long long mt2_min_wide = getenv("G4D_CHAIN_MT2_MIN_WAVES_WIDE") ? atoll(getenv("G4D_CHAIN_MT2_MIN_WAVES_WIDE")) : 2048;
+    const int mt = mt_env ? (mt_env >= 2 ? 2 : 1) : ((waves32 >= mt2_min || (wide && waves32 >= mt2_min_wide)) ? 2 : 1);
 #define G4D_CHAIN(T1, T2, T3, T4)                                   \
     if (mt == 2) launch_chain<T1, T2, T3, T4, 2>(mode, s, st);      \
     else launch_chain<T1, T2, T3, T4, 1>(mode, s, st);              \
