@@ -451,3 +451,43 @@ def test_fp_without_skip_on_the_pre_contracted_table(mlp, head_widths, B, n, m, 
     if head is not None:
         np.testing.assert_allclose(got[1].transpose(1, 2).cpu().numpy(), want_head.cpu().numpy(), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("pool", ["max_pool", "avg_pool"])
+@pytest.mark.parametrize("B,N,P,C,mlps,nsamples", [
+    (2, 1024, 256, 96, [[96, 32, 32, 64], [96, 64, 64, 128]], [16, 32]),       # SA2 of the encoder
+    (8, 256, 64, 192, [[192, 64, 64, 128], [192, 128, 128, 256]], [32, 64]),   # SA3 of the encoder, benched size
+    (3, 777, 129, 40, [[40, 64, 128], [40, 48, 64, 128]], [16, 64]),           # a 2-layer scale (table) next to one whose width is not a multiple of 16 (no table)
+    (1, 300, 33, 7, [[7, 128, 128]], [8]),                                     # ragged feature width, single scale, window 8
+])
+def test_sa_with_features_on_the_per_source_point_table(B, N, P, C, mlps, nsamples, pool, monkeypatch):
+    """SA levels with features run the feature part of their first layer once per SOURCE point (W [x_j - q ; f_j] = Wx (x_j - q) + Wf f_j,
+    fused.sa_level_table) and the chain kernel's loader adds the xyz part (g4d_mlp_chain_group_table_f32): against the op-by-op module,
+    the fused path without the table and -- on the smallest case -- the oracle; max and avg pooling, several scales sharing one table."""
+    torch.manual_seed(B * 100 + C)
+    xyz = dev(syn.unit_cloud(B, N, seed=N))
+    feats = torch.randn(B, C, N, device="cuda")
+    sa = PM.PointnetSAModuleMSG(npoint=P, radii=[0.15 + 0.1 * i for i in range(len(mlps))], nsamples=nsamples, mlps=[list(m) for m in mlps],
+                                pool_method=pool).cuda()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    sa.eval()
+    fpm = fused.to_point_major(feats)
+    packed = [fused.pack_conv_stack(mm) for mm in sa.mlps]
+    fits = [fused.sa_table_fits(L_, C, 1, {"max_pool": 1, "avg_pool": 2}[pool], g.nsample, B * N, B * P * g.nsample) for g, L_ in zip(sa.groupers, packed)]
+    assert fits[0] or N == 300 or C == 40, fits
+    outs = {}
+    with torch.no_grad():
+        nx, want = sa(xyz, feats)
+        for on in (True, False):
+            monkeypatch.setattr(fused, "SA_TABLE", on)
+            nx2, outs[on] = fused.sa_forward(sa, xyz, fpm)
+            assert torch.equal(nx, nx2)
+    np.testing.assert_allclose(outs[True].cpu().numpy(), outs[False].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if N <= 300:
+        from oracle import modules_oracle as MO
+        sd = {k: v.cpu().numpy() for k, v in sa.state_dict().items()}
+        _, f = MO.sa_module(xyz.cpu().numpy(), feats.cpu().numpy(), P, [g.radius for g in sa.groupers], nsamples, sd, pool=pool)
+        np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), f, rtol=1e-5, atol=1e-5)
