@@ -465,6 +465,11 @@ __global__ void __launch_bounds__(256) three_nn_grid_kernel(int n, int m, const 
     }
 }
 
+void grid_sorted_layout(int n, size_t *offset_bytes, size_t *stride_bytes) {
+    *offset_bytes = kGridHdrBytes + ((((size_t)grid_cmax(n) + 1) * 4 + 63) & ~(size_t)63);
+    *stride_bytes = grid_cloud_bytes(n);
+}
+
 int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st, int budget) {  // also used by ball_query.hip (query sorting)
     const int cmax = grid_cmax(n);
     if (budget <= 0 || budget > cmax) budget = cmax;

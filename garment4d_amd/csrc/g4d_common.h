@@ -56,7 +56,8 @@ __device__ __forceinline__ g4d_f32x2 dist2(g4d_f32x2 x, g4d_f32x2 y, g4d_f32x2 z
 
 // ball_grid.hip: counting sort of a cloud into the cells of a uniform grid (cell edge 1.01 * rmax); `ws` holds, per cloud, a
 // 64-byte header, the cell start table and the records (x, y, z, original index) in cell order
-int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st, int budget = 0);  // rmax <= 0: finest grid within `budget` cells
+int grid_build(int b, int n, float rmax, const float *xyz, void *ws, hipStream_t st, int budget = 0);
+void grid_sorted_layout(int n, size_t *offset_bytes, size_t *stride_bytes);   // where a cloud's (x, y, z, index) records in cell order sit in that workspace  // rmax <= 0: finest grid within `budget` cells
 size_t grid_bytes_per_cloud(int n);
 size_t grid_records_offset(int n);  // byte offset of the float4 records inside a cloud's workspace
 

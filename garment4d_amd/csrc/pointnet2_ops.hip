@@ -150,15 +150,26 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
 // it together: ~60 of the ~85 instructions per step); scanning the whole set lets K grow to m and the per-candidate tests skip
 // half of the inserts.
 template <int FM>
+// `qrec` (optional): the unknown cloud as (x, y, z, original index) records in CELL ORDER -- the `sorted` array of its ball-grid
+// workspace (ball_grid.hip), one array of n records per cloud at stride qstride bytes.  The 64 queries of a wave are then neighbours:
+// a known point is close to all of them or to none, so the wave-uniform tests around the inserts -- which pass when ANY lane improves
+// -- fail for most candidates instead of passing for most of them (64 unrelated queries x 4 candidates: ~80 % at K = 512).
 __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                            const float *__restrict__ known_all, float *__restrict__ dist2_all,
-                                                           int *__restrict__ idx_all) {
+                                                           int *__restrict__ idx_all, const unsigned char *__restrict__ qrec, size_t qstride) {
     __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    int p = blockIdx.x * 256 + threadIdx.x;
     const float *known = known_all + (size_t)b * m * 3;
-    const float *u = unknown_all + ((size_t)b * n + min(p, n - 1)) * 3;
-    const float ux = u[0], uy = u[1], uz = u[2];
+    float ux, uy, uz;
+    int orig = p;
+    if (qrec) {
+        const float4 r = reinterpret_cast<const float4 *>(qrec + (size_t)b * qstride)[min(p, n - 1)];
+        ux = r.x; uy = r.y; uz = r.z; orig = __float_as_int(r.w);
+    } else {
+        const float *u = unknown_all + ((size_t)b * n + min(p, n - 1)) * 3;
+        ux = u[0]; uy = u[1]; uz = u[2];
+    }
     float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
     int i1 = 0, i2 = 0, i3 = 0;
     for (int base = 0; base < m; base += kNNChunk) {
@@ -187,8 +198,8 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
         }
     }
     if (p < n) {
-        float *d2o = dist2_all + ((size_t)b * n + p) * 3;
-        int *ix = idx_all + ((size_t)b * n + p) * 3;
+        float *d2o = dist2_all + ((size_t)b * n + orig) * 3;
+        int *ix = idx_all + ((size_t)b * n + orig) * 3;
         d2o[0] = b1; d2o[1] = b2; d2o[2] = b3;
         ix[0] = i1; ix[1] = i2; ix[2] = i3;
     }
@@ -391,12 +402,29 @@ extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const
     static const int wide_min_n = [] { const char *e = getenv("G4D_NN_WIDE_MIN_N"); return e ? atoi(e) : 4096; }();
     if (n >= wide_min_n && m >= 256) {   // 64 queries per wave over the whole known set: see three_nn_wide_kernel
         dim3 gridw((n + 255) / 256, b);
-        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx))
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx, (const unsigned char *)nullptr, (size_t)0))
         return check_launch("g4d_three_nn_f32");
     }
     dim3 grid((n + 63) / 64, b);
     G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_kernel<FM>, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx))
     return check_launch("g4d_three_nn_f32");
+}
+
+// three_nn with the ball-grid workspace of the UNKNOWN cloud at hand (g4d_ball_grid_build_f32 on `unknown`, any radius): the same scan,
+// the queries taken in the workspace's cell order (see three_nn_wide_kernel).  Output identical to g4d_three_nn_f32.
+extern "C" int g4d_three_nn_cells_f32(int b, int n, int m, const float *unknown, const void *unknown_grid, const float *known, float *dist2,
+                                      int *idx, g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_three_nn_cells_f32", b, n, m);
+    G4D_REQUIRE(b <= 65535, "g4d_three_nn_cells_f32: b > 65535 not supported");
+    if ((long long)b * n == 0) return G4D_OK;
+    if (!unknown_grid || m == 0) return g4d_three_nn_f32(b, n, m, unknown, known, dist2, idx, stream);
+    G4D_REQUIRE(unknown && dist2 && idx && known, "g4d_three_nn_cells_f32: null pointer");
+    size_t off = 0, stride = 0;
+    grid_sorted_layout(n, &off, &stride);
+    dim3 gridw((n + 255) / 256, b);
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx,
+                                                          reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride))
+    return check_launch("g4d_three_nn_cells_f32");
 }
 
 extern "C" int g4d_three_interp_f32(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,

@@ -81,6 +81,7 @@ class Pointnet2MSGSEG(nn.Module):
         xyz = pointcloud[..., 0:3].contiguous()
         feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None  # already point-major
         l_xyz, l_feats = [xyz], [feats]
+        grid0 = None
         if fused.OVERLAP_SAMPLING:
             # sampling depends on coordinates only: the three FPS -> gather steps run as one chain on a side stream, overlapping
             # the ball-grid build of level 1 and the ball queries + MLPs of the levels before them
@@ -96,8 +97,14 @@ class Pointnet2MSGSEG(nn.Module):
                 l_xyz.append(nx)
                 l_feats.append(nf)
         else:
-            for sa in self.SA_modules:
-                nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1])
+            for li, sa in enumerate(self.SA_modules):
+                grid = None
+                radii = [g.radius for g in sa.groupers]
+                if li == 0 and xyz.shape[1] >= fused.GRID_MIN_N and sa.npoint is not None and max(radii) <= 2.01 * min(radii):
+                    # the level-0 cloud's cell grid: the first level's ball query uses it, and so does the three-NN of the LAST
+                    # feature-propagation level (same cloud as its unknown set)
+                    grid0 = grid = fused.build_ball_grid(xyz, max(radii))
+                nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1], grid=grid)
                 l_xyz.append(nx)
                 l_feats.append(nf)
         middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None
@@ -106,7 +113,7 @@ class Pointnet2MSGSEG(nn.Module):
             l_feats[i - 1] = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
         # last FP level + FC head share one launch (the FP features are tapped out for the caller)
         l_feats[0], sem_logits = fused.fp_forward(self.FP_modules[0], l_xyz[0], l_xyz[1], l_feats[0], l_feats[1],
-                                                  head=self.FC_layer)  # logits (B, N, classes)
+                                                  head=self.FC_layer, unknown_grid=grid0)  # logits (B, N, classes)
         if channel_major:
             l_feats = [None if f is None else fused.to_channel_major(f) for f in l_feats]
             middle = None if middle is None else fused.to_channel_major(middle)

@@ -633,9 +633,14 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
 THREE_NN_GRID_MIN_M = int(os.environ.get("G4D_NN_GRID_MIN_M", "4096"))  # known sets at least this large search the cell grid (csrc/ball_grid.hip); below, the scan wins
 
 
-def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None):
+NN_CELLS = os.environ.get("G4D_NN_CELLS", "1") != "0"   # three_nn scan over cell-ordered queries when the unknown cloud's ball grid exists
+
+
+def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=None):
     """Three nearest `known` (B,m,3) points of every `unknown` (B,n,3) point: (dist2 (B,n,3) squared, idx (B,n,3) int32).
-    grid=None: the cell-grid search from m = THREE_NN_GRID_MIN_M on, the scan below; True / False force a route (identical output)."""
+    grid=None: the cell-grid search from m = THREE_NN_GRID_MIN_M on, the scan below; True / False force a route (identical output).
+    unknown_grid: the (workspace, rmax) pair of build_ball_grid(unknown, ...), if the caller has it: the scan then takes the queries
+    in cell order (g4d_three_nn_cells_f32; identical output)."""
     B, n, _ = _chk(unknown).shape
     m = _chk(known).shape[1]
     dev = unknown.device
@@ -643,6 +648,10 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None):
         dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
     if nn_idx is None:
         nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=dev)
+    if NN_CELLS and unknown_grid is not None and grid is None and n >= 4096 and 256 <= m < THREE_NN_GRID_MIN_M and B > 0:
+        _lib.call("g4d_three_nn_cells_f32", B, n, m, unknown.data_ptr(), unknown_grid[0].data_ptr(), known.data_ptr(), dist2.data_ptr(),
+                  nn_idx.data_ptr(), _lib.stream_ptr())
+        return dist2, nn_idx
     if grid is None:
         grid = m >= THREE_NN_GRID_MIN_M
     if grid and m > 0 and B * n > 0:
@@ -657,7 +666,7 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None):
 FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
 
 
-def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
+def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, unknown_grid=None):
     """Fused PointnetFPModule.forward (pointnet2_modules.py:127-156), eval mode; all features point-major:
     unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout).
     With `head` (an FC stack of Conv1d blocks) returns (features, head(features)), fused into the same launch when
@@ -680,7 +689,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None):
         return out if head is None else (out, conv_stack_forward(head, out))
     m = known.shape[1]
     C2 = known_feats_pm.shape[2]
-    dist2, nn_idx = three_nn(unknown, known)
+    dist2, nn_idx = three_nn(unknown, known, unknown_grid=unknown_grid)   # unknown_grid: build_ball_grid(unknown, ...) of an earlier SA level, if any
 
     def first(L, pl, o, c0):
         _lib.call("g4d_interp_linear_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm),

@@ -370,6 +370,14 @@ int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const flo
                                   const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
                                   int ldo, int col0, g4d_stream_t stream);
 
+/* three_nn (interpolate_gpu.cu:9-52) when the ball-grid workspace of the UNKNOWN cloud exists already (g4d_ball_grid_build_f32 on
+ * `unknown`, any radius -- the encoder has built it for the first set-abstraction level): the scan of g4d_three_nn_f32 with the queries
+ * taken in that workspace's cell order, so that the 64 queries of a wave are neighbours and its wave-uniform tests skip the inserts for
+ * most known points.  dist2 / idx identical to g4d_three_nn_f32 (written at the original query positions); unknown_grid == NULL falls
+ * through to it. */
+int g4d_three_nn_cells_f32(int b, int n, int m, const float *unknown, const void *unknown_grid, const float *known, float *dist2, int *idx,
+                           g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

@@ -121,11 +121,11 @@ with torch.no_grad():
         fl = 2.0 * B * unknown.shape[1] * sum(L.K * L.Cout for L in layers)
         n_, m_ = unknown.shape[1], known.shape[1]
         d2 = torch.empty((B, n_, 3), device=dev); ni = torch.empty((B, n_, 3), dtype=torch.int32, device=dev)
-        items.append((f"FP{4+i} three_nn {n_}<-{m_}", lambda unknown=unknown, known=known, d2=d2, ni=ni, n_=n_, m_=m_:
-                      _lib.call("g4d_three_nn_f32", B, n_, m_, unknown.data_ptr(), known.data_ptr(), d2.data_ptr(), ni.data_ptr(), _lib.stream_ptr())))
+        ug = fused.build_ball_grid(unknown, 0.2) if (i == -3 and n_ >= fused.GRID_MIN_N) else None   # the last FP level reuses SA1's grid
+        items.append((f"FP{4+i} three_nn {n_}<-{m_}", lambda unknown=unknown, known=known, d2=d2, ni=ni, ug=ug: fused.three_nn(unknown, known, d2, ni, unknown_grid=ug)))
         items.append((f"FP{4+i} three_nn + MLP {[L.Cout for L in layers]} rows {B*n_} [{fl/1e9:.2f} GF]",
-                      lambda fp=fp, unknown=unknown, known=known, uf=uf, kf=kf, head=head: fused.fp_forward(fp, unknown, known, uf, kf, head=head), fl))
-        r = fused.fp_forward(fp, unknown, known, uf, kf, head=head)
+                      lambda fp=fp, unknown=unknown, known=known, uf=uf, kf=kf, head=head, ug=ug: fused.fp_forward(fp, unknown, known, uf, kf, head=head, unknown_grid=ug), fl))
+        r = fused.fp_forward(fp, unknown, known, uf, kf, head=head, unknown_grid=ug)
         feats[i - 1] = r[0] if head is not None else r
     P_ = {k: torch.from_numpy(v).to(dev) for k, v in syn.smpl_like_params(seed=40).items()}
     betas, pose = [torch.from_numpy(a).to(dev) for a in syn.smpl_like_pose(B, seed=100)]

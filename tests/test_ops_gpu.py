@@ -324,3 +324,32 @@ def test_ball_query_lanes_kernel_equals_the_scan(B, N, P, order, monkeypatch):
         for a, b, r, n_ in zip(lanes, scan, radii, ns):
             assert np.array_equal(a, b), (order, sort, r)
             assert np.array_equal(a, K.ball_query(r, n_, xyz, q)), (order, sort, r)
+
+
+@pytest.mark.parametrize("B,n,m,kind", [(2, 8192, 1024, "fps"), (3, 5000, 2048, "rand"), (2, 4100, 333, "dup"), (2, 4500, 700, "nonfinite")])
+def test_three_nn_over_cell_ordered_queries_is_bit_exact(B, n, m, kind, contraction_mode):
+    """g4d_three_nn_cells_f32 (the scan with the queries taken in the cell order of the unknown cloud's ball grid, results scattered
+    back to their original positions) against the plain scan and the oracle: FPS subsets (the encoder's case), random known sets,
+    duplicates (distance ties), non-finite coordinates."""
+    from garment4d_amd import fused, _lib
+    rng = np.random.default_rng(n + m)
+    u = syn.unit_cloud(B, n, seed=n)
+    if kind == "fps":
+        k = np.stack([u[b][K.fps(u[b:b + 1], m)[0]] for b in range(B)])
+    elif kind == "dup":
+        k = np.repeat(u[:, :(m + 2) // 3], 3, axis=1)[:, :m].copy()
+    else:
+        k = rng.random((B, m, 3)).astype(np.float32)
+    if kind == "nonfinite":
+        u[0, 5] = np.nan; u[1, 7, 0] = np.inf; k[0, 3] = np.nan; k[1, 9, 2] = -np.inf
+    ud, kd = dev(u), dev(np.ascontiguousarray(k))
+    grid = fused.build_ball_grid(ud, 0.2)
+    d2 = torch.full((B, n, 3), -7.0, device="cuda"); ix = torch.full((B, n, 3), -7, dtype=torch.int32, device="cuda")
+    _lib.call("g4d_three_nn_cells_f32", B, n, m, ud.data_ptr(), grid[0].data_ptr(), kd.data_ptr(), d2.data_ptr(), ix.data_ptr(), _lib.stream_ptr())
+    d2s, ixs = fused.three_nn(ud, kd, grid=False)
+    assert torch.equal(ix, ixs)
+    assert torch.equal(torch.nan_to_num(d2, nan=-1.0), torch.nan_to_num(d2s, nan=-1.0))
+    if kind != "nonfinite":
+        wd, wi = K.three_nn(u, np.ascontiguousarray(k))
+        assert np.array_equal(host(ix), wi)
+        np.testing.assert_array_equal(np.sqrt(host(d2)), wd)
