@@ -143,6 +143,20 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
         ctx[mt] = make_ctx<MODE>(a, rowc[mt]);
     }
     zero_acc<TOUT, MT>(acc);
+    if constexpr (MODE == LOAD_INTERP && !LAST) {
+        if (a.tab) {   // wave-uniform: conv(sum_i w_i f_i) = sum_i w_i conv(f_i) -- the known-feature part of this layer, per known row, interpolated
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ct = 0; ct < TOUT; ++ct) {   // transposed tile: this lane holds channels 16 ct + 4 fq .. + 3 of row fi
+                    const int ch = ct * 16 + fq * 4;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4u *>(a.tab + ctx[mt].k0 + ch), t1 = *reinterpret_cast<const f32x4u *>(a.tab + ctx[mt].k1 + ch),
+                                t2 = *reinterpret_cast<const f32x4u *>(a.tab + ctx[mt].k2 + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[ct][mt][e] = ctx[mt].w0 * t0[e] + ctx[mt].w1 * t1[e] + ctx[mt].w2 * t2[e];
+                }
+        }
+    }
     const int kst0 = (a.K + 15) >> 4;
     // segment A: columns [a_lo, a_hi) come from pa[mt] + column (GROUP: the feature row behind the 3 xyz columns; DIRECT: the
     // row; INTERP: the three known rows, blended); segment B (INTERP only): columns [C2, K) from the skip row
@@ -425,7 +439,12 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
     s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
     s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
     G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
-    if (tab) {
+    if (tab && mode == LOAD_INTERP) {
+        G4D_REQUIRE(C2 == 0 && C1 > 0 && K0 == C1 && skip && nlayers >= 2 && Cout[0] % 16 == 0 && tab_ld >= Cout[0] && tab_ld % 4 == 0 &&
+                    (reinterpret_cast<size_t>(tab) & 15) == 0 && !pre_scale, "g4d_mlp_chain_interp_init_f32: needs skip features, >= 2 layers, a first-layer width that "
+                    "is a multiple of 16 and a 16-byte aligned table at least that wide");
+        s.in.tab = tab; s.in.tab_ld = tab_ld;
+    } else if (tab) {
         G4D_REQUIRE(mode == LOAD_GROUP && K0 % 16 == 0 && tab_ld >= K0 && tab_ld % 4 == 0 && (reinterpret_cast<size_t>(tab) & 15) == 0 && tab_wx && pre_scale &&
                     pre_shift && xyz && new_xyz && idx, "g4d_mlp_chain_group_table_f32: needs a 16-byte aligned table whose width is a multiple of 16, the xyz "
                     "weights, the affine and the grouping inputs");
@@ -528,4 +547,20 @@ extern "C" int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S
     return chain_f32_impl(LOAD_GROUP, rows, Kt, nullptr, 0, N, P, S, 0, 1, xyz, new_xyz, nullptr, idx, 0, 0, 0, 0, nullptr, nullptr, nullptr,
                           nullptr, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, -1, nullptr, 0, pre_scale, pre_shift, nullptr, 0,
                           table, tab_ld, tab_wx, stream);
+}
+
+// Feature propagation WITH skip features, the known-feature part of the first layer pre-contracted (pointnet2_modules.py:127-156):
+//   W [interp(f) ; s] = Wa interp(f) + Wb s = interp(Wa f) + Wb s
+// -- `table` (B*m rows, stride tab_ld) = known features times Wa^T (m rows per cloud instead of n); the first layer's accumulators start
+// from three_interpolate(table) and the matrix pipe adds the C1 skip columns; layer 0 of W / Kpad describes Wb (K = C1), scale / shift /
+// relu of layer 0 are the layer's own.  Everything else as g4d_mlp_chain_f32 in its interpolating mode.
+extern "C" int g4d_mlp_chain_interp_init_f32(long long rows, int n, int m, int C1, const float *skip, const float *table, int tab_ld,
+                                             const float *dist2, const int *nn_idx, int nlayers, const float *const *W,
+                                             const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
+                                             const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
+                                             g4d_stream_t stream) {
+    G4D_REQUIRE(table && skip && dist2 && nn_idx, "g4d_mlp_chain_interp_init_f32: null pointer");
+    return chain_f32_impl(LOAD_INTERP, rows, C1, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, 0, C1, nullptr, skip, dist2,
+                          nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, nullptr, nullptr,
+                          nullptr, 0, table, tab_ld, nullptr, stream);
 }

@@ -40,6 +40,9 @@ struct LinearArgs {
     const float *pre_scale, *pre_shift;
     float *in_tap;
     int in_tap_ld;
+    // INTERP WITH skip features (register-chain kernel only, C2 == 0 in these arguments): `tab` (stride tab_ld) holds the known features
+    // already multiplied by the known-feature columns of the first layer's weight; the first layer's accumulators START from
+    // three_interpolate(tab) and the matrix pipe adds the skip columns (K = C1).
     // GROUP over a pre-contracted table (register-chain kernel only): row j of `tab` (stride tab_ld) holds the feature part of the
     // first layer for source point j; the loader's row is relu((tab[j] + tab_wx . (x_j - q)) * pre_scale + pre_shift), tab_wx = [3][K]
     const float *tab, *tab_wx;
@@ -85,9 +88,10 @@ __device__ __forceinline__ RowCtx<MODE> make_ctx(const LinearArgs &a, int row) {
                     r2 = 1.0f / (__fsqrt_rn(d2[2]) + 1e-8f);
         const float norm = (r0 + r1) + r2;
         c.w0 = r0 / norm; c.w1 = r1 / norm; c.w2 = r2 / norm;
-        c.k0 = ((size_t)b * a.m + ix[0]) * a.C2;
-        c.k1 = ((size_t)b * a.m + ix[1]) * a.C2;
-        c.k2 = ((size_t)b * a.m + ix[2]) * a.C2;
+        const size_t ks = (a.tab && a.C2 == 0) ? (size_t)a.tab_ld : (size_t)a.C2;   // register-chain kernel with an accumulator-init table: offsets into it
+        c.k0 = ((size_t)b * a.m + ix[0]) * ks;
+        c.k1 = ((size_t)b * a.m + ix[1]) * ks;
+        c.k2 = ((size_t)b * a.m + ix[2]) * ks;
         c.sk = (size_t)row * a.C1;
     } else if constexpr (MODE == LOAD_CSR) {
         c.f = row / a.Vg;

@@ -718,6 +718,31 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
                       ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p),
                       final.view(B * n, -1).data_ptr(), final.shape[-1], 0, tap_layer, _ptr(tap_t), 0 if tap_t is None else tap_t.shape[-1], stream)
             return (out, final) if head is not None else out
+    if (FP_TABLE and C1 > 0 and head is None and len(layers) >= 2 and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN
+            and m < n and chain_fits(layers, 0, 1, 2)):
+        # Skip features: W [interp(f) ; s] = interp(Wa f) + Wb s -- the known-feature columns of the first layer are contracted over the
+        # m KNOWN rows (table), the first layer's accumulators start from the interpolated table and the matrix pipe adds the skip columns.
+        key = id(layers[0])
+        hit = getattr(fp, "_g4d_fp_split", None)
+        if hit is None or hit[0] != key:
+            L0 = layers[0]
+            with torch.no_grad():
+                W0 = L0.W[:L0.Cout, :L0.K]
+                ones, zeros = torch.ones(L0.Cout, device=W0.device), torch.zeros(L0.Cout, device=W0.device)
+                La = PackedLayer(W0[:, :C2].contiguous(), ones, zeros, relu=False)
+                Lb = PackedLayer(W0[:, C2:C2 + C1].contiguous(), L0.scale[:L0.Cout], L0.shift[:L0.Cout], relu=bool(L0.relu))
+            hit = (key, La, Lb, L0)   # L0 kept alive: its id is the key
+            fp._g4d_fp_split = hit
+        _, La, Lb, _ = hit
+        table = linear(known_feats_pm.view(B * m, C2), La)
+        rest = [Lb] + layers[1:]
+        PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
+        _lib.call("g4d_mlp_chain_interp_init_f32", B * n, n, m, C1, unknow_feats_pm.data_ptr(), table.data_ptr(), table.shape[-1], dist2.data_ptr(),
+                  nn_idx.data_ptr(), len(rest), ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p),
+                  ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p),
+                  ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p),
+                  ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p), out.view(B * n, -1).data_ptr(), out.shape[-1], 0, -1, 0, 0, stream)
+        return out
     if head is not None:
         # FP stack + FC head in one launch; the FP output is tapped to HBM (it is returned to the caller too)
         hl = pack_conv_stack(head)

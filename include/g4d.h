@@ -378,6 +378,17 @@ int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const flo
 int g4d_three_nn_cells_f32(int b, int n, int m, const float *unknown, const void *unknown_grid, const float *known, float *dist2, int *idx,
                            g4d_stream_t stream);
 
+/* Feature propagation WITH skip features, the known-feature part of its first layer pre-contracted (pointnet2_modules.py:127-156):
+ *   W [interp(f) ; s] = Wa interp(f) + Wb s = interp(Wa f) + Wb s.
+ * `table` (B*m rows, row stride tab_ld floats, 16-byte aligned) = known features times Wa^T -- one g4d_linear_f32 over the m known rows
+ * per cloud (scale 1, shift 0, no ReLU); the first layer's accumulators start from three_interpolate(table) and the matrix pipe adds the
+ * C1 skip columns.  Layer 0 of W / Kpad describes Wb (K = C1, fragment order), its scale / shift / relu are the layer's own; >= 2
+ * layers, Cout[0] a multiple of 16; widths per g4d_mlp_chain_supported.  Everything else as g4d_mlp_chain_f32 (mode 2). */
+int g4d_mlp_chain_interp_init_f32(long long rows, int n, int m, int C1, const float *skip, const float *table, int tab_ld, const float *dist2,
+                                  const int *nn_idx, int nlayers, const float *const *W, const float *const *scale,
+                                  const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo, int col0,
+                                  int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

@@ -491,3 +491,33 @@ def test_sa_with_features_on_the_per_source_point_table(B, N, P, C, mlps, nsampl
         sd = {k: v.cpu().numpy() for k, v in sa.state_dict().items()}
         _, f = MO.sa_module(xyz.cpu().numpy(), feats.cpu().numpy(), P, [g.radius for g in sa.groupers], nsamples, sd, pool=pool)
         np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), f, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(8, 1024, 256, 256, 96, [352, 256, 128]), (2, 700, 99, 64, 35, [99, 128, 128]), (1, 300, 40, 32, 16, [48, 64, 64]),
+                                             (3, 2000, 500, 128, 128, [256, 128, 64])])
+def test_fp_with_skip_features_on_the_interpolated_table(B, n, m, C2, C1, mlp, monkeypatch):
+    """FP levels WITH skip features whose stack fits the register-chain kernel: the known-feature columns of the first layer are contracted
+    over the m known rows, the accumulators start from the interpolated table and the matrix pipe adds the skip columns
+    (g4d_mlp_chain_interp_init_f32) -- against the op-by-op module, the fused path without the table and the oracle (smallest case)."""
+    torch.manual_seed(n + C1)
+    unknown = dev(syn.unit_cloud(B, n, seed=n))
+    known = unknown[:, :m].contiguous() + 0.01 * torch.randn(B, m, 3, device="cuda")
+    kf, uf = torch.randn(B, C2, m, device="cuda"), torch.randn(B, C1, n, device="cuda")
+    fp = PM.PointnetFPModule(mlp=list(mlp)).cuda()
+    for mod in fp.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5); mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.1)
+    fp.eval()
+    outs = {}
+    with torch.no_grad():
+        want = fp(unknown, known, uf, kf)
+        for table in (True, False):
+            monkeypatch.setattr(fused, "FP_TABLE", table)
+            outs[table] = fused.fp_forward(fp, unknown, known, fused.to_point_major(uf), fused.to_point_major(kf))
+    np.testing.assert_allclose(outs[True].cpu().numpy(), outs[False].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if n <= 300:
+        from oracle import modules_oracle as MO
+        sd = {k: v.cpu().numpy() for k, v in fp.state_dict().items()}
+        f = MO.fp_module(unknown.cpu().numpy(), known.cpu().numpy(), uf.cpu().numpy(), kf.cpu().numpy(), sd)
+        np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), f, rtol=1e-5, atol=1e-5)
