@@ -756,7 +756,9 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
     elif layers[0].Cout > 64:
         # wide FP level: every 64-channel tile of the first layer would redo the interpolation -> materialise the
-        # interpolated + concatenated rows once (a few MB), then plain DIRECT layers
+        # interpolated + concatenated rows once (a few MB), then plain DIRECT layers.  (Splitting the first layer here too -- table over
+        # the known rows, its interpolation added in the LDS-tiled kernel's epilogue, skip columns only on the matrix pipe: 35 % fewer
+        # flops but one more launch on 2048 rows -- measured 45.3 -> 47.1 us alone, 27.0 -> 27.3 us per step with 16 in flight: not kept.)
         x = torch.empty((B * n, C2 + C1), dtype=torch.float32, device=unknown.device)
         _lib.call("g4d_interp_concat_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm), dist2.data_ptr(),
                   nn_idx.data_ptr(), x.data_ptr(), stream)
