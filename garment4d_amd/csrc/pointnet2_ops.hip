@@ -75,15 +75,13 @@ __device__ __forceinline__ void nn_insert_lex(float d, int k, float &b1, float &
 }
 
 template <int FM>
-__global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
-                                                      const float *__restrict__ known_all, float *__restrict__ dist2_all,
-                                                      int *__restrict__ idx_all) {
+__device__ __forceinline__ void three_nn_body(int n, int m, const float *__restrict__ unknown_all, const float *__restrict__ known_all,
+                                              float *__restrict__ dist2_all, int *__restrict__ idx_all, int bx, int b) {
     __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];  // SoA: 4 points per ds_read_b128
     __shared__ float sd[3][64][3];
     __shared__ int si[3][64][3];
-    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+    const int p = bx * 64 + lane;
     const float *known = known_all + (size_t)b * m * 3;
     const int pc = min(p, n - 1);
     const float *u = unknown_all + ((size_t)b * n + pc) * 3;
@@ -140,6 +138,38 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
             ix[0] = i1; ix[1] = i2; ix[2] = i3;
         }
     }
+}
+
+template <int FM>
+__global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
+                                                      const float *__restrict__ known_all, float *__restrict__ dist2_all,
+                                                      int *__restrict__ idx_all) {
+    three_nn_body<FM>(n, m, unknown_all, known_all, dist2_all, idx_all, blockIdx.x, blockIdx.y);
+}
+
+// Several small three_nn problems of the same batch in ONE launch (the inner feature-propagation levels: 256 <- 64 and 1024 <- 256 points
+// are a few microseconds of work each, and every launch costs the 16-batch mix 3-5 us): blockIdx.x runs over the problems' 64-query tiles.
+struct NNMulti {
+    int count;
+    int n[4], m[4], blk_end[4];
+    const float *unknown[4], *known[4];
+    float *dist2[4];
+    int *idx[4];
+};
+template <int FM>
+__global__ void __launch_bounds__(256) three_nn_multi_kernel(const NNMulti q) {
+    int k = 0, first = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (k == i && k + 1 < q.count && (int)blockIdx.x >= q.blk_end[i]) { first = q.blk_end[i]; k = i + 1; }
+    // the problem index is block-uniform; the selects below keep the pointers in scalar registers
+    const int n = k == 0 ? q.n[0] : (k == 1 ? q.n[1] : (k == 2 ? q.n[2] : q.n[3]));
+    const int m = k == 0 ? q.m[0] : (k == 1 ? q.m[1] : (k == 2 ? q.m[2] : q.m[3]));
+    const float *u = k == 0 ? q.unknown[0] : (k == 1 ? q.unknown[1] : (k == 2 ? q.unknown[2] : q.unknown[3]));
+    const float *kn = k == 0 ? q.known[0] : (k == 1 ? q.known[1] : (k == 2 ? q.known[2] : q.known[3]));
+    float *d2 = k == 0 ? q.dist2[0] : (k == 1 ? q.dist2[1] : (k == 2 ? q.dist2[2] : q.dist2[3]));
+    int *ix = k == 0 ? q.idx[0] : (k == 1 ? q.idx[1] : (k == 2 ? q.idx[2] : q.idx[3]));
+    three_nn_body<FM>(n, m, u, kn, d2, ix, (int)blockIdx.x - first, blockIdx.y);
 }
 
 // Variant for large unknown sets (n >= 4096: the last feature-propagation level): a wave owns 64 unknown points and scans ALL known
@@ -408,6 +438,25 @@ extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const
     dim3 grid((n + 63) / 64, b);
     G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_kernel<FM>, grid, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx))
     return check_launch("g4d_three_nn_f32");
+}
+
+// Up to four three_nn problems of the same batch size in one launch (three_nn_multi_kernel); each result identical to g4d_three_nn_f32.
+extern "C" int g4d_three_nn_multi_f32(int b, int count, const int *n, const int *m, const float *const *unknown, const float *const *known,
+                                      float *const *dist2, int *const *idx, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && b <= 65535 && count >= 1 && count <= 4 && n && m && unknown && known && dist2 && idx, "g4d_three_nn_multi_f32: bad arguments (1..4 problems)");
+    if (b == 0) return G4D_OK;
+    NNMulti q = {};
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        G4D_REQUIRE(n[i] > 0 && m[i] > 0 && unknown[i] && known[i] && dist2[i] && idx[i], "g4d_three_nn_multi_f32: problem %d: empty or null", i);
+        q.n[i] = n[i]; q.m[i] = m[i]; q.unknown[i] = unknown[i]; q.known[i] = known[i]; q.dist2[i] = dist2[i]; q.idx[i] = idx[i];
+        blocks += (n[i] + 63) / 64;
+        q.blk_end[i] = blocks;
+    }
+    q.count = count;
+    dim3 grid((unsigned)blocks, (unsigned)b);
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_multi_kernel<FM>, grid, dim3(256), 0, G4D_STREAM(stream), q))
+    return check_launch("g4d_three_nn_multi_f32");
 }
 
 // three_nn with the ball-grid workspace of the UNKNOWN cloud at hand (g4d_ball_grid_build_f32 on `unknown`, any radius): the same scan,

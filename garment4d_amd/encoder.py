@@ -109,8 +109,13 @@ class Pointnet2MSGSEG(nn.Module):
                 l_feats.append(nf)
         middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None
         nfp = len(self.FP_modules)
+        # the three-NN searches of the inner FP levels depend on the sampled coordinates only and are microseconds of work each: one launch
+        inner = [i for i in range(-1, -nfp, -1) if l_xyz[i - 1].shape[1] < 4096]
+        pre = {}
+        if fused.NN_MULTI and 2 <= len(inner) <= 4:
+            pre = dict(zip(inner, fused.three_nn_multi([(l_xyz[i - 1], l_xyz[i]) for i in inner])))
         for i in range(-1, -nfp, -1):
-            l_feats[i - 1] = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
+            l_feats[i - 1] = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn=pre.get(i))
         # last FP level + FC head share one launch (the FP features are tapped out for the caller)
         l_feats[0], sem_logits = fused.fp_forward(self.FP_modules[0], l_xyz[0], l_xyz[1], l_feats[0], l_feats[1],
                                                   head=self.FC_layer, unknown_grid=grid0)  # logits (B, N, classes)

@@ -663,10 +663,30 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=No
     return dist2, nn_idx
 
 
+NN_MULTI = os.environ.get("G4D_NN_MULTI", "1") != "0"   # the small three_nn searches of the inner FP levels in one launch
+
+
+def three_nn_multi(pairs):
+    """[(unknown (B,n_i,3), known (B,m_i,3)), ...] (up to 4, same B) -> [(dist2, idx), ...] in one launch (g4d_three_nn_multi_f32);
+    each result equals three_nn(unknown, known)."""
+    assert 1 <= len(pairs) <= 4
+    B = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    outs = [(torch.empty((B, _chk(u).shape[1], 3), dtype=torch.float32, device=dev), torch.empty((B, u.shape[1], 3), dtype=torch.int32, device=dev))
+            for u, k in pairs]
+    c = len(pairs)
+    IA, PA = ctypes.c_int * c, ctypes.c_void_p * c
+    _lib.call("g4d_three_nn_multi_f32", B, c, ctypes.cast(IA(*[u.shape[1] for u, k in pairs]), ctypes.c_void_p),
+              ctypes.cast(IA(*[_chk(k).shape[1] for u, k in pairs]), ctypes.c_void_p), ctypes.cast(PA(*[u.data_ptr() for u, k in pairs]), ctypes.c_void_p),
+              ctypes.cast(PA(*[k.data_ptr() for u, k in pairs]), ctypes.c_void_p), ctypes.cast(PA(*[o[0].data_ptr() for o in outs]), ctypes.c_void_p),
+              ctypes.cast(PA(*[o[1].data_ptr() for o in outs]), ctypes.c_void_p), _lib.stream_ptr())
+    return outs
+
+
 FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
 
 
-def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, unknown_grid=None):
+def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, unknown_grid=None, nn=None):
     """Fused PointnetFPModule.forward (pointnet2_modules.py:127-156), eval mode; all features point-major:
     unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout).
     With `head` (an FC stack of Conv1d blocks) returns (features, head(features)), fused into the same launch when
@@ -689,7 +709,9 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
         return out if head is None else (out, conv_stack_forward(head, out))
     m = known.shape[1]
     C2 = known_feats_pm.shape[2]
-    dist2, nn_idx = three_nn(unknown, known, unknown_grid=unknown_grid)   # unknown_grid: build_ball_grid(unknown, ...) of an earlier SA level, if any
+    # nn: (dist2, idx) of three_nn(unknown, known) computed by the caller (three_nn_multi); unknown_grid: build_ball_grid(unknown, ...) of an
+    # earlier SA level, if any
+    dist2, nn_idx = nn if nn is not None else three_nn(unknown, known, unknown_grid=unknown_grid)
 
     def first(L, pl, o, c0):
         _lib.call("g4d_interp_linear_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm),

@@ -389,6 +389,12 @@ int g4d_mlp_chain_interp_init_f32(long long rows, int n, int m, int C1, const fl
                                   const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo, int col0,
                                   int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream);
 
+/* Up to four three_nn problems (interpolate_gpu.cu:9-52) of the same batch size b in ONE launch: n[i] unknown / m[i] known points per
+ * cloud, unknown[i] (b, n[i], 3), known[i] (b, m[i], 3), dist2[i] / idx[i] (b, n[i], 3).  Each result is identical to g4d_three_nn_f32's.
+ * For the inner feature-propagation levels, whose searches are microseconds of work: a launch saved is 3-5 us of the 16-batch mix. */
+int g4d_three_nn_multi_f32(int b, int count, const int *n, const int *m, const float *const *unknown, const float *const *known,
+                           float *const *dist2, int *const *idx, g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

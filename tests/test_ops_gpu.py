@@ -353,3 +353,16 @@ def test_three_nn_over_cell_ordered_queries_is_bit_exact(B, n, m, kind, contract
         wd, wi = K.three_nn(u, np.ascontiguousarray(k))
         assert np.array_equal(host(ix), wi)
         np.testing.assert_array_equal(np.sqrt(host(d2)), wd)
+
+
+def test_three_nn_multi_equals_separate_searches(contraction_mode):
+    """g4d_three_nn_multi_f32: several small problems of one batch in a single launch, each bit-identical to its own g4d_three_nn_f32."""
+    from garment4d_amd import fused
+    B = 3
+    shapes = [(256, 64), (1024, 256), (100, 3), (65, 1000)]
+    pairs = [(dev(syn.unit_cloud(B, n, seed=n)), dev(syn.unit_cloud(B, m, seed=m + 7))) for n, m in shapes]
+    for cnt in (1, 2, 4):
+        res = fused.three_nn_multi(pairs[:cnt])
+        for (u, k), (d2, ix) in zip(pairs[:cnt], res):
+            d2s, ixs = fused.three_nn(u, k, grid=False)
+            assert torch.equal(ix, ixs) and torch.equal(d2, d2s)
