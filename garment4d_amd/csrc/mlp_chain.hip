@@ -408,6 +408,7 @@ extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
         case 1010200: case 2020400: case 4040800: case 8081600:     // 16-16-32, 32-32-64, 64-64-128, 128-128-256
         case 2020000: case 4040000: case 8080000: case 8040000:     // 32-32, 64-64, 128-128, 128-64
         case 16080000:                                              // 256-128 (the middle feature-propagation level)
+        case 16080800:                                              // 256-128-128: ... followed by the next level's first-layer table
         case 1000000: case 2000000: case 4000000: case 8000000:     // single layers up to 128
         case 16000000:                                              // ... and 256 (behind a pre-contracted first layer)
         case 8040201:                                               // 128-64-32-(<=16): last FP level + segmentation head
@@ -490,6 +491,7 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
         case 8080000: G4D_CHAIN(8, 8, 0, 0)
         case 8040000: G4D_CHAIN(8, 4, 0, 0)
         case 16080000: G4D_CHAIN(16, 8, 0, 0)
+        case 16080800: G4D_CHAIN(16, 8, 8, 0)
         case 1000000: G4D_CHAIN(1, 0, 0, 0)
         case 2000000: G4D_CHAIN(2, 0, 0, 0)
         case 4000000: G4D_CHAIN(4, 0, 0, 0)

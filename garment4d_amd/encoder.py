@@ -114,11 +114,22 @@ class Pointnet2MSGSEG(nn.Module):
         pre = {}
         if fused.NN_MULTI and 2 <= len(inner) <= 4:
             pre = dict(zip(inner, fused.three_nn_multi([(l_xyz[i - 1], l_xyz[i]) for i in inner])))
+        # the last FP level has no skip features: its first layer is a table over ITS known rows = the output rows of the level before,
+        # which that level's chain launch can produce as one more layer
+        nxt_raw = None
+        if nfp > 1:
+            nxt_raw = fused.fp_table_layer(self.FP_modules[0], 0 if l_feats[0] is None else l_feats[0].shape[2],
+                                           fused.pack_conv_stack(self.FP_modules[1].mlp)[-1].Cout, self.FC_layer)
+        table0 = None
         for i in range(-1, -nfp, -1):
-            l_feats[i - 1] = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn=pre.get(i))
+            r = fused.fp_forward(self.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn=pre.get(i),
+                                 also_table=nxt_raw if i == -nfp + 1 else None)
+            if isinstance(r, tuple):
+                r, table0 = r
+            l_feats[i - 1] = r
         # last FP level + FC head share one launch (the FP features are tapped out for the caller)
         l_feats[0], sem_logits = fused.fp_forward(self.FP_modules[0], l_xyz[0], l_xyz[1], l_feats[0], l_feats[1],
-                                                  head=self.FC_layer, unknown_grid=grid0)  # logits (B, N, classes)
+                                                  head=self.FC_layer, unknown_grid=grid0, table=table0)  # logits (B, N, classes)
         if channel_major:
             l_feats = [None if f is None else fused.to_channel_major(f) for f in l_feats]
             middle = None if middle is None else fused.to_channel_major(middle)

@@ -259,7 +259,7 @@ def stack_fits(layers, pool, S, rows=None):
 
 USE_CHAIN = os.environ.get("G4D_MLP_CHAIN", "1") != "0"
 _CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (16, 8), (1,), (2,), (4,), (8,), (8, 4, 2, 1),
-                (4, 2, 1), (2, 4), (4, 8), (8, 16), (16,)}
+                (4, 2, 1), (2, 4), (4, 8), (8, 16), (16,), (16, 8, 8)}
 
 
 def chain_fits(layers, pool, S, mode):
@@ -686,7 +686,20 @@ def three_nn_multi(pairs):
 FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
 
 
-def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, unknown_grid=None, nn=None):
+def fp_table_layer(fp, C1, C2, head):
+    """The raw first layer (PackedLayer, scale 1 / shift 0 / no ReLU) of an FP level that fp_forward would run on a pre-contracted table
+    (no skip features), or None: a caller that produces this level's known features with another chain launch can append it there as one
+    more layer (fp_forward(..., also_table=...)) and hand the result back as table=."""
+    layers = pack_conv_stack(fp.mlp)
+    if not (FP_TABLE and C1 == 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN):
+        return None
+    rest = layers[1:] + (pack_conv_stack(head) if head is not None else [])
+    if not rest or not _lib.lib().g4d_mlp_chain_supported(len(rest), (ctypes.c_int * len(rest))(*[L.Cout for L in rest])):
+        return None
+    return layers[0].raw()
+
+
+def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, unknown_grid=None, nn=None, table=None, also_table=None):
     """Fused PointnetFPModule.forward (pointnet2_modules.py:127-156), eval mode; all features point-major:
     unknown (B,n,3), known (B,m,3)|None, unknow_feats_pm (B,n,C1)|None, known_feats_pm (B,m,C2) -> (B,n,Cout).
     With `head` (an FC stack of Conv1d blocks) returns (features, head(features)), fused into the same launch when
@@ -725,7 +738,9 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
         rest = layers[1:] + (pack_conv_stack(head) if head is not None else [])
         if rest and _lib.lib().g4d_mlp_chain_supported(len(rest), (ctypes.c_int * len(rest))(*[L.Cout for L in rest])):
             L0 = layers[0]
-            table = linear(known_feats_pm.view(B * m, C2), L0.raw())
+            if table is None:   # (else: computed by the launch that produced known_feats_pm, fp_forward(..., also_table=fp_table_layer(...)))
+                table = linear(known_feats_pm.view(B * m, C2), L0.raw())
+            assert table.shape == (B * m, L0.Cout)
             nl = len(layers)
             final = torch.empty((B, n, rest[-1].Cout), dtype=torch.float32, device=unknown.device) if head is not None else out
             PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
@@ -758,13 +773,20 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
         _, La, Lb, _ = hit
         table = linear(known_feats_pm.view(B * m, C2), La)
         rest = [Lb] + layers[1:]
+        tapl, tap_t, fin = -1, None, out.view(B * n, -1)
+        if also_table is not None and also_table.K == layers[-1].Cout and chain_fits(rest + [also_table], 0, 1, 2):
+            # one more layer behind the stack: the NEXT level's first-layer table over this level's output rows; the output itself is tapped
+            rest = rest + [also_table]
+            tapl, tap_t = len(rest) - 2, out.view(B * n, -1)
+            fin = torch.empty((B * n, also_table.Cout), dtype=torch.float32, device=unknown.device)
         PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
         _lib.call("g4d_mlp_chain_interp_init_f32", B * n, n, m, C1, unknow_feats_pm.data_ptr(), table.data_ptr(), table.shape[-1], dist2.data_ptr(),
                   nn_idx.data_ptr(), len(rest), ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p),
                   ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p),
                   ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p),
-                  ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p), out.view(B * n, -1).data_ptr(), out.shape[-1], 0, -1, 0, 0, stream)
-        return out
+                  ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p), fin.data_ptr(), fin.shape[-1], 0, tapl, _ptr(tap_t),
+                  0 if tap_t is None else tap_t.shape[-1], stream)
+        return (out, fin) if tap_t is not None else out
     if head is not None:
         # FP stack + FC head in one launch; the FP output is tapped to HBM (it is returned to the caller too)
         hl = pack_conv_stack(head)
