@@ -70,13 +70,12 @@ __global__ void __launch_bounds__(256) ball_boxes_kernel(int n, int nblk, long l
 }
 
 template <int QW, int NS, int FM>
-__global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
-                                                        const float *__restrict__ xyz_all) {
+__device__ __forceinline__ void ball_query_body(int n, int m, const BqArgs &a, const float *__restrict__ new_xyz_all,
+                                                const float *__restrict__ xyz_all, int bx, int b) {
     __shared__ float sp[2][3][kStage];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * QW;
+    const int q0 = (bx * 4 + wave) * QW;
     const float *xyz = xyz_all + (size_t)b * n * 3;
     const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
 
@@ -173,6 +172,25 @@ __global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqA
         for (int s = 0; s < NS; ++s)
             if (q0 + i < m && cnt[i][s] < a.nsample[s])
                 for (int l = cnt[i][s] + lane; l < a.nsample[s]; l += 64) a.idx[s][((size_t)b * m + q0 + i) * a.nsample[s] + l] = first[i][s];
+}
+
+template <int QW, int NS, int FM>
+__global__ void __launch_bounds__(256) ball_query_kernel(int n, int m, const BqArgs a, const float *__restrict__ new_xyz_all,
+                                                        const float *__restrict__ xyz_all) {
+    ball_query_body<QW, NS, FM>(n, m, a, new_xyz_all, xyz_all, blockIdx.x, blockIdx.y);
+}
+
+// Two small ball queries of the same batch (the inner set-abstraction levels: 256 and 64 centroids per cloud) in ONE launch: a launch
+// costs the 16-batch mix 3-5 us, these searches are microseconds of work.  blockIdx.x runs over both problems' 4-query workgroups.
+struct BqMulti {
+    int n[2], m[2], blk0;
+    BqArgs a[2];
+    const float *new_xyz[2], *xyz[2];
+};
+template <int NS, int FM>
+__global__ void __launch_bounds__(256) ball_query_multi_kernel(const BqMulti q) {
+    if ((int)blockIdx.x < q.blk0) ball_query_body<1, NS, FM>(q.n[0], q.m[0], q.a[0], q.new_xyz[0], q.xyz[0], blockIdx.x, blockIdx.y);
+    else ball_query_body<1, NS, FM>(q.n[1], q.m[1], q.a[1], q.new_xyz[1], q.xyz[1], (int)blockIdx.x - q.blk0, blockIdx.y);
 }
 
 // Sub-block-culled ball query for index-coherent clouds (g4d_ball_query_boxes_f32: the body / garment queries of
@@ -553,4 +571,42 @@ extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample
     G4D_REQUIRE(new_xyz && xyz && idx, "g4d_ball_query_f32: null pointer");
     int *ip[1] = {idx};
     return g4d_ball_query_msg_f32(b, n, m, 1, &radius, &nsample, new_xyz, xyz, ip, stream);
+}
+
+// Two ball queries (same batch size, same number of scales) in one launch; each output identical to g4d_ball_query_msg_f32's.
+extern "C" int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0,
+                                       const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1,
+                                       const float *new_xyz1, const float *xyz1, int *const *idx1, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && b <= 65535 && nscales >= 1 && nscales <= 4 && n0 > 0 && m0 > 0 && n1 > 0 && m1 > 0, "g4d_ball_query_msg2_f32: bad sizes");
+    G4D_REQUIRE(radii0 && nsamples0 && new_xyz0 && xyz0 && idx0 && radii1 && nsamples1 && new_xyz1 && xyz1 && idx1, "g4d_ball_query_msg2_f32: null pointer");
+    if (b == 0) return G4D_OK;
+    BqMulti q = {};
+    const int ns[2] = {n0, n1}, ms[2] = {m0, m1};
+    const float *rr[2] = {radii0, radii1};
+    const int *nsm[2] = {nsamples0, nsamples1};
+    int *const *ix[2] = {idx0, idx1};
+    for (int k = 0; k < 2; ++k) {
+        q.n[k] = ns[k]; q.m[k] = ms[k];
+        for (int s = 0; s < nscales; ++s) {
+            G4D_REQUIRE(nsm[k][s] > 0 && ix[k][s], "g4d_ball_query_msg2_f32: bad scale %d of problem %d", s, k);
+            q.a[k].radius2[s] = rr[k][s] * rr[k][s];
+            q.a[k].radius2_max = s == 0 ? q.a[k].radius2[0] : (q.a[k].radius2[s] > q.a[k].radius2_max ? q.a[k].radius2[s] : q.a[k].radius2_max);
+            q.a[k].nsample[s] = nsm[k][s];
+            q.a[k].idx[s] = ix[k][s];
+        }
+    }
+    q.new_xyz[0] = new_xyz0; q.xyz[0] = xyz0; q.new_xyz[1] = new_xyz1; q.xyz[1] = xyz1;
+    q.blk0 = (m0 + 3) / 4;
+    dim3 grid((unsigned)(q.blk0 + (m1 + 3) / 4), (unsigned)b);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define G4D_BQ2(NSV) G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((ball_query_multi_kernel<NSV, FM>), grid, dim3(256), 0, st, q))
+    switch (nscales) {
+        case 1: G4D_BQ2(1) break;
+        case 2: G4D_BQ2(2) break;
+        case 3: G4D_BQ2(3) break;
+        default: G4D_BQ2(4) break;
+    }
+#undef G4D_BQ2
+    return check_launch("g4d_ball_query_msg2_f32");
 }

@@ -97,6 +97,18 @@ class Pointnet2MSGSEG(nn.Module):
                 l_xyz.append(nx)
                 l_feats.append(nf)
         else:
+            # Sampling depends on the coordinates only (level l samples the centroids of level l-1): with the whole FPS chain first, the
+            # ball queries of the two small inner levels can share one launch.
+            SAs = list(self.SA_modules)
+            pre_nx, pre_idx = {}, {}
+            if (fused.BQ_MULTI and len(SAs) == 3 and all(sa.npoint is not None for sa in SAs) and SAs[0].npoint < fused.GRID_MIN_N
+                    and len(SAs[1].groupers) == len(SAs[2].groupers) <= 4):
+                src = xyz
+                for li, sa in enumerate(SAs):
+                    src = pre_nx[li] = fused.fps_gather(src, sa.npoint)
+                pre_idx[1], pre_idx[2] = fused.ball_query_msg2(
+                    ([g.radius for g in SAs[1].groupers], [g.nsample for g in SAs[1].groupers], pre_nx[0], pre_nx[1]),
+                    ([g.radius for g in SAs[2].groupers], [g.nsample for g in SAs[2].groupers], pre_nx[1], pre_nx[2]))
             for li, sa in enumerate(self.SA_modules):
                 grid = None
                 radii = [g.radius for g in sa.groupers]
@@ -104,7 +116,7 @@ class Pointnet2MSGSEG(nn.Module):
                     # the level-0 cloud's cell grid: the first level's ball query uses it, and so does the three-NN of the LAST
                     # feature-propagation level (same cloud as its unknown set)
                     grid0 = grid = fused.build_ball_grid(xyz, max(radii))
-                nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1], grid=grid)
+                nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1], new_xyz=pre_nx.get(li), grid=grid, idxs=pre_idx.get(li))
                 l_xyz.append(nx)
                 l_feats.append(nf)
         middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None

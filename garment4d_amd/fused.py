@@ -440,6 +440,25 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     return outs
 
 
+BQ_MULTI = os.environ.get("G4D_BQ_MULTI", "1") != "0"   # the ball queries of two small SA levels in one launch
+
+
+def ball_query_msg2(q0, q1):
+    """Two multi-scale ball queries in one launch: q = (radii, nsamples, xyz, new_xyz), same batch size and number of scales; returns the
+    two lists of (B,P,nsample) int32 tensors ball_query_msg would (g4d_ball_query_msg2_f32; scan route only)."""
+    (r0, s0, x0, c0), (r1, s1, x1, c1) = q0, q1
+    assert len(r0) == len(r1) and x0.shape[0] == x1.shape[0]
+    B, ns = x0.shape[0], len(r0)
+    o0 = [torch.empty((B, c0.shape[1], k), dtype=torch.int32, device=x0.device) for k in s0]
+    o1 = [torch.empty((B, c1.shape[1], k), dtype=torch.int32, device=x0.device) for k in s1]
+    FA, IA, PA = ctypes.c_float * ns, ctypes.c_int * ns, ctypes.c_void_p * ns
+    vp = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _lib.call("g4d_ball_query_msg2_f32", B, ns, x0.shape[1], c0.shape[1], vp(FA(*[float(r) for r in r0])), vp(IA(*[int(k) for k in s0])), _chk(c0).data_ptr(),
+              _chk(x0).data_ptr(), vp(PA(*[o.data_ptr() for o in o0])), x1.shape[1], c1.shape[1], vp(FA(*[float(r) for r in r1])), vp(IA(*[int(k) for k in s1])),
+              _chk(c1).data_ptr(), _chk(x1).data_ptr(), vp(PA(*[o.data_ptr() for o in o1])), _lib.stream_ptr())
+    return o0, o1
+
+
 def fps_gather(xyz, npoint, sidx=None, new_xyz=None):
     """new_xyz = xyz[furthest_point_sample(xyz, npoint)] (pointnet2_modules.py:32-35) -> (B,npoint,3).  `sidx` / `new_xyz`:
     optional pre-allocated outputs (the sampling chain of the encoder runs on a side stream into buffers owned by the main one)."""
@@ -574,7 +593,7 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
         _run_stack(first, layers, B * P * S, S, pool, out, col0, xyz.device)
 
 
-def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
+def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
     """Fused PointnetSAModule(MSG).forward (pointnet2_modules.py:19-55), eval mode.
     xyz (B,N,3); feats_pm (B,N,C) POINT-major or None  ->  (new_xyz (B,P,3)|None, feats (B,P,sum Cout) point-major).
     grid: passed to ball_query_msg (None = automatic, or a pre-built (workspace, rmax) pair)."""
@@ -592,7 +611,8 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None):
         P = new_xyz.shape[1]
         out = torch.empty((B, P, ctot), dtype=torch.float32, device=xyz.device)
         col0 = 0
-        idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, grid=grid)
+        if idxs is None:   # (else: the caller's ball_query_msg / ball_query_msg2 result for exactly these centroids)
+            idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, grid=grid)
         # scales whose first layer runs as a per-source-point table: one contraction of the level's features for all of them
         tab_scales = [k for k, (g, layers) in enumerate(zip(sa.groupers, packed))
                       if sa_table_fits(layers, C, int(g.use_xyz), pool, g.nsample, B * N, B * P * g.nsample)]

@@ -395,6 +395,13 @@ int g4d_mlp_chain_interp_init_f32(long long rows, int n, int m, int C1, const fl
 int g4d_three_nn_multi_f32(int b, int count, const int *n, const int *m, const float *const *unknown, const float *const *known,
                            float *const *dist2, int *const *idx, g4d_stream_t stream);
 
+/* Two ball queries (ball_query_gpu.cu:9-67) of the same batch size and the same number of scales in ONE launch -- the inner
+ * set-abstraction levels, whose searches are microseconds of work.  Arguments per problem as g4d_ball_query_msg_f32; each output is
+ * identical to that call's. */
+int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0,
+                            const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1,
+                            const float *new_xyz1, const float *xyz1, int *const *idx1, g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

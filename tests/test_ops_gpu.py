@@ -366,3 +366,15 @@ def test_three_nn_multi_equals_separate_searches(contraction_mode):
         for (u, k), (d2, ix) in zip(pairs[:cnt], res):
             d2s, ixs = fused.three_nn(u, k, grid=False)
             assert torch.equal(ix, ixs) and torch.equal(d2, d2s)
+
+
+def test_ball_query_msg2_equals_separate_queries(contraction_mode):
+    """g4d_ball_query_msg2_f32: the ball queries of two small levels in one launch, each bit-identical to its own g4d_ball_query_msg_f32."""
+    from garment4d_amd import fused
+    B = 3
+    x0, x1 = dev(syn.unit_cloud(B, 1024, seed=1)), dev(syn.unit_cloud(B, 256, seed=2))
+    c0, c1 = x0[:, :250].contiguous(), x1[:, :63].contiguous()
+    for radii0, ns0, radii1, ns1 in (([0.2, 0.4], [32, 64], [0.4, 0.8], [32, 64]), ([0.05], [16], [0.3], [8])):
+        a0, a1 = fused.ball_query_msg2((radii0, ns0, x0, c0), (radii1, ns1, x1, c1))
+        w0, w1 = fused.ball_query_msg(radii0, ns0, x0, c0, grid=False), fused.ball_query_msg(radii1, ns1, x1, c1, grid=False)
+        assert all(torch.equal(a, w) for a, w in zip(a0, w0)) and all(torch.equal(a, w) for a, w in zip(a1, w1))
