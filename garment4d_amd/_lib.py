@@ -72,6 +72,8 @@ SIGNATURES = {
     "g4d_mlp_chain_interp_init_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_three_nn_multi_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_ball_query_msg2_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_fps_gather_pair_supported": [_I, _I, _I],
+    "g4d_fps_gather_pair_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_lbs_one_supported": [_I, _I],
     "g4d_lbs_one_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_lbs_fused_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -174,6 +174,124 @@ __global__ void __launch_bounds__(64 * W) fps_reg_kernel(int n, int m, int bs, i
     }
 }
 
+// Two consecutive FPS levels in ONE launch (the encoder's 1024 -> 256 -> 64): level B samples the centroids level A has just picked, which
+// sit in this workgroup's LDS, so the second launch (3-5 us of the 16-batch mix, ~10 us of a single batch's latency) is not needed.
+// Stage A is fps_reg_kernel<4, UA, 1> (n = 256 UA = the reference's block size, no scratch), stage B fps_reg_kernel<1, UB, 1> run by wave 0
+// on the m1 = 64 UB picked points in pick order; same arithmetic, same tie-breaks, same outputs as the two launches.
+template <int UA, int UB, int FM>
+__global__ void __launch_bounds__(256) fps_reg_pair_kernel(int m2, const float *__restrict__ xyz_all, int *__restrict__ idx1_all,
+                                                          float *__restrict__ nx1_all, int *__restrict__ idx2_all, float *__restrict__ nx2_all) {
+    constexpr int T = 256, W = 4, nA = T * UA, bsA = nA, m1 = 64 * UB, bsB = m1;
+    constexpr int log2bsA = UA == 1 ? 8 : (UA == 2 ? 9 : 10), log2bsB = UB == 1 ? 6 : (UB == 2 ? 7 : (UB == 4 ? 8 : 9));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * 16);   // SoA copy of cloud A
+    float *sy = sx + nA;
+    float *sz = sy + nA;
+    int *spick = reinterpret_cast<int *>(sz + nA);                   // [m1]
+    float *bx = reinterpret_cast<float *>(spick + m1);               // cloud B = the picks of A, in pick order
+    float *by = bx + m1;
+    float *bz = by + m1;
+    int *spick2 = reinterpret_cast<int *>(bz + m1);                  // [m2]
+    const int t = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)blockIdx.x * nA * 3;
+
+    // ---- stage A (fps_reg_kernel<4, UA, 1>)
+    {
+        float px[UA], py[UA], pz[UA], md[UA];
+#pragma unroll
+        for (int i = 0; i < UA; ++i) {
+            const int k = t + brev_small<UA>(i) * T;
+            px[i] = xyz[k * 3 + 0]; py[i] = xyz[k * 3 + 1]; pz[i] = xyz[k * 3 + 2];
+            md[i] = 1e10f;
+            sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i];
+        }
+        if (t == 0) spick[0] = 0;
+        __syncthreads();
+        float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+        const int wave = t >> 6;
+        for (int j = 1; j < m1; ++j) {
+            float best = -1.f;
+            int bslot = 0;
+#pragma unroll
+            for (int i = 0; i < UA; ++i) {
+                const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+                const float d = dist2<FM>(dx, dy, dz);
+                const float d2 = min_f32(d, md[i]);
+                md[i] = d2;
+                const bool gt = d2 > best;
+                bslot = gt ? i : bslot;
+                best = gt ? d2 : best;
+            }
+            const int k = UA == 1 ? t : t + brev_small<UA>(bslot) * T;
+            float wval; int wk; unsigned wrank;
+            wave_argmax(best, k, bsA, log2bsA, wval, wk, wrank);
+            unsigned long long *buf = reinterpret_cast<unsigned long long *>(smem_raw) + (j & 1) * 16;
+            if ((t & 63) == 0) buf[wave] = ((unsigned long long)__float_as_uint(fmaxf(wval, 0.f)) << 32) | (unsigned)(~wrank);
+            __syncthreads();
+            const unsigned long long key = row_max_u64<W>(buf[t & (W - 1)]);
+            const unsigned rank = ~(unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, W - 1);
+            const unsigned c = __builtin_bitreverse32(rank >> 16) >> (32 - log2bsA);
+            const int old = (int)(((rank & 0xffffu) << log2bsA) | c);
+            x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
+            if (t == 0) spick[j] = old;
+        }
+        __syncthreads();
+        int *idx = idx1_all + (size_t)blockIdx.x * m1;
+        float *nx = nx1_all + (size_t)blockIdx.x * m1 * 3;
+        for (int j = t; j < m1; j += T) {
+            const int k = spick[j];
+            idx[j] = k;
+            const float x = sx[k], y = sy[k], z = sz[k];
+            nx[j * 3 + 0] = x; nx[j * 3 + 1] = y; nx[j * 3 + 2] = z;
+            bx[j] = x; by[j] = y; bz[j] = z;
+        }
+        __syncthreads();
+    }
+    if (t >= 64) return;
+    // ---- stage B (fps_reg_kernel<1, UB, 1>): one wave, no barrier
+    {
+        float px[UB], py[UB], pz[UB], md[UB];
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+            const int k = t + brev_small<UB>(i) * 64;
+            px[i] = bx[k]; py[i] = by[k]; pz[i] = bz[k];
+            md[i] = 1e10f;
+        }
+        if (t == 0) spick2[0] = 0;
+        float x1 = bx[0], y1 = by[0], z1 = bz[0];
+        for (int j = 1; j < m2; ++j) {
+            float best = -1.f;
+            int bslot = 0;
+#pragma unroll
+            for (int i = 0; i < UB; ++i) {
+                const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+                const float d = dist2<FM>(dx, dy, dz);
+                const float d2 = min_f32(d, md[i]);
+                md[i] = d2;
+                const bool gt = d2 > best;
+                bslot = gt ? i : bslot;
+                best = gt ? d2 : best;
+            }
+            const int k = UB == 1 ? t : t + brev_small<UB>(bslot) * 64;
+            float wval; int wk; unsigned wrank;
+            wave_argmax(best, k, bsB, log2bsB, wval, wk, wrank);
+            const int old = wk;
+            x1 = bx[old]; y1 = by[old]; z1 = bz[old];
+            if (t == 0) spick2[j] = old;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int *idx = idx2_all + (size_t)blockIdx.x * m2;
+        float *nx = nx2_all + (size_t)blockIdx.x * m2 * 3;
+        for (int j = t; j < m2; j += 64) {
+            const int k = spick2[j];
+            idx[j] = k;
+            nx[j * 3 + 0] = bx[k]; nx[j * 3 + 1] = by[k]; nx[j * 3 + 2] = bz[k];
+        }
+    }
+}
+
 // Any-N fallback: the reference's thread shape (class c = tid, strided scan from L2-resident global
 // memory), the same DPP + one-barrier reduction.  1024 threads; threads >= bs idle.
 template <int FM>
@@ -359,4 +477,20 @@ extern "C" int g4d_fps_f32(int b, int n, int m, const float *xyz, float *temp, i
 extern "C" int g4d_fps_gather_f32(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, g4d_stream_t stream) {
     G4D_REQUIRE(new_xyz || b == 0 || m == 0, "g4d_fps_gather_f32: new_xyz is NULL");
     return fps_impl(b, n, m, xyz, temp, idx, new_xyz, stream);
+}
+
+// Two consecutive FPS levels (n -> m1 -> m2, level B samples the points level A picked) in one launch; idx1 / new_xyz1 / idx2 / new_xyz2
+// are what g4d_fps_gather_f32(n -> m1) followed by g4d_fps_gather_f32(m1 -> m2) on new_xyz1 give.  Supported shapes:
+// g4d_fps_gather_pair_supported (n = 1024 and m1 = 256, the inner levels of the Pointnet2MSGSEG encoder).
+extern "C" int g4d_fps_gather_pair_supported(int n, int m1, int m2) { return n == 1024 && m1 == 256 && m2 >= 1 && m2 <= m1; }
+extern "C" int g4d_fps_gather_pair_f32(int b, int n, int m1, int m2, const float *xyz, int *idx1, float *new_xyz1, int *idx2, float *new_xyz2,
+                                       g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && g4d_fps_gather_pair_supported(n, m1, m2), "g4d_fps_gather_pair_f32: unsupported shape (n=%d m1=%d m2=%d)", n, m1, m2);
+    if (b == 0) return G4D_OK;
+    G4D_REQUIRE(xyz && idx1 && new_xyz1 && idx2 && new_xyz2, "g4d_fps_gather_pair_f32: null pointer");
+    const size_t lds = 2 * 16 * 16 + (size_t)n * 12 + (size_t)m1 * 16 + (size_t)m2 * 4;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((fps_reg_pair_kernel<4, 4, FM>), dim3(b), dim3(256), lds, s, m2, xyz, idx1, new_xyz1, idx2, new_xyz2))
+    return check_launch("g4d_fps_gather_pair_f32");
 }

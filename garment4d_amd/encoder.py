@@ -103,9 +103,13 @@ class Pointnet2MSGSEG(nn.Module):
             pre_nx, pre_idx = {}, {}
             if (fused.BQ_MULTI and len(SAs) == 3 and all(sa.npoint is not None for sa in SAs) and SAs[0].npoint < fused.GRID_MIN_N
                     and len(SAs[1].groupers) == len(SAs[2].groupers) <= 4):
-                src = xyz
-                for li, sa in enumerate(SAs):
-                    src = pre_nx[li] = fused.fps_gather(src, sa.npoint)
+                pre_nx[0] = fused.fps_gather(xyz, SAs[0].npoint)
+                pair = fused.fps_gather_pair(pre_nx[0], SAs[1].npoint, SAs[2].npoint)   # the two small levels in one launch when the shape allows
+                if pair is not None:
+                    pre_nx[1], pre_nx[2] = pair
+                else:
+                    pre_nx[1] = fused.fps_gather(pre_nx[0], SAs[1].npoint)
+                    pre_nx[2] = fused.fps_gather(pre_nx[1], SAs[2].npoint)
                 pre_idx[1], pre_idx[2] = fused.ball_query_msg2(
                     ([g.radius for g in SAs[1].groupers], [g.nsample for g in SAs[1].groupers], pre_nx[0], pre_nx[1]),
                     ([g.radius for g in SAs[2].groupers], [g.nsample for g in SAs[2].groupers], pre_nx[1], pre_nx[2]))

@@ -440,6 +440,22 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     return outs
 
 
+FPS_PAIR = os.environ.get("G4D_FPS_PAIR", "1") != "0"   # two consecutive small FPS levels in one launch
+
+
+def fps_gather_pair(xyz, m1, m2):
+    """(new_xyz1 (B,m1,3), new_xyz2 (B,m2,3)) = fps_gather(xyz, m1) and fps_gather(new_xyz1, m2) in one launch (g4d_fps_gather_pair_f32), or
+    None when the shape is not one the paired kernel covers."""
+    B, N, _ = _chk(xyz).shape
+    if not (FPS_PAIR and B > 0 and _lib.lib().g4d_fps_gather_pair_supported(N, m1, m2)):
+        return None
+    dev = xyz.device
+    i1, i2 = torch.empty((B, m1), dtype=torch.int32, device=dev), torch.empty((B, m2), dtype=torch.int32, device=dev)
+    n1, n2 = torch.empty((B, m1, 3), dtype=torch.float32, device=dev), torch.empty((B, m2, 3), dtype=torch.float32, device=dev)
+    _lib.call("g4d_fps_gather_pair_f32", B, N, m1, m2, xyz.data_ptr(), i1.data_ptr(), n1.data_ptr(), i2.data_ptr(), n2.data_ptr(), _lib.stream_ptr())
+    return n1, n2
+
+
 BQ_MULTI = os.environ.get("G4D_BQ_MULTI", "1") != "0"   # the ball queries of two small SA levels in one launch
 
 

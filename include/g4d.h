@@ -402,6 +402,14 @@ int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const float *rad
                             const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1,
                             const float *new_xyz1, const float *xyz1, int *const *idx1, g4d_stream_t stream);
 
+/* Two consecutive furthest-point-sampling levels in ONE launch (sampling_gpu.cu:93-253 twice: level B samples the m1 points level A
+ * picked): idx1 (b, m1) / new_xyz1 (b, m1, 3) / idx2 (b, m2) / new_xyz2 (b, m2, 3) are exactly what g4d_fps_gather_f32(n -> m1) followed by
+ * g4d_fps_gather_f32(m1 -> m2) on new_xyz1 give (idx2 indexes new_xyz1).  Shapes: g4d_fps_gather_pair_supported -- n = 1024, m1 = 256,
+ * the two inner levels of the Pointnet2MSGSEG encoder. */
+int g4d_fps_gather_pair_supported(int n, int m1, int m2);
+int g4d_fps_gather_pair_f32(int b, int n, int m1, int m2, const float *xyz, int *idx1, float *new_xyz1, int *idx2, float *new_xyz2,
+                            g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

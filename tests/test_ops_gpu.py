@@ -378,3 +378,29 @@ def test_ball_query_msg2_equals_separate_queries(contraction_mode):
         a0, a1 = fused.ball_query_msg2((radii0, ns0, x0, c0), (radii1, ns1, x1, c1))
         w0, w1 = fused.ball_query_msg(radii0, ns0, x0, c0, grid=False), fused.ball_query_msg(radii1, ns1, x1, c1, grid=False)
         assert all(torch.equal(a, w) for a, w in zip(a0, w0)) and all(torch.equal(a, w) for a, w in zip(a1, w1))
+
+
+@pytest.mark.parametrize("kind,m2", [("unit", 64), ("ties", 64), ("unit", 1), ("zeros", 33), ("unit", 256)])
+def test_fps_gather_pair_equals_two_launches(kind, m2, contraction_mode):
+    """g4d_fps_gather_pair_f32 (1024 -> 256 -> m2 in one launch) against the two separate launches and the oracle: indices and gathered
+    coordinates of both levels, incl. tie-heavy (duplicated / zero-padded) clouds where the block-size-dependent tie-break decides."""
+    from garment4d_amd import fused, _lib
+    B, n, m1 = 4, 1024, 256
+    x = syn.unit_cloud(B, n, seed=m2 + 3)
+    if kind == "ties":
+        x = syn.body_like_cloud(B, n, seed=5, dup_frac=0.3, zero_frac=0.1)
+    if kind == "zeros":
+        x[:, 300:] = 0.0
+    xd = dev(x)
+    i1 = torch.empty((B, m1), dtype=torch.int32, device="cuda"); i2 = torch.empty((B, m2), dtype=torch.int32, device="cuda")
+    n1 = torch.empty((B, m1, 3), device="cuda"); n2 = torch.empty((B, m2, 3), device="cuda")
+    _lib.call("g4d_fps_gather_pair_f32", B, n, m1, m2, xd.data_ptr(), i1.data_ptr(), n1.data_ptr(), i2.data_ptr(), n2.data_ptr(), _lib.stream_ptr())
+    w1 = K.fps(x, m1)
+    assert np.array_equal(host(i1), w1)
+    x1 = np.stack([x[b][w1[b]] for b in range(B)])
+    assert np.array_equal(host(n1), x1)
+    w2 = K.fps(x1, m2)
+    assert np.array_equal(host(i2), w2)
+    assert np.array_equal(host(n2), np.stack([x1[b][w2[b]] for b in range(B)]))
+    s1 = fused.fps_gather(xd, m1); s2 = fused.fps_gather(s1, m2)
+    assert torch.equal(s1, n1) and torch.equal(s2, n2)
