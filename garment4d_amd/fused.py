@@ -142,7 +142,7 @@ def pack_conv_stack(stack):
     return layers
 
 
-_CACHE_ATTRS = ("_g4d_packed", "_g4d_split", "_g4d_pe", "_g4d_table")
+_CACHE_ATTRS = ("_g4d_packed", "_g4d_split", "_g4d_pe", "_g4d_table", "_g4d_sa_table", "_g4d_fp_split")
 
 
 def invalidate(module):

@@ -521,3 +521,29 @@ def test_fp_with_skip_features_on_the_interpolated_table(B, n, m, C2, C1, mlp, m
         sd = {k: v.cpu().numpy() for k, v in fp.state_dict().items()}
         f = MO.fp_module(unknown.cpu().numpy(), known.cpu().numpy(), uf.cpu().numpy(), kf.cpu().numpy(), sd)
         np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), f, rtol=1e-5, atol=1e-5)
+
+
+def test_invalidate_drops_the_table_caches_after_a_data_update():
+    """Weights changed THROUGH .data do not bump the version counter the packed caches are keyed on; fused.invalidate(module) must also drop
+    the per-level first-layer tables (SA) and the split first layer (FP), or the table routes would keep serving the old weights."""
+    torch.manual_seed(3)
+    B, N, P, C = 2, 600, 80, 32
+    xyz = dev(syn.unit_cloud(B, N, seed=9))
+    feats = torch.randn(B, C, N, device="cuda")
+    sa = PM.PointnetSAModuleMSG(npoint=P, radii=[0.2, 0.3], nsamples=[16, 32], mlps=[[C, 32, 64], [C, 64, 64, 128]]).cuda().eval()
+    fp = PM.PointnetFPModule(mlp=[64 + 20, 64, 32]).cuda().eval()
+    kf, uf = torch.randn(B, 64, P, device="cuda"), torch.randn(B, 20, N, device="cuda")
+    with torch.no_grad():
+        nx, _ = fused.sa_forward(sa, xyz, fused.to_point_major(feats))
+        fused.fp_forward(fp, xyz, nx, fused.to_point_major(uf), fused.to_point_major(kf))
+        for mod in (sa, fp):
+            for p in mod.parameters():
+                if p.dim() > 1:
+                    p.data.mul_(1.7)
+        assert fused.invalidate(sa) > 0 and fused.invalidate(fp) > 0
+        _, got = fused.sa_forward(sa, xyz, fused.to_point_major(feats))
+        _, want = sa(xyz, feats)
+        np.testing.assert_allclose(fused.to_channel_major(got).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        got = fused.fp_forward(fp, xyz, nx, fused.to_point_major(uf), fused.to_point_major(kf))
+        want = fp(xyz, nx, uf, kf)
+        np.testing.assert_allclose(fused.to_channel_major(got).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
