@@ -126,6 +126,8 @@ class Pointnet2MSGSEG(nn.Module):
         middle = fused.sa_forward(self.Middle_modules, l_xyz[-1], l_feats[-1])[1] if self.global_feat else None
         nfp = len(self.FP_modules)
         # the three-NN searches of the inner FP levels depend on the sampled coordinates only and are microseconds of work each: one launch
+        # (the outermost level's search in the same launch too -- a third, large problem on the whole-set scan -- measured 32.3k -> 31.8k
+        #  frames/s: its long workgroups and the short ones share a launch badly; it keeps its own)
         inner = [i for i in range(-1, -nfp, -1) if l_xyz[i - 1].shape[1] < 4096]
         pre = {}
         if fused.NN_MULTI and 2 <= len(inner) <= 4:
