@@ -42,7 +42,7 @@ __device__ __forceinline__ F3s ld3(const float *base, unsigned elem) {
 }
 
 template <int C1, int C2, int C3>
-__global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
+__device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int bx, int nblocks) {
     constexpr int T1 = C1 / 16, T2 = C2 / 16, T3 = C3 / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fi = lane & 15, fq = lane >> 4;
@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
             rw.pq[mt] = ld3(a.new_xyz, (unsigned)qi * 3u);
         }
     };
-    const int stride = gridDim.x * 4;
-    int pass = blockIdx.x * 4 + wave;
+    const int stride = nblocks * 4;
+    int pass = bx * 4 + wave;
     load_idx(pass, ivn);
     load_rows(pass, ivn, cur);
     load_idx(pass + stride, ivn);
@@ -194,12 +194,76 @@ __global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
     }
 }
 
+template <int C1, int C2, int C3>
+__global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
+    sa_xyz_body<C1, C2, C3>(a, blockIdx.x, gridDim.x);
+}
+
+// Both xyz-only scales of an MSG level (16-16-32 at 16 samples and 32-32-64 at 32) in ONE launch: the first nb0 workgroups run the narrow
+// stack, the rest the wide one, each a persistent pool of its own (a launch costs the 16-batch mix 3-5 us; the narrow stack alone is 7 us).
+__global__ void __launch_bounds__(256, 2) sa_xyz_pair_kernel(const SaXyzArgs a0, const SaXyzArgs a1, int nb0) {
+    if ((int)blockIdx.x < nb0) sa_xyz_body<16, 16, 32>(a0, blockIdx.x, nb0);
+    else sa_xyz_body<32, 32, 64>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
+
 }  // namespace g4d
 
 using namespace g4d;
 
 extern "C" int g4d_sa_xyz_mlp3_supported(int c1, int c2, int c3, int nsample) {
     return ((c1 == 16 && c2 == 16 && c3 == 32) || (c1 == 32 && c2 == 32 && c3 == 64)) && (nsample == 16 || nsample == 32);
+}
+
+static int sa_xyz_fill(SaXyzArgs &a, int b, int n, int p, int nsample, const float *xyz, const float *new_xyz, const int *idx, int c1, int c2, int c3,
+                       const float *W1, int ldw1, const float *scale1, const float *shift1, const float *W2_frag, int kpad2, const float *scale2,
+                       const float *shift2, const float *W3_frag, int kpad3, const float *scale3, const float *shift3, int pool, float *out, int ldo,
+                       int col0) {
+    G4D_REQUIRE(b >= 0 && n > 0 && p >= 0, "g4d_sa_xyz_mlp3_f32: bad sizes");
+    G4D_REQUIRE(g4d_sa_xyz_mlp3_supported(c1, c2, c3, nsample), "g4d_sa_xyz_mlp3_f32: widths %d-%d-%d over %d samples are not instantiated", c1, c2,
+                c3, nsample);
+    G4D_REQUIRE(pool == 1 || pool == 2, "g4d_sa_xyz_mlp3_f32: pool must be 1 (max) or 2 (avg)");
+    const long long rows = (long long)b * p * nsample;
+    G4D_REQUIRE(xyz && new_xyz && idx && W1 && scale1 && shift1 && W2_frag && scale2 && shift2 && W3_frag && scale3 && shift3 && out && ldw1 >= 3,
+                "g4d_sa_xyz_mlp3_f32: null pointer");
+    G4D_REQUIRE(ldo >= col0 + c3 && col0 >= 0, "g4d_sa_xyz_mlp3_f32: output window out of range");
+    G4D_REQUIRE(rows < (1ll << 31) - 64 && (long long)b * n * 12 < (1ll << 32), "g4d_sa_xyz_mlp3_f32: needs rows < 2^31 and b*n*12 B < 4 GB");
+    a.n = n; a.p = p; a.S = nsample; a.logS = nsample == 16 ? 4 : 5; a.pool = pool; a.rows = rows;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.W1 = W1; a.sc1 = scale1; a.sh1 = shift1; a.ldw1 = ldw1;
+    G4D_REQUIRE(kpad2 % 16 == 0 && kpad2 >= c1 && kpad3 % 16 == 0 && kpad3 >= c2, "g4d_sa_xyz_mlp3_f32: Kpad of layers 2 / 3 must be multiples of 16 covering c1 / c2");
+    a.W2f = W2_frag; a.sc2 = scale2; a.sh2 = shift2; a.W3f = W3_frag; a.sc3 = scale3; a.sh3 = shift3; a.kst2 = kpad2 / 16; a.kst3 = kpad3 / 16;
+    a.out = out; a.ldo = ldo; a.col0 = col0;
+    return G4D_OK;
+}
+
+// Both scales of an xyz-only MSG level in one launch: scale 0 must be the 16-16-32 stack, scale 1 the 32-32-64 one (sa_xyz_pair_kernel);
+// same centroids / cloud, each scale with its own neighbour indices, weights and output window.  Results identical to two
+// g4d_sa_xyz_mlp3_f32 calls.
+extern "C" int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, const float *new_xyz, int pool, float *out, int ldo,
+                                        int nsample0, const int *idx0, const float *W1_0, int ldw1_0, const float *scale1_0, const float *shift1_0,
+                                        const float *W2_frag0, int kpad2_0, const float *scale2_0, const float *shift2_0, const float *W3_frag0,
+                                        int kpad3_0, const float *scale3_0, const float *shift3_0, int col0_0,
+                                        int nsample1, const int *idx1, const float *W1_1, int ldw1_1, const float *scale1_1, const float *shift1_1,
+                                        const float *W2_frag1, int kpad2_1, const float *scale2_1, const float *shift2_1, const float *W3_frag1,
+                                        int kpad3_1, const float *scale3_1, const float *shift3_1, int col0_1, g4d_stream_t stream) {
+    SaXyzArgs a0, a1;
+    if (int rc = sa_xyz_fill(a0, b, n, p, nsample0, xyz, new_xyz, idx0, 16, 16, 32, W1_0, ldw1_0, scale1_0, shift1_0, W2_frag0, kpad2_0, scale2_0, shift2_0,
+                             W3_frag0, kpad3_0, scale3_0, shift3_0, pool, out, ldo, col0_0)) return rc;
+    if (int rc = sa_xyz_fill(a1, b, n, p, nsample1, xyz, new_xyz, idx1, 32, 32, 64, W1_1, ldw1_1, scale1_1, shift1_1, W2_frag1, kpad2_1, scale2_1, shift2_1,
+                             W3_frag1, kpad3_1, scale3_1, shift3_1, pool, out, ldo, col0_1)) return rc;
+    if (a0.rows == 0) return G4D_OK;
+    // workgroups in proportion to the MFMA work of the two stacks (per row: 16*16 + 16*32 vs 32*32 + 32*64), two persistent workgroups per CU in all
+    static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+    const long long w0 = a0.rows * (16 * 16 + 16 * 32), w1 = a1.rows * (32 * 32 + 32 * 64);
+    const int total = 256 * bpc;
+    long long nb0 = (total * w0 + (w0 + w1) / 2) / (w0 + w1);
+    const long long want0 = ((a0.rows + 31) / 32 + 3) / 4, want1 = ((a1.rows + 31) / 32 + 3) / 4;
+    if (nb0 < 1) nb0 = 1;
+    if (nb0 > want0) nb0 = want0;
+    long long nb1 = total - nb0;
+    if (nb1 > want1) nb1 = want1;
+    if (nb1 < 1) nb1 = 1;
+    hipLaunchKernelGGL(sa_xyz_pair_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a0, a1, (int)nb0);
+    return check_launch("g4d_sa_xyz_mlp3_pair_f32");
 }
 
 extern "C" int g4d_sa_xyz_mlp3_f32(int b, int n, int p, int nsample, const float *xyz, const float *new_xyz, const int *idx, int c1, int c2,

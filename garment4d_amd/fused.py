@@ -530,6 +530,7 @@ def sampling_chain(xyz, npoints):
     return out
 
 
+SA_XYZ_PAIR = os.environ.get("G4D_SA_XYZ_PAIR", "1") != "0"   # ... and both such scales of a level in one launch
 USE_SA_XYZ = os.environ.get("G4D_SA_XYZ", "1") != "0"   # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
 
 
@@ -629,6 +630,20 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
         col0 = 0
         if idxs is None:   # (else: the caller's ball_query_msg / ball_query_msg2 result for exactly these centroids)
             idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, grid=grid)
+        if (USE_SA_XYZ and SA_XYZ_PAIR and C == 0 and len(packed) == 2 and current_precision() == "fp32" and B * N * 12 < 2 ** 32
+                and all(int(g.use_xyz) for g in sa.groupers) and all(len(L_) == 3 and all(L.relu for L in L_) for L_ in packed)
+                and [L.Cout for L in packed[0]] == [16, 16, 32] and [L.Cout for L in packed[1]] == [32, 32, 64]
+                and all(g.nsample in (16, 32) for g in sa.groupers)):
+            # both xyz-only scales of the level in one launch (csrc/sa_xyz.hip, sa_xyz_pair_kernel)
+            args = []
+            c0 = 0
+            for g, L_, idx in zip(sa.groupers, packed, idxs):
+                L1, L2, L3 = L_
+                args += [g.nsample, idx.data_ptr(), L1.W.data_ptr(), L1.Kpad, L1.scale.data_ptr(), L1.shift.data_ptr(), L2.Wf.data_ptr(), L2.Kpad,
+                         L2.scale.data_ptr(), L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), c0]
+                c0 += L3.Cout
+            _lib.call("g4d_sa_xyz_mlp3_pair_f32", B, N, P, xyz.data_ptr(), new_xyz.data_ptr(), pool, out.data_ptr(), out.shape[-1], *args, stream)
+            return new_xyz, out
         # scales whose first layer runs as a per-source-point table: one contraction of the level's features for all of them
         tab_scales = [k for k, (g, layers) in enumerate(zip(sa.groupers, packed))
                       if sa_table_fits(layers, C, int(g.use_xyz), pool, g.nsample, B * N, B * P * g.nsample)]

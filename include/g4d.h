@@ -410,6 +410,17 @@ int g4d_fps_gather_pair_supported(int n, int m1, int m2);
 int g4d_fps_gather_pair_f32(int b, int n, int m1, int m2, const float *xyz, int *idx1, float *new_xyz1, int *idx2, float *new_xyz2,
                             g4d_stream_t stream);
 
+/* Both scales of an xyz-only MSG set-abstraction level in ONE launch: scale 0 = the 16-16-32 stack, scale 1 = the 32-32-64 stack of
+ * g4d_sa_xyz_mlp3_f32 (arguments per scale as there: neighbour indices, layer 1 row-major with its affine, layers 2 / 3 in fragment
+ * order with theirs, output column).  Same cloud, centroids, pooling mode and output tensor; results identical to the two calls. */
+int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, const float *new_xyz, int pool, float *out, int ldo,
+                             int nsample0, const int *idx0, const float *W1_0, int ldw1_0, const float *scale1_0, const float *shift1_0,
+                             const float *W2_frag0, int kpad2_0, const float *scale2_0, const float *shift2_0, const float *W3_frag0, int kpad3_0,
+                             const float *scale3_0, const float *shift3_0, int col0_0,
+                             int nsample1, const int *idx1, const float *W1_1, int ldw1_1, const float *scale1_1, const float *shift1_1,
+                             const float *W2_frag1, int kpad2_1, const float *scale2_1, const float *shift2_1, const float *W3_frag1, int kpad3_1,
+                             const float *scale3_1, const float *shift3_1, int col0_1, g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and
