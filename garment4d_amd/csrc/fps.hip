@@ -381,6 +381,7 @@ static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz,
 }
 
 int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s);  // fps_bucket.hip
+int fps_bucket_grid_launch(int b, int n, int m, int bs, int log2bs, const float *xyz, int *idx, float *nx, float rmax, void *grid_ws, hipStream_t s);
 
 
 static int g_fps_force_w = -1;  // tuning hook: G4D_FPS_W=1|4|8|16|0(generic); unset = automatic (bucketed kernel for 2048 < n <= 8192)
@@ -493,4 +494,25 @@ extern "C" int g4d_fps_gather_pair_f32(int b, int n, int m1, int m2, const float
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((fps_reg_pair_kernel<4, 4, FM>), dim3(b), dim3(256), lds, s, m2, xyz, idx1, new_xyz1, idx2, new_xyz2))
     return check_launch("g4d_fps_gather_pair_f32");
+}
+
+extern "C" int g4d_ball_grid_build_f32(int b, int n, float rmax, const float *xyz, void *grid, g4d_stream_t stream);
+// g4d_fps_gather_f32 (no scratch) and g4d_ball_grid_build_f32 of the same clouds in one launch when the sampling takes the bucketed kernel
+// (4096 < n <= 8192: workgroups [b, 2 b) of the sampling launch build the grids), two launches otherwise.  Outputs identical either way.
+extern "C" int g4d_fps_gather_grid_f32(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, float rmax, void *grid, g4d_stream_t stream) {
+    using namespace g4d;
+    G4D_REQUIRE(b >= 0 && n > 0 && m > 0 && rmax > 0.f, "g4d_fps_gather_grid_f32: bad sizes");
+    if (b == 0) return G4D_OK;
+    G4D_REQUIRE(xyz && idx && new_xyz && grid, "g4d_fps_gather_grid_f32: null pointer");
+    static const int merged = getenv("G4D_FPS_GRID_MERGED") ? atoi(getenv("G4D_FPS_GRID_MERGED")) : 1;
+    static const int use_bucket = getenv("G4D_FPS_BUCKET") ? atoi(getenv("G4D_FPS_BUCKET")) : 1;
+    if (merged && use_bucket && !getenv("G4D_FPS_W") && !getenv("G4D_FPS_BUCKET_W") && !getenv("G4D_FPS_DEAL")) {
+        const int bs = ref_block_size(n);
+        int log2bs = 0;
+        while ((1 << log2bs) < bs) ++log2bs;
+        const int rc = fps_bucket_grid_launch(b, n, m, bs, log2bs, xyz, idx, new_xyz, rmax, grid, reinterpret_cast<hipStream_t>(stream));
+        if (rc >= 0) return rc;
+    }
+    if (const int rc = g4d_fps_gather_f32(b, n, m, xyz, nullptr, idx, new_xyz, stream)) return rc;
+    return g4d_ball_grid_build_f32(b, n, rmax, xyz, grid, stream);
 }

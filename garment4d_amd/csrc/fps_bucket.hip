@@ -26,6 +26,7 @@
 // dependent issue: a lone wave retires one dependent instruction per ~6 cycles, a DPP step costs 19, an LDS round
 // trip 64, a 16-wave barrier 60 (scripts/micro/clock.hip); the slowest wave's ~190-instruction path is the round.
 #include "g4d_common.h"
+#include "ball_grid_build.h"
 
 namespace g4d {
 
@@ -99,8 +100,8 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
 template <int W, int P, int FM>
-__global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
-                                                           float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
+__device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
+                                                float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all, int cloud) {
     constexpr int T = 64 * W, NPAD = T * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);         // [2][16] candidate keys
@@ -113,10 +114,10 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const float *xyz = xyz_all + (size_t)blockIdx.x * n * 3;
-    float *temp = temp_all ? temp_all + (size_t)blockIdx.x * n : nullptr;
-    int *idx = idx_all + (size_t)blockIdx.x * m;
-    float *nx = nx_all ? nx_all + (size_t)blockIdx.x * m * 3 : nullptr;   // optional: the selected points themselves (gather fused)
+    const float *xyz = xyz_all + (size_t)cloud * n * 3;
+    float *temp = temp_all ? temp_all + (size_t)cloud * n : nullptr;
+    int *idx = idx_all + (size_t)cloud * m;
+    float *nx = nx_all ? nx_all + (size_t)cloud * m * 3 : nullptr;   // optional: the selected points themselves (gather fused)
     const float INF = __builtin_inff();
 
     // ---- A. Morton keys of the cloud -------------------------------------------------------------------------
@@ -300,9 +301,26 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
 #ifdef G4D_FPS_DEBUG
     __syncthreads();
     if (lane == 0 && temp) atomicAdd(&temp[0], (float)dbg_active);  // debug only: total active (wave, bucket) sweeps
-    if (lane == 0 && temp && (wave == 0 || wave == 5) && blockIdx.x == 0)
+    if (lane == 0 && temp && (wave == 0 || wave == 5) && cloud == 0)
         for (int q = 0; q < 4; ++q) temp[1 + (wave ? 4 : 0) + q] = (float)dbg_t[q];
 #endif
+}
+
+template <int W, int P, int FM>
+__global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
+                                                           float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
+    fps_bucket_body<W, P, FM>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
+}
+
+// The sampling launch with a second ROLE: workgroups [0, b) run the FPS of cloud blockIdx.x, workgroups [b, 2 b) build the ball-query
+// cell grid of cloud blockIdx.x - b (ball_grid_build.h).  Both depend on the cloud only; the grid build (17 us alone, one workgroup per
+// cloud) disappears behind the 750 us of the sampling and the step has one launch fewer.
+template <int FM>
+__global__ void __launch_bounds__(1024) fps_bucket_grid_kernel(int b, int n, int m, int bs, int log2bs, int deal, int pick_off,
+                                                              const float *__restrict__ xyz_all, int *__restrict__ idx_all, float *__restrict__ nx_all,
+                                                              int cmax, float cell_req, unsigned char *__restrict__ ws_all, size_t ws_stride) {
+    if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
+    else ball_grid_build_body(n, cmax, cmax, cell_req, xyz_all, ws_all, ws_stride, (int)blockIdx.x - b);
 }
 
 template <int W, int P, int FM>
@@ -325,6 +343,27 @@ template <int W, int P>
 static int launch_bucket(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     G4D_WITH_FM(distance_contraction(), return (launch_bucket_fm<W, P, FM>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s)))
     return G4D_OK;
+}
+
+// FPS (+ gather) of b clouds and the cell grid of the same clouds in one launch; -1 when the shape is not the bucketed kernel's default one
+int fps_bucket_grid_launch(int b, int n, int m, int bs, int log2bs, const float *xyz, int *idx, float *nx, float rmax, void *grid_ws, hipStream_t s) {
+    if (!(n > 4096 && n <= 8192)) return -1;
+    constexpr int W = 16, P = 8;
+    const size_t npad = (size_t)64 * W * P;
+    const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
+    const size_t pick_off = (1024 + body + 15) & ~(size_t)15;
+    const int cmax = grid_cmax(n);
+    const size_t lds_fps = pick_off + (size_t)m * 4, lds_grid = ((size_t)cmax + 1) * 4 + 16 * 8 * 4;
+    const size_t lds = lds_fps > lds_grid ? lds_fps : lds_grid;
+    static unsigned long long attr[3] = {0, 0, 0};
+    const int mode = distance_contraction();
+    const int slot = mode == 0 ? 0 : (mode == 1 ? 1 : 2);
+    const void *k = slot == 0 ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<0>)
+                    : (slot == 1 ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<1>) : reinterpret_cast<const void *>(fps_bucket_grid_kernel<2>));
+    if (const int rc = ensure_dynamic_lds(k, 160 * 1024 - 1024, attr[slot], "g4d_fps_gather_grid_f32")) return rc;
+    G4D_WITH_FM(mode, hipLaunchKernelGGL(fps_bucket_grid_kernel<FM>, dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P, (int)pick_off, xyz, idx, nx,
+                                         cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
+    return check_launch("g4d_fps_gather_grid_f32");
 }
 
 // Called by g4d_fps_f32 (fps.hip) for 2048 < n <= 8192.  Returns -1 when the shape is not covered.

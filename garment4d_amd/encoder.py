@@ -103,7 +103,11 @@ class Pointnet2MSGSEG(nn.Module):
             pre_nx, pre_idx = {}, {}
             if (fused.BQ_MULTI and len(SAs) == 3 and all(sa.npoint is not None for sa in SAs) and SAs[0].npoint < fused.GRID_MIN_N
                     and len(SAs[1].groupers) == len(SAs[2].groupers) <= 4):
-                pre_nx[0] = fused.fps_gather(xyz, SAs[0].npoint)
+                r0 = [g.radius for g in SAs[0].groupers]
+                if fused.GRID_MIN_N <= xyz.shape[1] <= 12800 and max(r0) <= 2.01 * min(r0) and xyz.shape[0] > 0:
+                    pre_nx[0], grid0 = fused.fps_gather_grid(xyz, SAs[0].npoint, max(r0))   # level 1's sampling + the cloud's cell grid: one launch
+                else:
+                    pre_nx[0] = fused.fps_gather(xyz, SAs[0].npoint)
                 pair = fused.fps_gather_pair(pre_nx[0], SAs[1].npoint, SAs[2].npoint)   # the two small levels in one launch when the shape allows
                 if pair is not None:
                     pre_nx[1], pre_nx[2] = pair
@@ -119,7 +123,9 @@ class Pointnet2MSGSEG(nn.Module):
                 if li == 0 and xyz.shape[1] >= fused.GRID_MIN_N and sa.npoint is not None and max(radii) <= 2.01 * min(radii):
                     # the level-0 cloud's cell grid: the first level's ball query uses it, and so does the three-NN of the LAST
                     # feature-propagation level (same cloud as its unknown set)
-                    grid0 = grid = fused.build_ball_grid(xyz, max(radii))
+                    if grid0 is None:
+                        grid0 = fused.build_ball_grid(xyz, max(radii))
+                    grid = grid0
                 nx, nf = fused.sa_forward(sa, l_xyz[-1], l_feats[-1], new_xyz=pre_nx.get(li), grid=grid, idxs=pre_idx.get(li))
                 l_xyz.append(nx)
                 l_feats.append(nf)

@@ -440,6 +440,17 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     return outs
 
 
+def fps_gather_grid(xyz, npoint, rmax):
+    """(new_xyz, grid) = (fps_gather(xyz, npoint), build_ball_grid(xyz, rmax)) -- one launch for 4096 < N <= 8192 (g4d_fps_gather_grid_f32:
+    the grid build rides in the sampling launch as extra workgroups), two otherwise; identical results."""
+    B, N, _ = _chk(xyz).shape
+    sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
+    ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B, N), 16), dtype=torch.uint8, device=xyz.device)
+    _lib.call("g4d_fps_gather_grid_f32", B, N, npoint, xyz.data_ptr(), sidx.data_ptr(), new_xyz.data_ptr(), float(rmax), ws.data_ptr(), _lib.stream_ptr())
+    return new_xyz, (ws, float(rmax))
+
+
 FPS_PAIR = os.environ.get("G4D_FPS_PAIR", "1") != "0"   # two consecutive small FPS levels in one launch
 
 

@@ -421,6 +421,11 @@ int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, const float 
                              const float *W2_frag1, int kpad2_1, const float *scale2_1, const float *shift2_1, const float *W3_frag1, int kpad3_1,
                              const float *scale3_1, const float *shift3_1, int col0_1, g4d_stream_t stream);
 
+/* g4d_fps_gather_f32 (no scratch) AND g4d_ball_grid_build_f32 of the same b clouds: for 4096 < n <= 8192 one launch -- workgroups [b, 2 b) of
+ * the sampling launch build the cell grids (both depend on the cloud only; the build hides behind the sampling) -- two launches otherwise.
+ * idx (b, m), new_xyz (b, m, 3), grid (g4d_ball_grid_bytes(b, n) bytes): identical to the two calls' outputs. */
+int g4d_fps_gather_grid_f32(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, float rmax, void *grid, g4d_stream_t stream);
+
 /* The whole lbs() in ONE launch (csrc/lbs.hip lbs_one_kernel): a workgroup owns 64 vertices x up to 8 frames; its 8 waves request
  * the tile's blend rows up front, do the per-frame work (Rodrigues, joints, coefficients, kinematic chain) while those loads fly,
  * meet in LDS and skin.  Same constants and outputs as g4d_lbs_fused_f32, no scratch.  Supported when J <= 32 and

@@ -404,3 +404,19 @@ def test_fps_gather_pair_equals_two_launches(kind, m2, contraction_mode):
     assert np.array_equal(host(n2), np.stack([x1[b][w2[b]] for b in range(B)]))
     s1 = fused.fps_gather(xd, m1); s2 = fused.fps_gather(s1, m2)
     assert torch.equal(s1, n1) and torch.equal(s2, n2)
+
+
+@pytest.mark.parametrize("n,m", [(8192, 1024), (5000, 300), (3000, 100)])
+def test_fps_gather_grid_equals_the_two_launches(n, m, contraction_mode):
+    """g4d_fps_gather_grid_f32: FPS + gather and the cloud's cell grid in one launch (4096 < n <= 8192) or two (else): samples equal to the
+    oracle's, and a ball query through the returned grid equal to the scan."""
+    from garment4d_amd import fused
+    B = 3
+    x = syn.unit_cloud(B, n, seed=n)
+    xd = dev(x)
+    nx, grid = fused.fps_gather_grid(xd, m, 0.2)
+    w = K.fps(x, m)
+    assert np.array_equal(host(nx), np.stack([x[b][w[b]] for b in range(B)]))
+    a = fused.ball_query_msg([0.1, 0.2], [16, 32], xd, nx, grid=grid)
+    s = fused.ball_query_msg([0.1, 0.2], [16, 32], xd, nx, grid=False)
+    assert all(torch.equal(p, q) for p, q in zip(a, s))
