@@ -150,7 +150,7 @@ def kernel_rooflines(model, cloud):
     t = timed(lambda: _lib.call("g4d_fps_f32", B_CLOUDS, N_POINTS, 1024, xyz_dev.data_ptr(), 0, idx_dev.data_ptr(), _lib.stream_ptr()))
     fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024)
     tr = pmc_traffic("fps_bucket_kernel")
-    res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8)", "bound": "latency", "achieved": fps_bytes / t / 1e9,
+    res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8): the sampling role of the level-1 launch (the encoder's fps_bucket_grid_kernel adds the cell-grid build as 8 more workgroups)", "bound": "latency", "achieved": fps_bytes / t / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS,
                   "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
                   "traffic_source": None if tr is None else tr["source"], "algorithmic_bytes": fps_bytes,
