@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- point-cloud frames/s through the hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W          (N>1: one rank per GPU under torch.distributed.run -- started by the
+                                                          driver, or by bench.py itself when it finds no WORLD_SIZE in its environment)
 
 A "step" is one pass of the hot path over one batch of synthetic input: BASELINE config 2 -- B=8 clouds of
 N=8192 points through the Pointnet2MSGSEG-spec encoder (3x SA-MSG: FPS + ball query + grouped shared MLP + max
@@ -144,16 +145,24 @@ def kernel_rooflines(model, cloud):
     #    1023 strictly dependent rounds: LATENCY-bound (SURVEY 8d regime 1).  Algorithmic bytes = xyz in + idx out (the fused
     #    path passes temp=NULL: no scratch traffic); the HBM fraction is reported because the contract asks for it -- the
     #    meaningful figure is us_per_round.
+    # Timed through the entry point the encoder calls (g4d_fps_gather_grid_f32 -> fps_bucket_grid_kernel: the sampling role above plus
+    # one cell-grid workgroup per cloud riding in the same launch, which ends long before the sampling does).
     xyz_dev = cloud
     idx_dev = torch.empty((B_CLOUDS, 1024), dtype=torch.int32, device=cloud.device)
+    nx_dev = torch.empty((B_CLOUDS, 1024, 3), dtype=torch.float32, device=cloud.device)
     from garment4d_amd import _lib
-    t = timed(lambda: _lib.call("g4d_fps_f32", B_CLOUDS, N_POINTS, 1024, xyz_dev.data_ptr(), 0, idx_dev.data_ptr(), _lib.stream_ptr()))
-    fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024)
-    tr = pmc_traffic("fps_bucket_kernel")
-    res["fps"] = {"kernel": "fps_bucket_kernel<16,8> (8192->1024, B=8): the sampling role of the level-1 launch (the encoder's fps_bucket_grid_kernel adds the cell-grid build as 8 more workgroups)", "bound": "latency", "achieved": fps_bytes / t / 1e9,
+    rmax = max(g.radius for g in model.SA_modules[0].groupers)
+    ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B_CLOUDS, N_POINTS), 16), dtype=torch.uint8, device=cloud.device)
+    t = timed(lambda: _lib.call("g4d_fps_gather_grid_f32", B_CLOUDS, N_POINTS, 1024, xyz_dev.data_ptr(), idx_dev.data_ptr(), nx_dev.data_ptr(),
+                                float(rmax), ws.data_ptr(), _lib.stream_ptr()))
+    fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024 + 12 * 1024)   # cloud in, picks + their coordinates out
+    grid_bytes = B_CLOUDS * (12 * N_POINTS + 16 * N_POINTS)        # the grid role: cloud in, (x, y, z, index) records out (+ cell offsets)
+    tr = pmc_traffic("fps_bucket_grid_kernel")
+    res["fps"] = {"kernel": "fps_bucket_grid_kernel<FM> via g4d_fps_gather_grid_f32 (8192->1024 + gather, B=8; second role: the clouds' cell grids)",
+                  "bound": "latency", "achieved": fps_bytes / t / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS,
                   "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
-                  "traffic_source": None if tr is None else tr["source"], "algorithmic_bytes": fps_bytes,
+                  "traffic_source": None if tr is None else tr["source"], "algorithmic_bytes": fps_bytes, "grid_role_bytes": grid_bytes,
                   "avg_launch_us": t * 1e6, "rounds_per_launch": 1023, "us_per_round": t * 1e6 / 1023,
                   "rounds_per_s_per_cloud": 1023 / t,
                   "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
@@ -336,14 +345,32 @@ def cpu_frame_parallel(sd, workers, frames_each, with_lbs):
             "max_start_lateness_s": max(r["late"] for r in res)}
 
 
+def self_launch(ngpus, script, argv):
+    """`python bench.py --gpus N` started WITHOUT a launcher: become the launcher.  The reference starts one process per GPU
+    (`srun ... python train_temporal.py`, scripts/train/train_tshirt_posed.sh; rank / world size from the environment,
+    utils/train_utils.py:49-92); here the same command line is re-executed under torch.distributed.run with N ranks on this node,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve) at a free port.  Never returns."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, dict(os.environ, G4D_BENCH_SELF_LAUNCHED="1"))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]), bool(int(sys.argv[5])))
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # a line is only ever reported for the number of ranks that was asked for: no silent N = 1 run under `--gpus 8`
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     ndev = torch.cuda.device_count()
     if local >= ndev:
@@ -358,6 +385,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; used for the barrier / max-reduce only
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus, f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}"
 
     with_lbs = not args.no_lbs
     try:
@@ -470,7 +498,9 @@ def main():
                                  else f"{ns} resident batches replayed (MALL-warm inputs)",
                        "note": f"a step lasts longer than ms_per_step: {ns} batches overlap (single-batch latency: latency_ms_single_stream)",
                        "device": torch.cuda.get_device_name(dev),
-                       "collective_backend": None if dist is None else f"{args.backend} world_size={world} (barrier + max-reduce of the time only)",
+                       "collective_backend": None if dist is None else f"{args.backend} world_size={dist.get_world_size()} (barrier + max-reduce of the time only)",
+                       "launcher": "self (bench.py re-executed under torch.distributed.run)" if os.environ.get("G4D_BENCH_SELF_LAUNCHED") else
+                                   ("torch.distributed.run" if world > 1 else "single process"),
                        "distance_contraction": __import__("garment4d_amd.numerics", fromlist=["x"]).get_distance_contraction(),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roof["fps"], "roofline_mfma": roof["mlp"],

@@ -76,6 +76,9 @@ SIGNATURES = {
     "g4d_fps_gather_pair_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_sa_xyz_mlp3_pair_f32": [_I, _I, _I, _vp, _vp, _I, _vp, _I, _I, _vp, _vp, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _I, _vp, _vp, _I, _I, _vp, _vp, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _I, _vp, _vp, _I, _vp],
     "g4d_fps_gather_grid_f32": [_I, _I, _I, _vp, _vp, _vp, ctypes.c_float, _vp, _vp],
+    "g4d_launch_group_begin": [],
+    "g4d_launch_group_end": [_vp, _vp],
+    "g4d_launch_group_abort": [],
     "g4d_lbs_one_supported": [_I, _I],
     "g4d_lbs_one_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_lbs_fused_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -30,6 +30,8 @@
 
 namespace g4d {
 
+constexpr int kFpsHdr = 2048;   // LDS header in front of the sort keys / SoA cloud: exchange slots, candidate records, round results
+
 // --- pieces shared with fps.hip (kept local: both files are self-contained translation units)
 __device__ __forceinline__ unsigned fpsb_rank(int k, int bs, int log2bs) {
     const unsigned c = (unsigned)k & (unsigned)(bs - 1);
@@ -99,21 +101,23 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 }
 
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
-template <int W, int P, int FM>
-__device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
+// KMAX > 1: the multi-pick round loop (below); KMAX = 1: one sample per round.
+template <int W, int P, int FM, int KMAX = 1>
+__device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs, int deal_kcap, int pick_off, const float *__restrict__ xyz_all,
                                                 float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all, int cloud) {
     constexpr int T = 64 * W, NPAD = T * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);         // [2][16] candidate keys
     float *red = reinterpret_cast<float *>(smem_raw + 256);                                // [6][16] bbox partials
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem_raw + 1024);   // [NPAD] during the sort
-    float *sx = reinterpret_cast<float *>(smem_raw + 1024);                                // SoA cloud afterwards
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem_raw + kFpsHdr);   // [NPAD] during the sort
+    float *sx = reinterpret_cast<float *>(smem_raw + kFpsHdr);                                // SoA cloud afterwards
     int *spick = reinterpret_cast<int *>(smem_raw + pick_off);                             // [m] the samples, written out once at the end
     float *sy = sx + n;
     float *sz = sy + n;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kcap = deal_kcap >> 8, deal = deal_kcap & 0xff;   // (two small ints in one kernel argument)
     const float *xyz = xyz_all + (size_t)cloud * n * 3;
     float *temp = temp_all ? temp_all + (size_t)cloud * n : nullptr;
     int *idx = idx_all + (size_t)cloud * m;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         md[i] = ok ? (temp ? temp[k] : 1e10f) : -2.f;  // -2: below every real min-distance, never a candidate
         if (ok) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
     }
-    // bucket boxes, lane i holds the box of bucket i; per-slot tie ranks of the points
+    // bucket boxes, lane l holds the box of bucket l % P (64 / P copies: the multi-pick loop tests 64 / P samples at once); per-slot tie ranks
     float blx = INF, bly = INF, blz = INF, bhx = -INF, bhy = -INF, bhz = -INF;
     unsigned rk[P];
 #pragma unroll
@@ -198,15 +202,11 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         rk[i] = ok ? fpsb_rank(pk[i], bs, log2bs) : 0xffffffffu;
         const float a0 = wave_min_f32(ok ? px[i] : INF), a1 = wave_min_f32(ok ? py[i] : INF), a2 = wave_min_f32(ok ? pz[i] : INF);
         const float a3 = wave_max_f32(ok ? px[i] : -INF), a4 = wave_max_f32(ok ? py[i] : -INF), a5 = wave_max_f32(ok ? pz[i] : -INF);
-        if (lane == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }
+        if ((lane & (P - 1)) == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }   // lane l holds the box of bucket l % P
     }
     if (t == 0) { spick[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
     __syncthreads();
 
-    float x1 = sx[0], y1 = sy[0], z1 = sz[0];
-    float gval = INF;          // global max of the min-distances (the last winner's value): nothing can exceed it
-    float cval = -2.f;         // this wave's cached candidate (value, rank); refreshed only when one of its buckets was swept
-    unsigned crank = 0xffffffffu;
 #ifdef G4D_FPS_DEBUG
     unsigned dbg_active = 0;
     long long dbg_t[5] = {0, 0, 0, 0, 0}, dbg_c0 = 0;
@@ -214,78 +214,311 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 #else
 #define G4D_STAMP(i)
 #endif
-    for (int j = 1; j < m; ++j) {
+    if constexpr (KMAX > 1) {
+        // ---- multi-pick rounds (round 3) ---------------------------------------------------------------------------------------
+        // FPS is a chain of m - 1 dependent arg-maxes, but consecutive winners are usually INDEPENDENT: let c1 > c2 > ... be the points
+        // in the (value, tie-rank) order of the current min-distances.  Sampling c1 changes md[k] only where d(k, c1) < md[k]; if
+        // d(c2, c1) >= md[c2] then c2 keeps its key, every other key stays or drops and c1's own drops to 0, so the NEXT arg-max is c2 --
+        // exactly, ties included (keys are a total order) -- without looking at the updated distances.  By induction a whole prefix
+        // c1 .. cn goes out in one round as long as each c_i has md > 0 and is unaffected (d(c_i, c_j) >= md[c_i], the very comparison
+        // the sweep's min would make, same dist2<FM>) by every c_j before it.  On a uniform 8192-point cloud 1023 picks take ~200
+        // rounds instead of 1023 (numpy emulation; the far-apart maxima of neighbouring "holes" of the sample set are independent).
+        //   * every wave keeps its TOP TWO keys (recomputed only when one of its buckets was swept) and publishes both: 2 W keys,
+        //     one 16-byte LDS store per wave, one barrier;
+        //   * every wave then walks the merged order of the 2 W keys redundantly (same data, same code -> same result, no second
+        //     barrier): lane l holds key l with its point's coordinates (LDS SoA cloud); arg-max by DPP, accept, mark the candidates
+        //     the accepted point would change as dirty; the walk stops at a dirty or zero-valued key, after KE picks, or once a wave's
+        //     SECOND key has gone (its third is unknown, so nothing below that key is known to be next);
+        //   * next round: box tests of all accepted samples at once (lane l: bucket l % P against sample l / P), sweeps of the active
+        //     (sample, bucket) pairs (min is order-independent), pruning bound = the value of the LAST accepted key (every remaining
+        //     min-distance is <= it).
+        constexpr int KE0 = KMAX * P <= 64 ? KMAX : 64 / P;   // samples per round (compile-time bound)
+        const int KE = min(KE0, max(1, kcap));               // run-time cap (tuning hook G4D_FPS_KCAP)
+        constexpr int NK = 2 * W;                            // keys per round (<= 32)
+        static_assert(NK * 32 <= 1024 && 1024 + 256 + KE0 * 16 <= kFpsHdr, "fps multi-pick: the exchange areas must fit the LDS header");
+        static_assert(NK <= 64 && KE0 >= 1, "fps multi-pick: key / sample counts must fit a wave");
+        unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem_raw);    // [2 W] candidate records of 32 bytes: key, x, y, z (the bbox partials are dead)
+        unsigned *nstop = reinterpret_cast<unsigned *>(smem_raw + 1024);                // [2] the round's length: LDS atomic min over the candidates' stop positions (two slots, alternating)
+        float *res = reinterpret_cast<float *>(smem_raw + 1024 + 256);                  // [KE0] the round's samples in rank order: x, y, z, value
+        const int ls = lane / P;                             // which sample of the round this lane tests its box against
+        float xs = sx[0], ys = sy[0], zs = sz[0];            // lane layout: sample lane / P; round 1: the one sample is point 0
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        int ns = 1, j = 1, rpar = 0;
+        if (t == 0) { nstop[0] = 0xffu; nstop[1] = 0xffu; }   // (ordered before the first use by the barriers of round 1)
+        float gval = INF;
+        // this wave's best (lane 0) and second-best (lane 1) candidate: key (0 = none) and the point's coordinates; kept until a bucket of the wave is swept
+        unsigned long long rkey = 0ull;
+        float rx = sx[0], ry = sy[0], rz = sz[0];
 #ifdef G4D_FPS_DEBUG
-        dbg_c0 = clock64();
+        long long dbg_rounds = 0, dbg_stop[4] = {0, 0, 0, 0}, dbg_ph[4] = {0, 0, 0, 0}, dbg_actw = 0, dbg_a[4] = {0, 0, 0, 0}, dbg_pairs = 0, dbg_c1 = 0;   // stop: dirty | zero | cap | second key
 #endif
-        // 1. which buckets can change?  gap between the sample and the box, per axis, same op order as the point distance;
-        //    a bucket whose box is at least sqrt(gval) away cannot lower any min-distance (every one is <= gval)
-        const float gx = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
-        const float gy = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
-        const float gz = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
-        const float dbox = dist2<FM>(gx, gy, gz);
-        const unsigned active = (unsigned)__builtin_amdgcn_ballot_w64(lane < P && dbox < gval);
+        while (j < m) {
 #ifdef G4D_FPS_DEBUG
-        dbg_active += __builtin_popcount(active);
+            dbg_c0 = clock64(); ++dbg_rounds;
 #endif
-        G4D_STAMP(0)
-        if (active != 0u) {  // wave-uniform; about half of the waves skip the whole block in a typical round
-            // 2. sweep the active buckets
+            // 1. which (sample, bucket) pairs can change anything?
+            const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
+            const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
+            const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
+            const float dbox = dist2<FM>(gx, gy, gz);
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(ls < ns && dbox < gval);
+            if (active != 0ull) {   // wave-uniform
+                // 2. sweeps
+                for (int i = 0; i < ns; ++i) {
+                    const unsigned mi = (unsigned)(active >> (i * P)) & (P >= 32 ? 0xffffffffu : ((1u << (P & 31)) - 1u));
+                    if (mi == 0u) continue;
+                    const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), i * P));
+                    const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys), i * P));
+                    const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), i * P));
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                if ((active >> i) & 1u) {
-                    const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-                    md[i] = fpsb_min(dist2<FM>(dx, dy, dz), md[i]);
+                    for (int q = 0; q < P; ++q) {
+                        if ((mi >> q) & 1u) {
+                            const float dx = px[q] - ax, dy = py[q] - ay, dz = pz[q] - az;
+                            md[q] = fpsb_min(dist2<FM>(dx, dy, dz), md[q]);
+                        }
+                    }
                 }
+#ifdef G4D_FPS_DEBUG
+                { const long long now_ = clock64(); dbg_a[0] += now_ - dbg_c0; dbg_c1 = now_; dbg_pairs += __builtin_popcountll(active); }
+#endif
+                // 3. the lane's best and second-best slot (value, then smallest rank), then the wave's
+                float tv[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) tv[i] = md[i];
+#pragma unroll
+                for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w / 2; ++i) tv[i] = fmax_raw(tv[i], tv[i + w / 2]);
+                const float b1 = tv[0];
+                unsigned tr[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) tr[i] = (md[i] == b1) ? rk[i] : 0xffffffffu;
+#pragma unroll
+                for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w / 2; ++i) tr[i] = min(tr[i], tr[i + w / 2]);
+                const unsigned r1 = tr[0];
+#pragma unroll
+                for (int i = 0; i < P; ++i) tv[i] = (rk[i] == r1) ? -2.f : md[i];   // ranks of real points are unique: this drops exactly the best slot
+#pragma unroll
+                for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w / 2; ++i) tv[i] = fmax_raw(tv[i], tv[i + w / 2]);
+                const float b2 = tv[0];
+#pragma unroll
+                for (int i = 0; i < P; ++i) tr[i] = (md[i] == b2 && rk[i] != r1) ? rk[i] : 0xffffffffu;
+#pragma unroll
+                for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w / 2; ++i) tr[i] = min(tr[i], tr[i + w / 2]);
+                const unsigned r2 = tr[0];
+#ifdef G4D_FPS_DEBUG
+                { const long long now_ = clock64(); dbg_a[1] += now_ - dbg_c1; dbg_c1 = now_; }
+#endif
+                const float c1v = wave_max_f32(b1);
+                unsigned long long hit = __builtin_amdgcn_ballot_w64(b1 == c1v);
+                unsigned c1r;
+                int h1;
+                if (__builtin_popcountll(hit) == 1) {
+                    h1 = __builtin_ctzll(hit);
+                    c1r = (unsigned)__builtin_amdgcn_readlane((int)r1, h1);
+                } else {
+                    c1r = wave_min_u32(b1 == c1v ? r1 : 0xffffffffu);
+                    h1 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == c1v && r1 == c1r) | (1ull << 63));
+                }
+#ifdef G4D_FPS_DEBUG
+                { const long long now_ = clock64(); dbg_a[2] += now_ - dbg_c1; dbg_c1 = now_; }
+#endif
+                const float v2 = lane == h1 ? b2 : b1;
+                const unsigned q2 = lane == h1 ? r2 : r1;
+                const float c2v = wave_max_f32(v2);
+                hit = __builtin_amdgcn_ballot_w64(v2 == c2v);
+                unsigned c2r;
+                if (__builtin_popcountll(hit) == 1) c2r = (unsigned)__builtin_amdgcn_readlane((int)q2, __builtin_ctzll(hit));
+                else c2r = wave_min_u32(v2 == c2v ? q2 : 0xffffffffu);
+                {
+                    const float cvv = lane == 0 ? c1v : c2v;
+                    const unsigned crr = lane == 0 ? c1r : c2r;
+                    rkey = (cvv < 0.f || crr == 0xffffffffu) ? 0ull : (((unsigned long long)__float_as_uint(cvv) << 32) | (unsigned)(~crr));
+                    const unsigned ccls = log2bs ? (__builtin_bitreverse32(crr >> 16) >> (32 - log2bs)) : 0u;
+                    const int ci = (rkey && lane < 2) ? (int)(((crr & 0xffffu) << log2bs) | ccls) : 0;
+                    rx = sx[ci]; ry = sy[ci]; rz = sz[ci];
+                }
+#ifdef G4D_FPS_DEBUG
+                { const long long now_ = clock64(); dbg_a[3] += now_ - dbg_c1; dbg_c1 = now_; }
+#endif
             }
-            // 3. lane candidate: max value over its P points, smallest rank among the points holding it; then the wave's
-            //    (balanced trees: the round is a dependent-issue chain at ~6 cycles per instruction, depth is what counts)
-            float tv[P];
+#ifdef G4D_FPS_DEBUG
+            { const long long now_ = clock64(); dbg_ph[0] += now_ - dbg_c0; dbg_c0 = now_; dbg_actw += active != 0ull; }
+#endif
+            // 4. publish the two candidates as records {key, x, y, z}; barrier A
+            if (lane < 2) {
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u64x2 *>(&rec[(wave * 2 + lane) * 4]) = (u64x2){rkey, ((unsigned long long)__float_as_uint(ry) << 32) | __float_as_uint(rx)};
+                reinterpret_cast<float *>(rec)[(wave * 2 + lane) * 8 + 4] = rz;
+            }
+            __syncthreads();
+#ifdef G4D_FPS_DEBUG
+            { const long long now_ = clock64(); dbg_ph[1] += now_ - dbg_c0; dbg_c0 = now_; }
+#endif
+            // 5. every wave ranks ITS two candidates against all 2 W and tests them for independence, in one pass: lane (c = l / 32, jj = l % 32)
+            //    holds the pair (own candidate c, candidate jj).  rank = number of larger keys; bad = some larger key's point would lower this
+            //    candidate's min-distance (d < value: the comparison the sweep's min makes).  The sequential walk (take keys in descending
+            //    order; stop at a candidate that an earlier pick affects or whose value is 0; stop after a wave's second key) only ever tests a
+            //    candidate against ALL larger keys, so the flags of all candidates can be computed independently, here by 16 waves at once.
+            {
+                const int c = lane >> 5, jj = lane & 31;
+                const float *recf = reinterpret_cast<const float *>(rec);
+                const unsigned long long kj = jj < NK ? rec[jj * 4] : 0ull;
+                const float jx = recf[jj * 8 + 2], jy = recf[jj * 8 + 3], jz = recf[jj * 8 + 4];
+                const int me = wave * 2 + c;
+                const unsigned long long km = rec[me * 4];
+                const float mx = recf[me * 8 + 2], my = recf[me * 8 + 3], mz = recf[me * 8 + 4];
+                const float mv = __uint_as_float((unsigned)(km >> 32));
+                const bool gt = kj > km;   // (an empty slot has key 0: never larger; an empty OWN slot ranks behind every real key)
+                const bool aff = gt && !(dist2<FM>(mx - jx, my - jy, mz - jz) >= mv);
+                const unsigned long long gtm = __builtin_amdgcn_ballot_w64(gt), afm = __builtin_amdgcn_ballot_w64(aff);
+                const unsigned gth = c ? (unsigned)(gtm >> 32) : (unsigned)gtm, afh = c ? (unsigned)(afm >> 32) : (unsigned)afm;
+                const int rank = __builtin_popcount(gth);
+                // the walk stops AT this candidate (bad: affected by a larger key, empty, or -- unless it is the round's first -- value 0)
+                // or right AFTER it (a wave's second key: the wave's third is unknown; value 0)
+                const bool zero = !(mv > 0.f);
+                const bool bad = km == 0ull || afh != 0u || (zero && rank > 0);
+                const bool after = c == 1 || zero;
+                if (jj == 0) {
+                    // where the walk stops because of this candidate: AT it (bad) or right AFTER it; the round's length is the smallest
+                    atomicMin(&nstop[rpar], bad ? (unsigned)rank : (after ? (unsigned)rank + 1u : 0xffu));
+                    if (rank < KE) {   // ranks are unique among real keys: slot `rank` of the round has one writer (empty slots all carry point 0)
+                        const unsigned crk = ~(unsigned)km;
+                        const unsigned ccls = log2bs ? (__builtin_bitreverse32(crk >> 16) >> (32 - log2bs)) : 0u;
+                        *reinterpret_cast<f32x4 *>(&res[rank * 4]) = (f32x4){mx, my, mz, mv};
+                        if (j + rank < m) spick[j + rank] = km ? (int)(((crk & 0xffffu) << log2bs) | ccls) : 0;
+                    }
+                }
+                if (t == 0) nstop[rpar ^ 1] = 0xffu;   // the other slot: last read before barrier A of this round, next used after barrier A of the next
+            }
+            __syncthreads();
+            // 6. the round's length = the first stop; its samples in the lane layout of the next box test; pruning bound = the last sample's value
+            {
+                const int li = min(ls, KE0 - 1);
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(&res[li * 4]);   // (lanes of samples >= n read stale slots: masked by ls < ns)
+                int n = __builtin_amdgcn_readfirstlane((int)nstop[rpar]);
+                n = max(1, min(min(n, KE), m - j));
+                xs = sv.x; ys = sv.y; zs = sv.z;
+                gval = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.w), (n - 1) * P));
+                ns = n;
+            }
+            rpar ^= 1;
+            j += ns;
+#ifdef G4D_FPS_DEBUG
+            { const long long now_ = clock64(); dbg_ph[2] += now_ - dbg_c0; dbg_c0 = now_; }
+#endif
+        }
+        if (temp && ns > 1) {
+            // the reference's scratch ends up holding the min-distances to every sample but the LAST one (sampling_gpu.cu:129-141 updates
+            // with idx[j - 1] before it picks idx[j]): apply the final round's samples except its last
+            const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
+            const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
+            const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(ls < ns - 1 && dist2<FM>(gx, gy, gz) < INF);
+            for (int i = 0; i < ns - 1; ++i) {
+                const unsigned mi = (unsigned)(active >> (i * P)) & (P >= 32 ? 0xffffffffu : ((1u << (P & 31)) - 1u));
+                const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), i * P));
+                const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys), i * P));
+                const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), i * P));
 #pragma unroll
-            for (int i = 0; i < P; ++i) tv[i] = md[i];
-#pragma unroll
-            for (int w = P; w > 1; w >>= 1)
-#pragma unroll
-                for (int i = 0; i < w / 2; ++i) tv[i] = fmax_raw(tv[i], tv[i + w / 2]);
-            const float b = tv[0];
-            unsigned tr[P];
-#pragma unroll
-            for (int i = 0; i < P; ++i) tr[i] = (md[i] == b) ? rk[i] : 0xffffffffu;
-#pragma unroll
-            for (int w = P; w > 1; w >>= 1)
-#pragma unroll
-                for (int i = 0; i < w / 2; ++i) tr[i] = min(tr[i], tr[i + w / 2]);
-            const unsigned r = tr[0];
-            cval = wave_max_f32(b);
-            const unsigned long long hit = __builtin_amdgcn_ballot_w64(b == cval);
-            if (__builtin_popcountll(hit) == 1) {
-                crank = (unsigned)__builtin_amdgcn_readlane((int)r, __builtin_ctzll(hit));
-            } else {
-                crank = wave_min_u32(b == cval ? r : 0xffffffffu);
+                for (int q = 0; q < P; ++q)
+                    if ((mi >> q) & 1u) md[q] = fpsb_min(dist2<FM>(px[q] - ax, py[q] - ay, pz[q] - az), md[q]);
             }
         }
-        G4D_STAMP(1)
-        // 4. workgroup arg-max: ONE LDS atomic max per wave on a rotating slot, one barrier, one read
-        if (lane == 0)
-            atomicMax(&slots[j % 3], ((unsigned long long)__float_as_uint(fmaxf(cval, 0.f)) << 32) | (unsigned)(~crank));
-        __syncthreads();
-        G4D_STAMP(2)
-        const unsigned long long best = slots[j % 3];
-        if (t == 0) slots[(j + 2) % 3] = 0ull;  // next use is after the NEXT barrier; last read was before this one
-        const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(best >> 32));
-        const unsigned rank = ~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)best);
-        gval = __uint_as_float(bhi);
-        const unsigned c = log2bs ? (__builtin_bitreverse32(rank >> 16) >> (32 - log2bs)) : 0u;
-        const int old = (int)(((rank & 0xffffu) << log2bs) | c);
-        x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
-        // The pick goes to LDS, not to global memory: __syncthreads() drains the wave's outstanding global stores (vmcnt(0)), so a
-        // store issued here would put its write round trip in front of wave 0's NEXT barrier arrival -- on the critical path of a
-        // round in which wave 0 has nothing else to do.  The list (and the gathered coordinates) is written once, after the loop.
-        if (t == 0) spick[j] = old;
 #ifdef G4D_FPS_DEBUG
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0 && temp && (wave == 0 || wave == 5) && cloud == 0) {
+            float *o = temp + (wave ? 16 : 0);
+            o[0] = (float)dbg_rounds; o[1] = (float)dbg_stop[0]; o[2] = (float)dbg_stop[1]; o[3] = (float)dbg_stop[2]; o[4] = (float)dbg_stop[3];
+            o[5] = (float)dbg_ph[0]; o[6] = (float)dbg_ph[1]; o[7] = (float)dbg_ph[2]; o[8] = (float)dbg_actw;
+            o[9] = (float)dbg_a[0]; o[10] = (float)dbg_a[1]; o[11] = (float)dbg_a[2]; o[12] = (float)dbg_a[3]; o[13] = (float)dbg_pairs;
+        }
+        return;
 #endif
-        G4D_STAMP(3)
+    } else {
+        float x1 = sx[0], y1 = sy[0], z1 = sz[0];
+        float gval = INF;          // global max of the min-distances (the last winner's value): nothing can exceed it
+        float cval = -2.f;         // this wave's cached candidate (value, rank); refreshed only when one of its buckets was swept
+        unsigned crank = 0xffffffffu;
+        for (int j = 1; j < m; ++j) {
+#ifdef G4D_FPS_DEBUG
+            dbg_c0 = clock64();
+#endif
+            // 1. which buckets can change?  gap between the sample and the box, per axis, same op order as the point distance;
+            //    a bucket whose box is at least sqrt(gval) away cannot lower any min-distance (every one is <= gval)
+            const float gx = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
+            const float gy = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
+            const float gz = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
+            const float dbox = dist2<FM>(gx, gy, gz);
+            const unsigned active = (unsigned)__builtin_amdgcn_ballot_w64(lane < P && dbox < gval);
+#ifdef G4D_FPS_DEBUG
+            dbg_active += __builtin_popcount(active);
+#endif
+            G4D_STAMP(0)
+            if (active != 0u) {  // wave-uniform; about half of the waves skip the whole block in a typical round
+                // 2. sweep the active buckets
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    if ((active >> i) & 1u) {
+                        const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+                        md[i] = fpsb_min(dist2<FM>(dx, dy, dz), md[i]);
+                    }
+                }
+                // 3. lane candidate: max value over its P points, smallest rank among the points holding it; then the wave's
+                //    (balanced trees: the round is a dependent-issue chain at ~6 cycles per instruction, depth is what counts)
+                float tv[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) tv[i] = md[i];
+#pragma unroll
+                for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w / 2; ++i) tv[i] = fmax_raw(tv[i], tv[i + w / 2]);
+                const float b = tv[0];
+                unsigned tr[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) tr[i] = (md[i] == b) ? rk[i] : 0xffffffffu;
+#pragma unroll
+                for (int w = P; w > 1; w >>= 1)
+#pragma unroll
+                    for (int i = 0; i < w / 2; ++i) tr[i] = min(tr[i], tr[i + w / 2]);
+                const unsigned r = tr[0];
+                cval = wave_max_f32(b);
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(b == cval);
+                if (__builtin_popcountll(hit) == 1) {
+                    crank = (unsigned)__builtin_amdgcn_readlane((int)r, __builtin_ctzll(hit));
+                } else {
+                    crank = wave_min_u32(b == cval ? r : 0xffffffffu);
+                }
+            }
+            G4D_STAMP(1)
+            // 4. workgroup arg-max: ONE LDS atomic max per wave on a rotating slot, one barrier, one read
+            if (lane == 0)
+                atomicMax(&slots[j % 3], ((unsigned long long)__float_as_uint(fmaxf(cval, 0.f)) << 32) | (unsigned)(~crank));
+            __syncthreads();
+            G4D_STAMP(2)
+            const unsigned long long best = slots[j % 3];
+            if (t == 0) slots[(j + 2) % 3] = 0ull;  // next use is after the NEXT barrier; last read was before this one
+            const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(best >> 32));
+            const unsigned rank = ~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)best);
+            gval = __uint_as_float(bhi);
+            const unsigned c = log2bs ? (__builtin_bitreverse32(rank >> 16) >> (32 - log2bs)) : 0u;
+            const int old = (int)(((rank & 0xffffu) << log2bs) | c);
+            x1 = sx[old]; y1 = sy[old]; z1 = sz[old];
+            // The pick goes to LDS, not to global memory: __syncthreads() drains the wave's outstanding global stores (vmcnt(0)), so a
+            // store issued here would put its write round trip in front of wave 0's NEXT barrier arrival -- on the critical path of a
+            // round in which wave 0 has nothing else to do.  The list (and the gathered coordinates) is written once, after the loop.
+            if (t == 0) spick[j] = old;
+#ifdef G4D_FPS_DEBUG
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            G4D_STAMP(3)
+        }
     }
     __syncthreads();
     for (int j = t; j < m; j += T) {
@@ -306,20 +539,30 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 #endif
 }
 
-template <int W, int P, int FM>
+template <int W, int P, int FM, int KMAX>
 __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
-    fps_bucket_body<W, P, FM>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
+    fps_bucket_body<W, P, FM, KMAX>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
+}
+
+// samples per round of the bucketed kernels: 8 (multi-pick, default) or 1 (G4D_FPS_MULTI=1: one arg-max per round, the round-2 loop)
+static int fps_multi() {
+    static const int k = getenv("G4D_FPS_MULTI") ? atoi(getenv("G4D_FPS_MULTI")) : 8;
+    return k > 1 ? 8 : 1;
+}
+static int fps_kcap() {   // tuning hook: at most this many samples per round
+    static const int k = getenv("G4D_FPS_KCAP") ? atoi(getenv("G4D_FPS_KCAP")) : 8;
+    return k < 1 ? 1 : (k > 64 ? 64 : k);
 }
 
 // The sampling launch with a second ROLE: workgroups [0, b) run the FPS of cloud blockIdx.x, workgroups [b, 2 b) build the ball-query
 // cell grid of cloud blockIdx.x - b (ball_grid_build.h).  Both depend on the cloud only; the grid build (17 us alone, one workgroup per
 // cloud) disappears behind the 750 us of the sampling and the step has one launch fewer.
-template <int FM>
+template <int FM, int KMAX>
 __global__ void __launch_bounds__(1024) fps_bucket_grid_kernel(int b, int n, int m, int bs, int log2bs, int deal, int pick_off,
                                                               const float *__restrict__ xyz_all, int *__restrict__ idx_all, float *__restrict__ nx_all,
                                                               int cmax, float cell_req, unsigned char *__restrict__ ws_all, size_t ws_stride) {
-    if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
+    if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM, KMAX>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
     else ball_grid_build_body(n, cmax, cmax, cell_req, xyz_all, ws_all, ws_stride, (int)blockIdx.x - b);
 }
 
@@ -327,15 +570,17 @@ template <int W, int P, int FM>
 static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
-    const size_t pick_off = (1024 + body + 15) & ~(size_t)15;
+    const size_t pick_off = (kFpsHdr + body + 15) & ~(size_t)15;
     const size_t lds = pick_off + (size_t)m * 4;
-    auto kern = fps_bucket_kernel<W, P, FM>;
-    static unsigned long long attr_done = 0;  // one bit per device
-    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done, "g4d_fps_f32(bucketed)")) return rc;
+    if (lds > 160 * 1024 - 1024) return -1;   // the pick list lives in LDS: m beyond ~15.8k at n = 8192 goes to the next route (fps.hip)
+    const bool multi = fps_multi() > 1;
+    auto kern = multi ? fps_bucket_kernel<W, P, FM, 8> : fps_bucket_kernel<W, P, FM, 1>;
+    static unsigned long long attr_done[2] = {0, 0};  // one bit per device
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done[multi], "g4d_fps_f32(bucketed)")) return rc;
     // measured at N = 8192, M = 1024, B = 8 (scripts/time_fps.py): deal 1 / 2 / 4 / 8 -> 0.812 / 0.783 / 0.757 / 0.748 us per round
     static const int deal_env = getenv("G4D_FPS_DEAL") ? atoi(getenv("G4D_FPS_DEAL")) : 0;  // tuning hook: 1 | 2 | 4 | ... | P; 0 = P
     const int deal = (deal_env >= 1 && deal_env <= P && P % deal_env == 0) ? deal_env : P;
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal, (int)pick_off, xyz, temp, idx, nx);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, n, m, bs, log2bs, deal | (fps_kcap() << 8), (int)pick_off, xyz, temp, idx, nx);
     return check_launch("g4d_fps_f32(bucketed)");
 }
 
@@ -351,18 +596,25 @@ int fps_bucket_grid_launch(int b, int n, int m, int bs, int log2bs, const float 
     constexpr int W = 16, P = 8;
     const size_t npad = (size_t)64 * W * P;
     const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
-    const size_t pick_off = (1024 + body + 15) & ~(size_t)15;
+    const size_t pick_off = (kFpsHdr + body + 15) & ~(size_t)15;
     const int cmax = grid_cmax(n);
     const size_t lds_fps = pick_off + (size_t)m * 4, lds_grid = ((size_t)cmax + 1) * 4 + 16 * 8 * 4;
     const size_t lds = lds_fps > lds_grid ? lds_fps : lds_grid;
-    static unsigned long long attr[3] = {0, 0, 0};
+    if (lds > 160 * 1024 - 1024) return -1;   // (pick list too long for LDS: the caller falls back to two launches)
+    static unsigned long long attr[6] = {0, 0, 0, 0, 0, 0};
     const int mode = distance_contraction();
-    const int slot = mode == 0 ? 0 : (mode == 1 ? 1 : 2);
-    const void *k = slot == 0 ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<0>)
-                    : (slot == 1 ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<1>) : reinterpret_cast<const void *>(fps_bucket_grid_kernel<2>));
+    const bool multi = fps_multi() > 1;
+    const int slot = (mode == 0 ? 0 : (mode == 1 ? 1 : 2)) + (multi ? 3 : 0);
+    const void *k = nullptr;
+    G4D_WITH_FM(mode, k = multi ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 8>) : reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 1>))
     if (const int rc = ensure_dynamic_lds(k, 160 * 1024 - 1024, attr[slot], "g4d_fps_gather_grid_f32")) return rc;
-    G4D_WITH_FM(mode, hipLaunchKernelGGL(fps_bucket_grid_kernel<FM>, dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P, (int)pick_off, xyz, idx, nx,
-                                         cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
+    if (multi) {
+        G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_bucket_grid_kernel<FM, 8>), dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P | (fps_kcap() << 8), (int)pick_off, xyz, idx, nx,
+                                             cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
+    } else {
+        G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_bucket_grid_kernel<FM, 1>), dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P | (fps_kcap() << 8), (int)pick_off, xyz, idx, nx,
+                                             cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
+    }
     return check_launch("g4d_fps_gather_grid_f32");
 }
 

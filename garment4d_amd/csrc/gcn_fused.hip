@@ -98,21 +98,22 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
     }
     if constexpr (FAST) {
         // the tile's CSR rows, padded to `ell` (column offset into `win`, weight) pairs each: the aggregation loop then has a
-        // block-uniform trip count and no per-entry predicate (a padded pair adds 0 * (the row's first neighbour) -- exactly
-        // nothing for finite activations).  Thread t fills pairs t, t + 256, ...
+        // block-uniform trip count and no per-entry predicate.  A padded pair is (the ZERO row behind the window, weight 0): it adds
+        // 0 * 0 whatever the activations hold -- pointing it at a real neighbour row would turn an inf / NaN there into NaN for rows
+        // that do not reference it (an isolated vertex must come out as bias only, as g4d_spmm_rows_f32 gives).  Thread t fills
+        // pairs t, t + 256, ...
         for (int k = t; k < kTile * kEll; k += 256) {
             const int r = k / kEll, j = k - r * kEll;
-            int col = lo;
+            int off = kWin * kLdW;
             float w = 0.f;
             if (r < nrows) {
                 const int b = a.rowptr[r0 + r], n = a.rowptr[r0 + r + 1] - b;
-                if (n > 0) {
-                    const int e = b + (j < n ? j : 0);
-                    col = a.colidx[e];
-                    w = j < n ? a.vals[e] : 0.f;
+                if (j < n) {
+                    off = (a.colidx[b + j] - lo) * kLdW;
+                    w = a.vals[b + j];
                 }
             }
-            ent[k] = make_int2((col - lo) * kLdW, __float_as_int(w));
+            ent[k] = make_int2(off, __float_as_int(w));
         }
         maxlen = ell;
     } else {
@@ -264,7 +265,7 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
 template <int NT, int TILE>
 __global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(const GcnFusedArgs a) {
     constexpr int kTile = TILE, kWin = Geo<TILE>::kWin;
-    __shared__ __attribute__((aligned(16))) float win[kWin * kLdW];
+    __shared__ __attribute__((aligned(16))) float win[(kWin + 1) * kLdW];   // + one row of zeros: the target of padded CSR pairs
     __shared__ __attribute__((aligned(16))) float asl[kTile * kLd];
     __shared__ int2 ent[kTile * kEll];
     __shared__ int s_lohi[3];   // window [lo, hi], longest row
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(cons
     const int nrows = min(kTile, a.vg - r0);
     // window of the tile: [lo, hi) over the column indices of its rows (a contiguous CSR range)
     if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; s_lohi[2] = 0; }
+    if (t < kLdW) win[kWin * kLdW + t] = 0.f;
     lds_barrier();
     const int e0 = a.rowptr[r0], e1 = a.rowptr[r0 + nrows];
     {

@@ -31,6 +31,7 @@ struct ChainLayer {
     const float *shift;
     int kst;             // Kpad / 16: k-steps per channel tile in W
     int relu, cout;
+    int fmask;           // -1; 0 under the weight-streaming diagnostic (every fragment load reads fragment 0)
 };
 
 struct ChainArgs {
@@ -39,6 +40,8 @@ struct ChainArgs {
     int tap_layer;   // hidden layer whose activations are also written to HBM (-1: none)
     float *tap_out;
     int tap_ld;
+    int xcd_swz;     // workgroup -> row-block map: 1 = every XCD (blockIdx % 8) takes one CONTIGUOUS eighth of the row blocks
+    int dbg_wsame;   // diagnostic only (G4D_CHAIN_DBG_WSAME=1, wrong results): every weight fragment load reads fragment 0
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
@@ -96,7 +99,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TOUT][MT]) {
 constexpr int kWDepth = 6;
 
 __device__ __forceinline__ f32x4 load_wfrag(const ChainLayer &L, int ct, int ks, int lane) {
-    return *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
+    return *reinterpret_cast<const f32x4 *>(L.W + ((size_t)((ct * L.kst + ks) & L.fmask) * 64 + lane) * 4);
 }
 
 // the first kWDepth fragments of a chained layer (fragment f = ks * TOUT + ct), requested before the previous layer's epilogue
@@ -321,13 +324,22 @@ __device__ __forceinline__ void tap_store(const ChainArgs &s, int cout, int lane
     }
 }
 
+// One role of a launch: workgroup `bid` of `nb` runs the stack described by `s` over its 64 * MT rows.
 template <int MODE, int T1, int T2, int T3, int T4, int MT>
-__global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
-    __shared__ float xch[4 * 256];  // pooling partials of the 4 waves when a group spans waves (<= 256 channels)
+__device__ __forceinline__ void chain_body(const ChainArgs &s, int bid, int nb, float *xch) {
     const LinearArgs &a = s.in;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row0 = (blockIdx.x * 4 + wave) * (16 * MT);
+    // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  With the identity map every
+    // XCD touches every cloud's gather source (tables, features: 4 MB at the last FP level = one whole L2); with the swizzle XCD x owns
+    // the x-th contiguous eighth of the row blocks -- at B = 8 one cloud -- and its L2 holds only that eighth of the source.
+    // (Measured neutral on the cfg2 step, 32.9k frames/s either way: the gathers are latency-, not capacity-bound.  Kept: it is free.)
+    int wg = bid;
+    if (s.xcd_swz) {
+        const int q = nb >> 3, r = nb & 7, x = wg & 7;
+        wg = x * q + min(x, r) + (wg >> 3);
+    }
+    const int row0 = (wg * 4 + wave) * (16 * MT);
     G4D_CSTAMP(0)
     f32x4 h1[T1][MT];
     f32x4 ring[kWDepth];  // weight fragments in flight for the next chained layer (requested BEFORE the current layer's epilogue)
@@ -376,6 +388,22 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
     G4D_CSTAMP(4)
 }
 
+template <int MODE, int T1, int T2, int T3, int T4, int MT>
+__global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
+    __shared__ float xch[4 * 256];  // pooling partials of the 4 waves when a group spans waves (<= 256 channels)
+    chain_body<MODE, T1, T2, T3, T4, MT>(s, blockIdx.x, gridDim.x, xch);
+}
+
+// Two independent stacks in ONE launch: workgroups [0, nb0) run role A, the rest role B (each a grid of its own).  Every launch costs
+// the 16-stream regime ~2.4 us of serialised dispatch on top of its ramp and tail (scripts/exp_dispatch.py: a one-workgroup kernel
+// costs 0.9 us per launch with 4-8 streams in flight, 2.35 with 16, 6.5 with 32), so the two scales of an MSG level share one.
+template <int MODE, int A1, int A2, int A3, int A4, int AMT, int B1, int B2, int B3, int B4, int BMT>
+__global__ void __launch_bounds__(256) mlp_chain_pair_kernel(const ChainArgs sa, const ChainArgs sb, int nb0) {
+    __shared__ float xch[4 * 256];
+    if ((int)blockIdx.x < nb0) chain_body<MODE, A1, A2, A3, A4, AMT>(sa, blockIdx.x, nb0, xch);
+    else chain_body<MODE, B1, B2, B3, B4, BMT>(sb, (int)blockIdx.x - nb0, (int)gridDim.x - nb0, xch);
+}
+
 template <int T1, int T2, int T3, int T4, int MT>
 static void launch_chain(int mode, const ChainArgs &s, hipStream_t st) {
     const long long rows_per_wg = 4ll * 16 * MT;
@@ -419,64 +447,7 @@ extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
     }
 }
 
-static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
-                          const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
-                          int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
-                          int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
-                          const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
-                          int tap_layer, float *tap_out, int tap_ld, const float *pre_scale, const float *pre_shift, float *in_tap,
-                          int in_tap_ld, const float *tab, int tab_ld, const float *tab_wx, g4d_stream_t stream) {
-    G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP || mode == LOAD_INTERP, "g4d_mlp_chain_f32: mode must be 0 (direct), 1 (group) or 2 (interp)");
-    G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
-    if (rows == 0) return G4D_OK;
-    G4D_REQUIRE(W && scale && shift && Kpad && Cout && relu && out, "g4d_mlp_chain_f32: null pointer");
-    G4D_REQUIRE(g4d_mlp_chain_supported(nlayers, Cout), "g4d_mlp_chain_f32: unsupported layer widths (see g4d_mlp_chain_supported)");
-    G4D_REQUIRE(pool >= 0 && pool <= 2, "g4d_mlp_chain_f32: pool must be 0|1|2");
-    if (pool) G4D_REQUIRE((S == 4 || S == 8 || S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_chain_f32: pooling needs S in {4,8,16,32,64}");
-    ChainArgs s = {};
-    s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
-    s.in.X = X; s.in.ldx = ldx;
-    s.in.xyz = xyz; s.in.new_xyz = new_xyz; s.in.feats = feats; s.in.idx = idx; s.in.N = N; s.in.P = P; s.in.C = C; s.in.use_xyz = use_xyz;
-    s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
-    s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
-    G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
-    if (tab && mode == LOAD_INTERP) {
-        G4D_REQUIRE(C2 == 0 && C1 > 0 && K0 == C1 && skip && nlayers >= 2 && Cout[0] % 16 == 0 && tab_ld >= Cout[0] && tab_ld % 4 == 0 &&
-                    (reinterpret_cast<size_t>(tab) & 15) == 0 && !pre_scale, "g4d_mlp_chain_interp_init_f32: needs skip features, >= 2 layers, a first-layer width that "
-                    "is a multiple of 16 and a 16-byte aligned table at least that wide");
-        s.in.tab = tab; s.in.tab_ld = tab_ld;
-    } else if (tab) {
-        G4D_REQUIRE(mode == LOAD_GROUP && K0 % 16 == 0 && tab_ld >= K0 && tab_ld % 4 == 0 && (reinterpret_cast<size_t>(tab) & 15) == 0 && tab_wx && pre_scale &&
-                    pre_shift && xyz && new_xyz && idx, "g4d_mlp_chain_group_table_f32: needs a 16-byte aligned table whose width is a multiple of 16, the xyz "
-                    "weights, the affine and the grouping inputs");
-        s.in.tab = tab; s.in.tab_ld = tab_ld; s.in.tab_wx = tab_wx; s.in.pre_scale = pre_scale; s.in.pre_shift = pre_shift;
-    } else if (pre_scale) {
-        G4D_REQUIRE(mode == LOAD_INTERP && C1 == 0 && C2 % 16 == 0 && K0 == C2 && pre_shift, "g4d_mlp_chain_table_f32: needs the interpolating loader, "
-                    "no skip features and a table width that is a multiple of 16");
-        G4D_REQUIRE(!in_tap || (in_tap_ld >= C2 && in_tap_ld % 4 == 0 && (reinterpret_cast<size_t>(in_tap) & 15) == 0), "g4d_mlp_chain_table_f32: bad input tap");
-        s.in.pre_scale = pre_scale; s.in.pre_shift = pre_shift; s.in.in_tap = in_tap; s.in.in_tap_ld = in_tap_ld;
-    }
-    for (int l = 0; l < nlayers; ++l) {
-        G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 16 == 0 && Cout[l] > 0, "g4d_mlp_chain_f32: bad layer %d", l);
-        G4D_REQUIRE(Kpad[l] >= (l == 0 ? K0 : Cout[l - 1]), "g4d_mlp_chain_f32: Kpad of layer %d too small", l);
-        s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
-        s.layer[l].kst = Kpad[l] / 16; s.layer[l].relu = relu[l]; s.layer[l].cout = Cout[l];
-    }
-    const int key = chain_key(nlayers, Cout);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // rows per wave (16 * MT).  Measured on the cfg2 stacks (scripts/time_stacks.py, G4D_CHAIN_MT sweep): 32 rows per wave win
-    // once the launch still has >= 2048 waves (each weight fragment load then feeds 8 MFMAs); 16 rows per wave otherwise (small
-    // launches need the waves); 64 rows per wave never won.  The widest stacks (128-wide first layer) at 1024 waves -- SA3 scale 1 of
-    // cfg2 -- are 6 % faster ALONE with 32 rows per wave (37.5 vs 40.1 us behind the table loader), but that instantiation holds 378
-    // registers: one wave per SIMD and none on a CU that hosts a sampling workgroup; with 16 batches in flight the 16-row one (212
-    // registers, two per SIMD, one beside the FPS waves) gives 30.2k instead of 29.8k frames/s, so it is the default
-    // (G4D_CHAIN_MT2_MIN_WAVES_WIDE=1024 restores the other choice).
-    const long long waves32 = (rows + 31) / 32;
-    static const int mt_env = getenv("G4D_CHAIN_MT") ? atoi(getenv("G4D_CHAIN_MT")) : 0;  // tuning hook: 1 | 2
-    const bool wide = key >= 8000000;
-    static const long long mt2_min = getenv("G4D_CHAIN_MT2_MIN_WAVES") ? atoll(getenv("G4D_CHAIN_MT2_MIN_WAVES")) : 2048;      // tuning hooks
-    static const long long mt2_min_wide = getenv("G4D_CHAIN_MT2_MIN_WAVES_WIDE") ? atoll(getenv("G4D_CHAIN_MT2_MIN_WAVES_WIDE")) : 2048;
-    const int mt = mt_env ? (mt_env >= 2 ? 2 : 1) : ((waves32 >= mt2_min || (wide && waves32 >= mt2_min_wide)) ? 2 : 1);
+static int chain_launch_one(int mode, int key, int mt, const ChainArgs &s, hipStream_t st) {
 #define G4D_CHAIN(T1, T2, T3, T4)                                   \
     if (mt == 2) launch_chain<T1, T2, T3, T4, 2>(mode, s, st);      \
     else launch_chain<T1, T2, T3, T4, 1>(mode, s, st);              \
@@ -505,6 +476,142 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
     }
 #undef G4D_CHAIN
     return check_launch("g4d_mlp_chain_f32");
+}
+
+// ---- launch groups: independent stacks recorded between g4d_launch_group_begin() and g4d_launch_group_end() go out as ONE launch
+// when a merged kernel is instantiated for the combination (the two scales of an MSG level), one launch each otherwise.  Per host
+// thread, like the error text.
+constexpr int kMaxRoles = 4;
+struct ChainRole { ChainArgs s; int mode, key, mt; };
+static thread_local struct { bool active; int n; ChainRole role[kMaxRoles]; } g_group = {false, 0, {}};
+
+static long long role_blocks(const ChainRole &r) { const long long per = 64ll * r.mt; return (r.s.in.rows + per - 1) / per; }
+
+// role A = the heavier stack (its workgroups are dispatched first: the launch's tail is then the light role's)
+static bool chain_launch_pair(const ChainRole &A, const ChainRole &B, hipStream_t st) {
+    if (A.mode != LOAD_GROUP || B.mode != LOAD_GROUP) return false;
+    const long long na = role_blocks(A), nb = role_blocks(B);
+    if (na + nb >= (1ll << 31)) return false;
+    const dim3 grid((unsigned)(na + nb)), block(256);
+#define G4D_PAIR(KA, MA, KB, MB, ...)                                                                                   \
+    if (A.key == KA && A.mt == MA && B.key == KB && B.mt == MB) {                                                       \
+        hipLaunchKernelGGL((mlp_chain_pair_kernel<LOAD_GROUP, __VA_ARGS__>), grid, block, 0, st, A.s, B.s, (int)na);    \
+        return true;                                                                                                    \
+    }
+    G4D_PAIR(4080000, 2, 2040000, 1, 4, 8, 0, 0, 2, 2, 4, 0, 0, 1)     // SA level 2 of Pointnet2MSGSEG at B = 8: 64-128 on 65536 rows + 32-64 on 32768
+    G4D_PAIR(8160000, 1, 4080000, 1, 8, 16, 0, 0, 1, 4, 8, 0, 0, 1)    // SA level 3: 128-256 on 32768 rows + 64-128 on 16384
+    G4D_PAIR(4080000, 2, 2040000, 2, 4, 8, 0, 0, 2, 2, 4, 0, 0, 2)     // larger batches (both scales at 32 rows per wave)
+    G4D_PAIR(4080000, 1, 2040000, 1, 4, 8, 0, 0, 1, 2, 4, 0, 0, 1)     // smaller ones
+#undef G4D_PAIR
+    return false;
+}
+
+extern "C" int g4d_launch_group_begin(void) {
+    G4D_REQUIRE(!g_group.active, "g4d_launch_group_begin: a group is already open on this thread");
+    g_group.active = true;
+    g_group.n = 0;
+    return G4D_OK;
+}
+
+// Launches what was recorded (on `stream`) and closes the group; *launches (optional) = the number of kernel launches it took.
+extern "C" int g4d_launch_group_end(g4d_stream_t stream, int *launches) {
+    G4D_REQUIRE(g_group.active, "g4d_launch_group_end: no open group on this thread");
+    g_group.active = false;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int n = g_group.n;
+    g_group.n = 0;
+    static const int merge = getenv("G4D_LAUNCH_GROUPS") ? atoi(getenv("G4D_LAUNCH_GROUPS")) : 1;   // A/B switch: 0 = one launch per recorded stack
+    if (launches) *launches = n;
+    if (n == 2 && merge) {
+        const ChainRole &r0 = g_group.role[0], &r1 = g_group.role[1];
+        const bool heavy0 = role_blocks(r0) * r0.mt * (r0.key / 10000) >= role_blocks(r1) * r1.mt * (r1.key / 10000);
+        const ChainRole &A = heavy0 ? r0 : r1, &B = heavy0 ? r1 : r0;
+        if (chain_launch_pair(A, B, st)) {
+            if (launches) *launches = 1;
+            return check_launch("g4d_launch_group_end");
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (int rc = chain_launch_one(g_group.role[i].mode, g_group.role[i].key, g_group.role[i].mt, g_group.role[i].s, st)) return rc;
+    return G4D_OK;
+}
+
+// drops an open group without launching anything (error paths of the host layer)
+extern "C" int g4d_launch_group_abort(void) {
+    g_group.active = false;
+    g_group.n = 0;
+    return G4D_OK;
+}
+
+static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                          const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                          int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
+                          int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
+                          const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
+                          int tap_layer, float *tap_out, int tap_ld, const float *pre_scale, const float *pre_shift, float *in_tap,
+                          int in_tap_ld, const float *tab, int tab_ld, const float *tab_wx, g4d_stream_t stream) {
+    G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP || mode == LOAD_INTERP, "g4d_mlp_chain_f32: mode must be 0 (direct), 1 (group) or 2 (interp)");
+    G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
+    if (rows == 0) return G4D_OK;
+    G4D_REQUIRE(W && scale && shift && Kpad && Cout && relu && out, "g4d_mlp_chain_f32: null pointer");
+    G4D_REQUIRE(g4d_mlp_chain_supported(nlayers, Cout), "g4d_mlp_chain_f32: unsupported layer widths (see g4d_mlp_chain_supported)");
+    G4D_REQUIRE(pool >= 0 && pool <= 2, "g4d_mlp_chain_f32: pool must be 0|1|2");
+    if (pool) G4D_REQUIRE((S == 4 || S == 8 || S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_chain_f32: pooling needs S in {4,8,16,32,64}");
+    static const int xcd_swz = getenv("G4D_CHAIN_XCD") ? atoi(getenv("G4D_CHAIN_XCD")) : 1;          // A/B switch
+    static const int dbg_wsame = getenv("G4D_CHAIN_DBG_WSAME") ? atoi(getenv("G4D_CHAIN_DBG_WSAME")) : 0;
+    ChainArgs s = {};
+    s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
+    s.in.X = X; s.in.ldx = ldx;
+    s.in.xyz = xyz; s.in.new_xyz = new_xyz; s.in.feats = feats; s.in.idx = idx; s.in.N = N; s.in.P = P; s.in.C = C; s.in.use_xyz = use_xyz;
+    s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
+    s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
+    G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
+    if (tab && mode == LOAD_INTERP) {
+        G4D_REQUIRE(C2 == 0 && C1 > 0 && K0 == C1 && skip && nlayers >= 2 && Cout[0] % 16 == 0 && tab_ld >= Cout[0] && tab_ld % 4 == 0 &&
+                    (reinterpret_cast<size_t>(tab) & 15) == 0 && !pre_scale, "g4d_mlp_chain_interp_init_f32: needs skip features, >= 2 layers, a first-layer width that "
+                    "is a multiple of 16 and a 16-byte aligned table at least that wide");
+        s.in.tab = tab; s.in.tab_ld = tab_ld;
+    } else if (tab) {
+        G4D_REQUIRE(mode == LOAD_GROUP && K0 % 16 == 0 && tab_ld >= K0 && tab_ld % 4 == 0 && (reinterpret_cast<size_t>(tab) & 15) == 0 && tab_wx && pre_scale &&
+                    pre_shift && xyz && new_xyz && idx, "g4d_mlp_chain_group_table_f32: needs a 16-byte aligned table whose width is a multiple of 16, the xyz "
+                    "weights, the affine and the grouping inputs");
+        s.in.tab = tab; s.in.tab_ld = tab_ld; s.in.tab_wx = tab_wx; s.in.pre_scale = pre_scale; s.in.pre_shift = pre_shift;
+    } else if (pre_scale) {
+        G4D_REQUIRE(mode == LOAD_INTERP && C1 == 0 && C2 % 16 == 0 && K0 == C2 && pre_shift, "g4d_mlp_chain_table_f32: needs the interpolating loader, "
+                    "no skip features and a table width that is a multiple of 16");
+        G4D_REQUIRE(!in_tap || (in_tap_ld >= C2 && in_tap_ld % 4 == 0 && (reinterpret_cast<size_t>(in_tap) & 15) == 0), "g4d_mlp_chain_table_f32: bad input tap");
+        s.in.pre_scale = pre_scale; s.in.pre_shift = pre_shift; s.in.in_tap = in_tap; s.in.in_tap_ld = in_tap_ld;
+    }
+    for (int l = 0; l < nlayers; ++l) {
+        G4D_REQUIRE(W[l] && scale[l] && shift[l] && Kpad[l] % 16 == 0 && Cout[l] > 0, "g4d_mlp_chain_f32: bad layer %d", l);
+        G4D_REQUIRE(Kpad[l] >= (l == 0 ? K0 : Cout[l - 1]), "g4d_mlp_chain_f32: Kpad of layer %d too small", l);
+        s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
+        s.layer[l].kst = Kpad[l] / 16; s.layer[l].relu = relu[l]; s.layer[l].cout = Cout[l];
+        s.layer[l].fmask = dbg_wsame ? 0 : -1;
+    }
+    s.xcd_swz = xcd_swz; s.dbg_wsame = dbg_wsame;
+    const int key = chain_key(nlayers, Cout);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // rows per wave (16 * MT).  Measured on the cfg2 stacks (scripts/time_stacks.py, G4D_CHAIN_MT sweep): 32 rows per wave win
+    // once the launch still has >= 2048 waves (each weight fragment load then feeds 8 MFMAs); 16 rows per wave otherwise (small
+    // launches need the waves); 64 rows per wave never won.  The widest stacks (128-wide first layer) at 1024 waves -- SA3 scale 1 of
+    // cfg2 -- are 6 % faster ALONE with 32 rows per wave (37.5 vs 40.1 us behind the table loader), but that instantiation holds 378
+    // registers: one wave per SIMD and none on a CU that hosts a sampling workgroup; with 16 batches in flight the 16-row one (212
+    // registers, two per SIMD, one beside the FPS waves) gives 30.2k instead of 29.8k frames/s, so it is the default
+    // (G4D_CHAIN_MT2_MIN_WAVES_WIDE=1024 restores the other choice).
+    const long long waves32 = (rows + 31) / 32;
+    static const int mt_env = getenv("G4D_CHAIN_MT") ? atoi(getenv("G4D_CHAIN_MT")) : 0;  // tuning hook: 1 | 2
+    const bool wide = key >= 8000000;
+    static const long long mt2_min = getenv("G4D_CHAIN_MT2_MIN_WAVES") ? atoll(getenv("G4D_CHAIN_MT2_MIN_WAVES")) : 2048;      // tuning hooks
+    static const long long mt2_min_wide = getenv("G4D_CHAIN_MT2_MIN_WAVES_WIDE") ? atoll(getenv("G4D_CHAIN_MT2_MIN_WAVES_WIDE")) : 2048;
+    const int mt = mt_env ? (mt_env >= 2 ? 2 : 1) : ((waves32 >= mt2_min || (wide && waves32 >= mt2_min_wide)) ? 2 : 1);
+    if (g_group.active) {   // inside g4d_launch_group_begin / _end: the stack becomes a role of the group's launch
+        G4D_REQUIRE(g_group.n < kMaxRoles, "g4d_launch_group: more than %d recorded launches", kMaxRoles);
+        ChainRole &r = g_group.role[g_group.n++];
+        r.s = s; r.mode = mode; r.key = key; r.mt = mt;
+        return G4D_OK;
+    }
+    return chain_launch_one(mode, key, mt, s, st);
 }
 
 extern "C" int g4d_mlp_chain_f32(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,

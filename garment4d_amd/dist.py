@@ -113,7 +113,9 @@ def allgather_frames(local: torch.Tensor, n_total: int, group=WORLD) -> torch.Te
 def clip_max_over_frames(frame_feats_local: torch.Tensor, frame_ids_local: torch.Tensor, n_clips: int, T: int,
                          group=None) -> torch.Tensor:
     """max over the T frames of each clip; when a clip's frames live on several ranks (`group` given, see resolve_group) the
-    per-rank partial maxima are combined by all_reduce(MAX).
+    per-rank partial maxima are combined by all_reduce(MAX).  group=None NEVER reduces across ranks (an initialised default group is
+    not a request, see resolve_group): a clip without a local frame then yields a -inf row -- callers that shard frames pass
+    group=WORLD (PCAGarmentEncoderSeg.forward raises when a frame shard arrives without a group).
     frame_feats_local (f_local, C); frame_ids_local (f_local,) global frame ids (clip = id // T) -> (n_clips, C)."""
     C = frame_feats_local.shape[1]
     out = frame_feats_local.new_full((n_clips, C), float("-inf"))

@@ -13,6 +13,7 @@ layout -- are produced only at the API boundary (`to_channel_major`).  Torch is 
 parameter packing only; every FLOP of the forward runs in libg4d_hip.so.  Train-mode BatchNorm needs batch
 statistics over the grouped tensor and stays on the op-by-op path (pointnet2_modules.py).
 """
+import contextlib
 import ctypes
 import os
 
@@ -440,10 +441,19 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     return outs
 
 
+def _fps_needs_no_scratch(N, npoint):
+    """Mirrors fps_impl (csrc/fps.hip): the register-resident / bucketed sampling kernels keep the cloud and the pick list in LDS and
+    take temp = NULL; everything else (N < 64, N > 12800, or a pick list that does not fit beside the cloud) runs the generic kernel,
+    which needs the reference's (B, N) scratch initialised to 1e10."""
+    return N >= 64 and N * 12 + npoint * 4 + 512 <= 158 * 1024 and N <= 12800
+
+
 def fps_gather_grid(xyz, npoint, rmax):
     """(new_xyz, grid) = (fps_gather(xyz, npoint), build_ball_grid(xyz, rmax)) -- one launch for 4096 < N <= 8192 (g4d_fps_gather_grid_f32:
     the grid build rides in the sampling launch as extra workgroups), two otherwise; identical results."""
     B, N, _ = _chk(xyz).shape
+    if not _fps_needs_no_scratch(N, npoint):   # the sampling would need its (B, N) scratch, which this entry point has no slot for
+        return fps_gather(xyz, npoint), build_ball_grid(xyz, rmax)
     sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
     ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B, N), 16), dtype=torch.uint8, device=xyz.device)
@@ -495,7 +505,7 @@ def fps_gather(xyz, npoint, sidx=None, new_xyz=None):
         sidx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     if new_xyz is None:
         new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
-    reg = N >= 64 and N * 12 + npoint * 4 + 512 <= 158 * 1024 and N <= 12800   # register-resident FPS (cloud + pick list in LDS): no scratch
+    reg = _fps_needs_no_scratch(N, npoint)   # register-resident FPS (cloud + pick list in LDS): no scratch
     temp = None if reg else torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
     # the sampling kernel writes the selected coordinates as it goes (g4d_fps_gather_f32): no gather launch
     _lib.call("g4d_fps_gather_f32", B, N, npoint, xyz.data_ptr(), _ptr(temp), sidx.data_ptr(), new_xyz.data_ptr(), stream)
@@ -539,6 +549,26 @@ def sampling_chain(xyz, npoints):
             out.append((nx, ev, sidx))   # sidx rides along: the caller must keep it alive until its stream has waited for `ev`
             src = nx
     return out
+
+
+class launch_group:
+    """with fused.launch_group() as g: ...   -- the register-chain stacks called inside are recorded and go out as one kernel launch where a
+    merged kernel exists (g4d_launch_group_begin / _end, include/g4d.h); g.launches = the number of launches it took.  The calls inside
+    must be independent of each other."""
+
+    def __enter__(self):
+        _lib.call("g4d_launch_group_begin")
+        self.launches = None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            _lib.lib().g4d_launch_group_abort()
+            return False
+        n = ctypes.c_int(0)
+        _lib.call("g4d_launch_group_end", _lib.stream_ptr(), ctypes.addressof(n))
+        self.launches = n.value
+        return False
 
 
 SA_XYZ_PAIR = os.environ.get("G4D_SA_XYZ_PAIR", "1") != "0"   # ... and both such scales of a level in one launch
@@ -659,16 +689,20 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
         tab_scales = [k for k, (g, layers) in enumerate(zip(sa.groupers, packed))
                       if sa_table_fits(layers, C, int(g.use_xyz), pool, g.nsample, B * N, B * P * g.nsample)]
         table, toffs = sa_level_table(sa, packed, feats_pm, tab_scales) if tab_scales else (None, [])
-        for k, (grouper, layers, idx) in enumerate(zip(sa.groupers, packed, idxs)):
-            S = grouper.nsample
-            use_xyz = int(grouper.use_xyz)
-            assert use_xyz or feats_pm is not None
-            tb = None
-            if k in tab_scales:
-                c0, wxT = toffs[tab_scales.index(k)]
-                tb = (table, c0, wxT)
-            sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=tb)
-            col0 += layers[-1].Cout
+        # the scales of a level are independent of each other: when all of them run on the table-loader chain kernel they are one
+        # launch group (one kernel launch where a merged kernel exists, csrc/mlp_chain.hip)
+        grouped = len(packed) > 1 and len(tab_scales) == len(packed)
+        with (launch_group() if grouped else contextlib.nullcontext()):
+            for k, (grouper, layers, idx) in enumerate(zip(sa.groupers, packed, idxs)):
+                S = grouper.nsample
+                use_xyz = int(grouper.use_xyz)
+                assert use_xyz or feats_pm is not None
+                tb = None
+                if k in tab_scales:
+                    c0, wxT = toffs[tab_scales.index(k)]
+                    tb = (table, c0, wxT)
+                sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=tb)
+                col0 += layers[-1].Cout
         return new_xyz, out
     # GroupAll (pointnet2_utils.py:268-291): one group of all N points, raw coordinates
     out = torch.empty((B, 1, ctot), dtype=torch.float32, device=xyz.device)

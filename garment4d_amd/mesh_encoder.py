@@ -123,6 +123,12 @@ class PCAGarmentEncoderSeg(nn.Module):
         if frame_ids is None:
             assert F_ == nbatch * T
             frame_ids = torch.arange(F_, device=x.device)
+        elif F_ != nbatch * T and gdist.resolve_group(group) is None:
+            # a frame shard (fewer than nbatch * T local frames) without a process group: the clip max below would be local-only and
+            # clips held elsewhere would come out as -inf rows -- group=None stopped meaning "the default group" in round 2 (DESIGN.md
+            # section 7), so say it instead of computing something else
+            raise ValueError(f"PCAGarmentEncoderSeg.forward: {F_} local frames of {nbatch} x {T} but no process group -- pass "
+                             "group=garment4d_amd.dist.WORLD (or a ProcessGroup), or call forward_frames()")
         cm = fused.to_channel_major if self.channel_major_outputs else (lambda t: t)
         out = {"middle_results": {}}
         feat_global, sem_logits, feats_pm, xyz_list = self.pointnet.forward_fused(x.contiguous(), precision=fused.current_precision())

@@ -7,6 +7,12 @@ distance contraction -- how the squared distance inside FPS / ball query / three
   "chain"           fma(dz,dz, fma(dy,dy, dx*dx))  (the other pairing; always used by knn when contraction is on)
 Index outputs (FPS picks, ball membership, 3-NN order) can differ between modes wherever two candidates are within an ulp;
 checkpoints trained on the CUDA build expect "nvcc".  Process-wide; also settable with G4D_DIST_CONTRACT before first use.
+
+NOT thread-safe: the mode is ONE global of the library (g_contract, csrc/api.hip), read each time a kernel is launched.  Set it once at
+start-up.  `distance_contraction(...)` below is a convenience for single-threaded tests: two host threads (or two streams driven from
+different threads) that switch modes race, and a launch enqueued by another thread inside the `with` block takes the temporary mode.
+(`fused.precision` is different: a context variable, per thread.)  The default moved from "off" (round 1) to "nvcc" (round 2): indices
+can differ from a round-1 library wherever two candidates are within an ulp unless G4D_DIST_CONTRACT=off.
 """
 import contextlib
 
@@ -31,6 +37,7 @@ def set_distance_contraction(mode) -> str:
 
 @contextlib.contextmanager
 def distance_contraction(mode):
+    """Temporarily switch the PROCESS-WIDE mode (single-threaded use only, see the module docstring)."""
     prev = set_distance_contraction(mode)
     try:
         yield

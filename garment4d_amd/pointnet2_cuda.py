@@ -40,13 +40,27 @@ def _i(t, name):
 _GRID_MIN_N = 4096  # same threshold as fused.GRID_MIN_N
 _NN_GRID_MIN_M = 4096  # same threshold as fused.THREE_NN_GRID_MIN_M
 
+# The reference's boundary never allocates: the cell-grid searches need a scratch the nine-name signature has no slot
+# for, so it is a cached workspace per (device, stream) -- grown, never shrunk, reused by every later call on that stream (kernels of one
+# stream run in order, so consecutive calls may share it; two streams never do).  No allocator call on the steady-state path.
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _workspaces[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return ws
+
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     pq, px, pi = _f(new_xyz, "new_xyz"), _f(xyz, "xyz"), _i(idx, "idx")
-    if n >= _GRID_MIN_N and b > 0 and m > 0 and nsample > 0:
-        # large cloud: cell-bucketed search (csrc/ball_grid.hip), bit-identical output; the scratch comes from torch's allocator
+    if n >= _GRID_MIN_N and b > 0 and m > 0 and nsample > 0 and 0.0 < float(radius) < float("inf"):
+        # large cloud: cell-bucketed search (csrc/ball_grid.hip), bit-identical output.  The cells are sized by the radius, so radius 0
+        # (legal in the reference: every row stays zero) and radius inf take the scan below like small clouds do.
         import ctypes
-        ws = torch.empty(_lib.lib().g4d_ball_grid_bytes(b, n), dtype=torch.uint8, device=xyz.device)
+        ws = _workspace(_lib.lib().g4d_ball_grid_bytes(b, n), xyz.device)
         R, NS, IP = (ctypes.c_float * 1)(float(radius)), (ctypes.c_int * 1)(int(nsample)), (ctypes.c_void_p * 1)(pi)
         _lib.call("g4d_ball_query_grid_f32", b, n, m, 1, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p), pq, px,
                   ctypes.cast(IP, ctypes.c_void_p), ws.data_ptr(), _lib.stream_ptr())
@@ -87,8 +101,8 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     pu, pk, pd, pi = _f(unknown, "unknown"), _f(known, "known"), _f(dist2, "dist2"), _i(idx, "idx")
     if m >= _NN_GRID_MIN_M and b > 0 and n > 0:
-        # large known set: search the cell grid (csrc/ball_grid.hip), bit-identical output; scratch from torch's allocator
-        ws = torch.empty(_lib.lib().g4d_ball_grid_bytes(b, m), dtype=torch.uint8, device=known.device)
+        # large known set: search the cell grid (csrc/ball_grid.hip), bit-identical output; cached scratch (see _workspace)
+        ws = _workspace(_lib.lib().g4d_ball_grid_bytes(b, m), known.device)
         _lib.call("g4d_three_nn_grid_f32", b, n, m, pu, pk, pd, pi, ws.data_ptr(), _lib.stream_ptr())
         return
     _lib.call("g4d_three_nn_f32", b, n, m, pu, pk, pd, pi, _lib.stream_ptr())

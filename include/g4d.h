@@ -421,6 +421,18 @@ int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, const float 
                              const float *W2_frag1, int kpad2_1, const float *scale2_1, const float *shift2_1, const float *W3_frag1, int kpad3_1,
                              const float *scale3_1, const float *shift3_1, int col0_1, g4d_stream_t stream);
 
+/* ---- launch groups (round 3) --------------------------------------------------------------------------------------------------
+ * Independent register-chain stacks (g4d_mlp_chain_f32 and its table variants) called between g4d_launch_group_begin() and
+ * g4d_launch_group_end() on the same host thread are RECORDED instead of launched; _end() puts them on `stream` as ONE kernel launch
+ * when a merged kernel is instantiated for the combination (the two scales of an MSG set-abstraction level: workgroups [0, nb0) run
+ * the heavier stack, the rest the other one), else as one launch each, in the recorded order.  Results are bit-identical to the
+ * separate launches either way.  Why: a launch costs the many-streams regime ~2.4 us of serialised dispatch on top of its own ramp
+ * and tail (scripts/exp_dispatch.py).  The recorded calls must not depend on each other's outputs.  *launches (may be NULL) receives
+ * the number of kernel launches _end() issued.  G4D_LAUNCH_GROUPS=0 turns merging off.  _abort() drops an open group. */
+int g4d_launch_group_begin(void);
+int g4d_launch_group_end(g4d_stream_t stream, int *launches);
+int g4d_launch_group_abort(void);
+
 /* g4d_fps_gather_f32 (no scratch) AND g4d_ball_grid_build_f32 of the same b clouds: for 4096 < n <= 8192 one launch -- workgroups [b, 2 b) of
  * the sampling launch build the cell grids (both depend on the cloud only; the build hides behind the sampling) -- two launches otherwise.
  * idx (b, m), new_xyz (b, m, 3), grid (g4d_ball_grid_bytes(b, n) bytes): identical to the two calls' outputs. */

@@ -37,8 +37,15 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--shard", default="clips", choices=["clips", "frames"])
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--gpus", type=int, default=0, help="ranks on this node; started without a launcher the script re-executes itself "
+                                                         "under torch.distributed.run (0 = whatever WORLD_SIZE says)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        bench.self_launch(a.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    assert a.gpus in (0, world), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local % ndev)
     dev = torch.device("cuda", local % ndev)

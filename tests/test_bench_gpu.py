@@ -32,3 +32,41 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and d["value"] > 10 * c["value"]
+
+
+def _one_json_line(p):
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run and the line
+    reports TWO ranks (gloo backend: both ranks share the one GPU of this box; the data path has no collective)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1",
+                        "--min-seconds", "0.05", "--streams", "4", "--input-pool-mb", "16", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 1000
+    assert "world_size=2" in d["config"]["collective_backend"] and d["config"]["launcher"].startswith("self")
+    assert "cpu_baseline" not in d            # reported at N = 1 only
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True, timeout=300,
+                       cwd=ROOT, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_bench_model_frame_sharded_two_ranks_by_itself():
+    """scripts/bench_model.py --shard frames --gpus 2: config 4's frame sharding (all-reduce MAX + all-gather per attention round) on two
+    self-launched gloo ranks sharing this box's GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_model.py"), "--gpus", "2", "--backend", "gloo", "--shard", "frames",
+                        "--clips-per-gpu", "1", "--T", "3", "--N", "2048", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _one_json_line(p)
+    assert d["n_gpus"] == 2 and d["config"]["sharding"] == "frames" and d["config"]["finite"] is True and d["config"]["frames_local"] == 3

@@ -1,5 +1,6 @@
 """Fused SA / FP / head kernels (MFMA shared-MLP with in-kernel grouping / interpolation / pooling) against the
 golden module outputs produced by the reference's own modules, and against the un-fused op-by-op path."""
+import contextlib
 import copy
 
 import numpy as np
@@ -547,3 +548,53 @@ def test_invalidate_drops_the_table_caches_after_a_data_update():
         got = fused.fp_forward(fp, xyz, nx, fused.to_point_major(uf), fused.to_point_major(kf))
         want = fp(xyz, nx, uf, kf)
         np.testing.assert_allclose(fused.to_channel_major(got).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,P,C,mlps,nsamples,expect_launches", [
+    (8, 1024, 256, 96, [[96, 32, 32, 64], [96, 64, 64, 128]], [16, 32], 1),        # SA2 of the encoder at the benched size: merged kernel
+    (8, 256, 64, 192, [[192, 64, 64, 128], [192, 128, 128, 256]], [32, 64], 1),    # SA3: merged kernel
+    (2, 1024, 256, 96, [[96, 32, 32, 64], [96, 64, 64, 128]], [16, 32], 1),        # smaller batch: both scales at 16 rows per wave
+    (3, 500, 100, 32, [[32, 64, 64], [32, 128, 128]], [8, 16], 2),                 # no merged kernel for this pair: two launches from the group
+])
+def test_launch_group_merges_the_scales_of_a_level_bit_identically(B, N, P, C, mlps, nsamples, expect_launches, monkeypatch):
+    """The scales of an MSG level go out as ONE launch (g4d_launch_group_begin / _end -> mlp_chain_pair_kernel) where a merged kernel
+    exists: bit-identical to one launch per scale, and the group reports how many launches it took."""
+    torch.manual_seed(C)
+    xyz = dev(syn.unit_cloud(B, N, seed=N + 1))
+    feats = torch.randn(B, C, N, device="cuda")
+    sa = PM.PointnetSAModuleMSG(npoint=P, radii=[0.15, 0.3], nsamples=nsamples, mlps=[list(m) for m in mlps]).cuda()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    sa.eval()
+    fpm = fused.to_point_major(feats)
+    seen = []
+    real = fused.launch_group
+
+    class spy(real):
+        def __exit__(self, *a):
+            r = super().__exit__(*a)
+            seen.append(self.launches)
+            return r
+
+    with torch.no_grad():
+        nx = fused.fps_gather(xyz, P)
+        monkeypatch.setattr(fused, "launch_group", spy)
+        _, merged = fused.sa_forward(sa, xyz, fpm, new_xyz=nx)
+        assert seen == [expect_launches], seen
+        monkeypatch.setattr(fused, "launch_group", contextlib.nullcontext)
+        _, separate = fused.sa_forward(sa, xyz, fpm, new_xyz=nx)
+    assert torch.equal(merged, separate)
+
+
+def test_launch_group_state_errors():
+    from garment4d_amd import _lib
+    _lib.call("g4d_launch_group_begin")
+    with pytest.raises(_lib.G4DError, match="already open"):
+        _lib.call("g4d_launch_group_begin")
+    _lib.lib().g4d_launch_group_abort()
+    with pytest.raises(_lib.G4DError, match="no open group"):
+        _lib.call("g4d_launch_group_end", _lib.stream_ptr(), 0)
+    with fused.launch_group() as g:      # an empty group launches nothing
+        pass
+    assert g.launches == 0
