@@ -121,6 +121,21 @@ def pmc_traffic(kernel_substr):
     return None
 
 
+def pmc_sq(kernel_substr):
+    """Matrix-pipe busy fraction of a kernel from the committed SQ counter passes (profiles/r*_pmc_sq*.csv, scripts/make_pmc_sq.sh):
+    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) -- newest round first; None when no profile holds the kernel."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq*.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                if kernel_substr in row["kernel"] and row.get("mfma_busy") not in (None, ""):
+                    return {"mfma_busy": float(row["mfma_busy"]), "source": os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def kernel_rooflines(model, cloud):
     """Instrumented eager pass: HIP events (on the stream the kernels are launched on = torch's current
     stream) around the two heaviest kernels.  Algorithmic bytes/flops per launch: DESIGN.md §Kernels."""
@@ -167,46 +182,62 @@ def kernel_rooflines(model, cloud):
                   "rounds_per_s_per_cloud": 1023 / t,
                   "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
                           "neither HBM nor MFMA limits it (frac is against HBM only because the contract wants a number) -- DESIGN.md section 5"}
-    # 2. heaviest MFMA launch of a step: SA3 scale 1, [195 -> 128 -> 128 -> 256] over B*64*64 grouped rows + max pool.  The path the
-    #    encoder takes (fused.sa_forward): the feature part of the first layer is contracted once per SOURCE point (a table over the
-    #    B*256 points of the level, shared by both scales), and one register-chain launch (csrc/mlp_chain.hip, table loader) runs
-    #    relu(affine(table[j] + Wx (x_j - q))) -> 128 -> 256 + max.  `achieved` / `frac` = the MFMA flops that launch EXECUTES over its
-    #    duration (matrix-pipe utilisation); `algorithmic` = the layer stack as the reference computes it (2 * rows * sum K_l C_l,
-    #    un-padded) over the launch + its share of the table launch; `full_chain` = the same stack on the three-layer chain kernel
-    #    (G4D_SA_TABLE=0), the kernel this object described before round 2's table route.
+    # 2. heaviest MFMA launch of a step: SA level 3 -- both scales, [195 -> 64 -> 64 -> 128] over B*64*32 grouped rows and
+    #    [195 -> 128 -> 128 -> 256] over B*64*64, each + max pool -- as ONE launch (mlp_chain_pair_kernel: fused.launch_group in
+    #    fused.sa_forward).  The path the encoder takes: the feature part of both first layers is contracted once per SOURCE point (one
+    #    table launch over the B*256 points of the level), and the pair launch runs relu(affine(table[j] + Wx (x_j - q))) in its loader and
+    #    the remaining two layers of each scale on the matrix pipe.  `achieved` / `frac` = the MFMA flops that launch EXECUTES over its
+    #    duration (matrix-pipe utilisation); `mfma_busy` = the same thing as the SQ counters see it (profiles/r*_pmc_sq*.csv);
+    #    `algorithmic` = the two layer stacks as the reference computes them (2 * rows * sum K_l C_l, un-padded) over the launch + the
+    #    table launch; `full_chain` = scale 1 alone on the three-layer chain kernel (G4D_SA_TABLE=0), what this object described in round 1.
     sa3 = model.SA_modules[2]
     packed = [fused.pack_conv_stack(mm) for mm in sa3.mlps]
-    layers = packed[1]
-    Bc, Nn, P, S, C = B_CLOUDS, 256, 64, 64, 192
+    Bc, Nn, P, C = B_CLOUDS, 256, 64, 192
+    nsamples = [g_.nsample for g_ in sa3.groupers]
     g = torch.Generator(device="cpu").manual_seed(0)
     xyz3 = torch.rand(Bc, Nn, 3, generator=g).to(cloud.device)
     new3 = xyz3[:, :P].contiguous()
     f3 = torch.randn(Bc, Nn, C, generator=g).to(cloud.device)
-    idx3 = torch.randint(0, Nn, (Bc, P, S), generator=g, dtype=torch.int32).to(cloud.device)
-    out3 = torch.empty(Bc * P, layers[-1].Cout, device=cloud.device)
-    rows = Bc * P * S
-    flops_alg = 2.0 * rows * sum(L.K * L.Cout for L in layers)
-    t_full = timed(lambda: fused.mlp_stack(1, rows, 3 + C, layers, out3, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
-    full = {"kernel": "mlp_chain_kernel<GROUP,8,8,16>", "avg_launch_us": t_full * 1e6, "achieved": flops_alg / t_full / 1e12,
-            "frac": flops_alg / t_full / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    idxs = [torch.randint(0, Nn, (Bc, P, S_), generator=g, dtype=torch.int32).to(cloud.device) for S_ in nsamples]
+    rows = [Bc * P * S_ for S_ in nsamples]
+    flops_alg = sum(2.0 * r * sum(L.K * L.Cout for L in L_) for r, L_ in zip(rows, packed))
+    layers, S, idx3 = packed[1], nsamples[1], idxs[1]
+    out1 = torch.empty(Bc * P, layers[-1].Cout, device=cloud.device)
+    flops_alg1 = 2.0 * rows[1] * sum(L.K * L.Cout for L in layers)
+    t_full = timed(lambda: fused.mlp_stack(1, rows[1], 3 + C, layers, out1, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
+    full = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (scale 1 alone, no table)", "avg_launch_us": t_full * 1e6, "achieved": flops_alg1 / t_full / 1e12,
+            "frac": flops_alg1 / t_full / 1e12 / MFMA_F32_PEAK_TFLOPS}
     scales = [k for k, (gr, L_) in enumerate(zip(sa3.groupers, packed)) if fused.sa_table_fits(L_, C, 1, 1, gr.nsample, Bc * Nn, Bc * P * gr.nsample)]
-    if 1 in scales:
+    if scales == [0, 1]:
         t_tab = timed(lambda: fused.sa_level_table(sa3, packed, f3, scales))
         table, toffs = fused.sa_level_table(sa3, packed, f3, scales)
-        tb = (table, *toffs[scales.index(1)])
-        t = timed(lambda: fused.sa_scale_mlp(xyz3, new3, f3, idx3, layers, 1, 1, out3.view(Bc, P, -1), 0, table=tb))
-        flops_exec = 2.0 * rows * sum(L.K * L.Cout for L in layers[1:])
-        share = layers[0].Cout / float(sum(packed[k][0].Cout for k in scales))
-        tr = pmc_traffic("mlp_chain_kernel<1, 8, 16")
-        res["mlp"] = {"kernel": "mlp_chain_kernel<GROUP,8,16>, table loader (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64; "
-                                "feature part of the first layer pre-contracted per source point)", "bound": "mfma",
+        out3 = torch.empty(Bc, P, sum(L_[-1].Cout for L_ in packed), device=cloud.device)
+        launches = []
+
+        def level():
+            with fused.launch_group() as grp:
+                c0 = 0
+                for k in scales:
+                    fused.sa_scale_mlp(xyz3, new3, f3, idxs[k], packed[k], 1, 1, out3, c0, table=(table, *toffs[k]))
+                    c0 += packed[k][-1].Cout
+            launches.append(grp.launches)
+
+        t = timed(level)
+        flops_exec = sum(2.0 * rows[k] * sum(L.K * L.Cout for L in packed[k][1:]) for k in scales)
+        merged = launches[-1] == 1
+        kname = "mlp_chain_pair_kernel<1, 8, 16, 0, 0, 1, 4, 8, 0, 0, 1>" if merged else "mlp_chain_kernel<1, 8, 16"
+        tr, sq = pmc_traffic(kname), pmc_sq(kname)
+        res["mlp"] = {"kernel": ("mlp_chain_pair_kernel<GROUP | 8,16 | 4,8>" if merged else "mlp_chain_kernel<GROUP,8,16> + <GROUP,4,8> (two launches)") +
+                                ", table loaders (SA3: 32768 rows x [195,128,128,256] + 16384 rows x [195,64,64,128], max pool; feature part of the first "
+                                "layers pre-contracted per source point)", "bound": "mfma", "launches": launches[-1],
                       "achieved": flops_exec / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": flops_exec / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "executed_flops": flops_exec,
+                      "mfma_busy": None if sq is None else sq["mfma_busy"], "mfma_busy_source": None if sq is None else sq["source"],
                       "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
                       "traffic_source": None if tr is None else tr["source"], "avg_launch_us": t * 1e6,
-                      "algorithmic": {"flops": flops_alg, "table_launch_us": t_tab * 1e6, "table_share": share,
-                                      "tflops_equivalent": flops_alg / (t + share * t_tab) / 1e12,
-                                      "frac_equivalent": flops_alg / (t + share * t_tab) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                      "algorithmic": {"flops": flops_alg, "table_launch_us": t_tab * 1e6,
+                                      "tflops_equivalent": flops_alg / (t + t_tab) / 1e12,
+                                      "frac_equivalent": flops_alg / (t + t_tab) / 1e12 / MFMA_F32_PEAK_TFLOPS},
                       "full_chain": full,
                       "note": "isolated launches on an idle chip; inside the 16-batch bench the same launch runs concurrently with others"}
     else:

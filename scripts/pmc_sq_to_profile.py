@@ -3,8 +3,10 @@
 python scripts/pmc_sq_to_profile.py out.csv pass1_counter_collection.csv [pass2 ...]
 
 Derived columns (MI355X: 256 CUs x 4 SIMDs; units per MI355X_MICROARCH.md, rocprofv3 PMC section):
-  mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE): share of the launch in which a SIMD's matrix pipe was busy,
-                averaged over all SIMDs of the chip (the counter counts cycles, summed over the SIMDs)
+  mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): share of the launch in which a SIMD's matrix pipe was busy,
+                averaged over all SIMDs of the chip.  The MFMA counter counts cycles summed over the SIMDs (calibration: exactly 32.0 per
+                v_mfma_f32_16x16x4_f32 in every fp32 kernel = its issue time, mfma_cyc_per_inst below); GRBM_GUI_ACTIVE comes out summed
+                over the 8 XCDs (one GRBM each: 8 x the kernel's cycles; e.g. 846k for a 44 us launch at ~2.4 GHz), hence the / 8
   issue_stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   (waves stalled at issue: MFMA operand / pipe dependencies)
   parked      = SQ_WAIT_ANY / SQ_WAVE_CYCLES        (waves parked in s_waitcnt / barriers)
   mfma_cyc_per_inst = SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA (32 for back-to-back v_mfma_f32_16x16x4_f32; ~16 for 16x16x32 bf16)
@@ -25,7 +27,7 @@ for k, cs in acc.items():
     n = max(len(v) for v in cs.values())
     g = avg.get("GRBM_GUI_ACTIVE", 0.0)
     wc = avg.get("SQ_WAVE_CYCLES", 0.0)
-    d = {"mfma_busy": avg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * g) if g else "",
+    d = {"mfma_busy": avg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * g / 8.0) if g else "",
          "issue_stall": avg.get("SQ_WAIT_INST_ANY", 0.0) / wc if wc else "",
          "parked": avg.get("SQ_WAIT_ANY", 0.0) / wc if wc else "",
          "mfma_cyc_per_inst": avg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / avg["SQ_INSTS_MFMA"] if avg.get("SQ_INSTS_MFMA") else ""}
