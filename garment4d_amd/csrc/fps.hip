@@ -381,6 +381,7 @@ static int launch_reg(int b, int n, int m, int bs, int log2bs, const float *xyz,
 }
 
 int fps_bucket_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s);  // fps_bucket.hip
+int fps_big_dispatch(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s);     // fps_big.hip
 int fps_bucket_grid_launch(int b, int n, int m, int bs, int log2bs, const float *xyz, int *idx, float *nx, float rmax, void *grid_ws, hipStream_t s);
 
 
@@ -410,7 +411,14 @@ static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx
         const int rc = fps_bucket_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
         if (rc >= 0) return rc;
     }
+    // 8192 < n <= 32768: the large-cloud bucketed kernel (fps_big.hip: min-distances in registers, coordinates from L2).  The
+    // register-resident kernel below still takes 8192 < n <= 12800 when cloud + pick list fit LDS (G4D_FPS_BIG=2 sends those here too).
+    static const int use_big = getenv("G4D_FPS_BIG") ? atoi(getenv("G4D_FPS_BIG")) : 1;
     const bool lds_ok = (size_t)n * 12 + (size_t)m * 4 + 512 <= 158 * 1024;   // SoA cloud + the pick list
+    if (use_big && force > 16 && n > 8192 && n <= 32768 && (use_big >= 2 || !(lds_ok && n <= 12800))) {
+        const int rc = fps_big_dispatch(b, n, m, bs, log2bs, xyz, temp, idx, nx, s);
+        if (rc >= 0) return rc;
+    }
 #define G4D_FPS_CASE(W, U, Q) return launch_reg<W, U, Q>(b, n, m, bs, log2bs, xyz, temp, idx, nx, s)
     if (lds_ok && force != 0 && bs >= 64) {
         const int qp = q <= 1 ? 1 : q <= 2 ? 2 : q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : 0;
@@ -466,7 +474,7 @@ static int fps_impl(int b, int n, int m, const float *xyz, float *temp, int *idx
         }
     }
 #undef G4D_FPS_CASE
-    G4D_REQUIRE(temp, "g4d_fps_f32: temp scratch (B,N) is required for this N (register-resident path covers 64 <= N <= 12800)");
+    G4D_REQUIRE(temp, "g4d_fps_f32: temp scratch (B,N) is required for this N (the scratch-free kernels cover 64 <= N <= 32768)");
     G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(fps_generic_kernel<FM>, dim3(b), dim3(1024), 0, s, n, m, bs, log2bs, xyz, temp, idx, nx))
     return check_launch("g4d_fps_f32(generic)");
 }

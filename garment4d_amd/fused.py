@@ -442,9 +442,11 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
 
 
 def _fps_needs_no_scratch(N, npoint):
-    """Mirrors fps_impl (csrc/fps.hip): the register-resident / bucketed sampling kernels keep the cloud and the pick list in LDS and
-    take temp = NULL; everything else (N < 64, N > 12800, or a pick list that does not fit beside the cloud) runs the generic kernel,
-    which needs the reference's (B, N) scratch initialised to 1e10."""
+    """Mirrors fps_impl (csrc/fps.hip): the register-resident / bucketed sampling kernels keep the cloud (or its min-distances) and the
+    pick list on chip and take temp = NULL; everything else (N < 64, N > 32768) runs the generic kernel, which needs the reference's
+    (B, N) scratch initialised to 1e10."""
+    if 8192 < N <= 32768 and npoint <= N:      # csrc/fps_big.hip (or the register-resident kernel below 12800 points)
+        return True
     return N >= 64 and N * 12 + npoint * 4 + 512 <= 158 * 1024 and N <= 12800
 
 

@@ -73,7 +73,7 @@ def compute_vnorms(verts, faces):
     return vn.astype(F32)
 
 
-def full_forward(sd, x, batch, body, garment_name, pca, template_faces, lbs_k, iteration=3):
+def full_forward(sd, x, batch, body, garment_name, pca, template_faces, lbs_k, iteration=3, return_ball_idx=False):
     """PCALBSGarmentUseSegEncoderSeg.forward.  x (nbatch,T,N,3); batch: numpy arrays under the reference's keys;
     body = dict(parents, faces)."""
     from . import gcn_oracle as GO
@@ -90,10 +90,14 @@ def full_forward(sd, x, batch, body, garment_name, pca, template_faces, lbs_k, i
                                                     batch["T_J_regressor"], batch["T_lbs_weights"], adj_old, K=lbs_k)
     enc["lbs_pred_garment_v"], enc["lbs_stage1_pred_garment_v"], enc["body_vn"] = posed, stage1, body_vn
     samples = (32, 8, 4) if garment_name == "Trousers" else (32, 16, 8)
-    enc["iter_regressed_lbs_garment_v"] = RO.refinement_head(
+    r = RO.refinement_head(
         sd, posed.reshape(nbatch * T, -1, 3), body_v, body_vn, enc["garment_v_list"],
         [np.ascontiguousarray(np.transpose(f, (0, 2, 1))) for f in enc["garment_f_list"]], adj, nbatch, T, garment_samples=samples,
-        iteration=iteration)
+        iteration=iteration, return_ball_idx=return_ball_idx)
+    if return_ball_idx:   # per round: the six ball-query index tensors the positional encoders grouped with (tests count membership flips)
+        enc["iter_regressed_lbs_garment_v"], enc["refine_ball_idx"] = r
+    else:
+        enc["iter_regressed_lbs_garment_v"] = r
     return enc
 
 

@@ -45,7 +45,8 @@ def test_cfg2_fps_properties_and_oracle():
 def test_cfg5_stress_ball_query_and_grouped_mlp():
     """B=32 N=32768 npoint=8192 nsample=64 r=0.05 mlp [3,64,64,128]: 64-bit offsets
     (B*C*P*S = 2^31 in the reference wraps), ball-query rows checked against the oracle on sampled queries, fused
-    group+MLP+max rows against the op-by-op path on sampled centroids."""
+    group+MLP+max rows against the ORACLE (modules_oracle.sa_module: QueryAndGroup + SharedMLP + max in numpy on top of the C
+    restatement of the ball query) and the op-by-op path on sampled centroids."""
     B, N, P, S, r = 32, 32768, 8192, 64, 0.05
     xyz = syn.unit_cloud(B, N, seed=5)
     x = dev(xyz)
@@ -67,12 +68,17 @@ def test_cfg5_stress_ball_query_and_grouped_mlp():
     for m in sa.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    from oracle import modules_oracle as MO
+    sd = {k: v.cpu().numpy() for k, v in sa.state_dict().items()}
     with torch.no_grad():
         _, got = fused.sa_forward(sa, x, None, new_xyz=new_xyz)           # (B,P,128) point-major, 16.7M grouped rows
-        sub = torch.from_numpy(rng.permutation(P)[:256]).cuda()
+        sub_h = rng.permutation(P)[:256]
+        sub = torch.from_numpy(sub_h).cuda()
         for b in (0, 31):
-            _, want = sa(x[b:b + 1], None, new_xyz=new_xyz[b:b + 1, sub].contiguous())   # (1,128,256)
             g = got[b, sub].t()
+            _, want_o = MO.sa_module(xyz[b:b + 1], None, P, [r], [S], sd, new_xyz=np.ascontiguousarray(xyz[b:b + 1, qsel[sub_h]]))   # (1,128,256)
+            np.testing.assert_allclose(g.cpu().numpy(), want_o[0], rtol=1e-5, atol=1e-5)                                             # elementwise, vs the oracle
+            _, want = sa(x[b:b + 1], None, new_xyz=new_xyz[b:b + 1, sub].contiguous())   # (1,128,256): the HIP op-by-op path
             err = float((g - want[0]).abs().max()) / max(1.0, float(want.abs().max()))
             assert err < 1e-5, err
 

@@ -88,13 +88,15 @@ def test_segment_points_vs_oracle(frac):
     assert np.array_equal(counts.cpu().numpy(), (np.argmax(logits, 2) == 6).sum(1))
 
 
-@pytest.mark.parametrize("garment,lbs_k,size", [("Tshirt", 64, "small"), ("Trousers", 3, "small"), ("Tshirt", 256, "cfg4")])
+@pytest.mark.parametrize("garment,lbs_k,size", [("Tshirt", 64, "small"), ("Trousers", 3, "small"), ("Tshirt", 256, "cfg4"), ("Tshirt", 256, "cfg4_T30")])
 def test_full_forward_vs_oracle(garment, lbs_k, size):
     """size "cfg4": BASELINE config 4's per-frame sizes -- N = 8192 points, 6890 body vertices, 4096 garment vertices, K = 256 -- for one
     4-frame clip: the kernel instantiations of the benched model (bucketed FPS, cell-grid ball query, K = 256 radix-select KNN,
-    LDS-resident 100-step smoothing, sub-block body ball query, windowed fused GCN launches) against the numpy restatement."""
-    if size == "cfg4":
-        nbatch, T, N = 1, 4, 8192
+    LDS-resident 100-step smoothing, sub-block body ball query, windowed fused GCN launches) against the numpy restatement.
+    "cfg4_T30": the same sizes for one FULL 30-frame clip -- T is the dimension of the temporal attention (a T x T soft-max over
+    Vg * C = 524288-long rows) and of the clip max of the garment summary."""
+    if size.startswith("cfg4"):
+        nbatch, T, N = 1, (30 if size == "cfg4_T30" else 4), 8192
         scene = syn.garment_scene(nbatch, T, N, body_rc=(65, 106), garment_rc=(64, 64), seed=11)
     else:
         nbatch, T, N = 2, 3, 2048
@@ -103,7 +105,7 @@ def test_full_forward_vs_oracle(garment, lbs_k, size):
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     with torch.no_grad():
         out = m(dev(scene["x"]), _body_model(scene["body"]), {k: dev(v) for k, v in scene["batch"].items()})
-    want = MOr.full_forward(sd, scene["x"], scene["batch"], scene["body"], garment, scene["pca"], scene["template"][1], lbs_k)
+    want = MOr.full_forward(sd, scene["x"], scene["batch"], scene["body"], garment, scene["pca"], scene["template"][1], lbs_k, return_ball_idx=True)
 
     def close(a, b, tol=1e-5):   # north_star: 1e-5 fp32, elementwise
         np.testing.assert_allclose(a.cpu().numpy() if torch.is_tensor(a) else a, b, rtol=tol, atol=tol)
@@ -158,13 +160,60 @@ def test_full_forward_vs_oracle(garment, lbs_k, size):
     if (~clip_clean).any():
         e = np.abs(out["lbs_pred_garment_v"].cpu().numpy() - want["lbs_pred_garment_v"]).max(-1)[~clip_clean]
         assert e.max() <= 2e-3, e.max()
+    # ---- refinement rounds: the discrete differences are FLAGGED per vertex, everything else meets 1e-5 on every vertex ------------
+    # Round r queries six balls (three body radii, three garment levels) around every vertex of round r - 1 (the posed garment for
+    # r = 0).  The two sides' query points differ by fp32 rounding, so a point within ~1e-6 of a ball's boundary can change sides:
+    # such queries are found by re-running the searches around the GPU's own vertices and comparing index rows with the oracle's.
+    # A flipped query changes the positional encoding of ITS vertex; the four graph convolutions of the round spread that over the
+    # vertex's 4-hop mesh neighbourhood, and the next round queries around the moved vertices: the flag set of a round is the 4-hop
+    # dilation of (the previous round's flags + this round's flips), per frame.  Every UNFLAGGED vertex -- including those of the same
+    # clip, which see the flip only through the temporal attention's T x T weights -- must agree to 1e-5 of the tensor scale; flagged
+    # vertices are bounded loosely and must be rare.  A clip with a flipped K-nearest set is flagged entirely (none on these seeds).
+    import scipy.sparse as sp
+    from garment4d_amd import fused
     assert len(out["iter_regressed_lbs_garment_v"]) == 3
+    F_ = nbatch * T
+    faces = np.asarray(scene["template"][1])
+    ii = np.concatenate([faces[:, k] for k in range(faces.shape[1])])
+    jj = np.concatenate([faces[:, (k + 1) % faces.shape[1]] for k in range(faces.shape[1])])
+    A = sp.coo_matrix((np.ones(ii.size * 2 + Vg), (np.concatenate([ii, jj, np.arange(Vg)]), np.concatenate([jj, ii, np.arange(Vg)]))), shape=(Vg, Vg)).tocsr()
+
+    def dilate(mask, hops=4):       # (F, Vg) bool -> its `hops`-ring neighbourhood on the garment mesh
+        x = mask.T.astype(np.float32)
+        for _ in range(hops):
+            x = (A @ x > 0).astype(np.float32)
+        return x.T > 0
+
+    def flipped_queries(prev_v, want_idx):
+        """(F, Vg) bool: some of the vertex's six ball queries returns another index row around the GPU's vertex than around the oracle's"""
+        q = prev_v.contiguous()
+        idx = fused.ball_query_msg([0.1, 0.2, 0.4], list(m.body_sample_num_list), dev(scene["batch"]["smpl_vertices_torch"].reshape(F_, -1, 3)), q, coherent=True)
+        idx += [fused.ball_query_msg([[0.1, 0.2, 0.4][i]], [m.garment_sample_num_list[i]], dev(want["garment_v_list"][i]), q)[0] for i in range(3)]
+        fl = np.zeros((F_, Vg), dtype=bool)
+        for a_, b_ in zip(idx, want_idx):
+            fl |= (a_.cpu().numpy() != b_).any(-1)
+        return fl
+
+    flag = np.repeat(knn_flipK.any(1), T)[:, None] | np.zeros((F_, Vg), dtype=bool)
+    prev = out["lbs_pred_garment_v"].reshape(F_, Vg, 3)
+    total_flips = 0
     for r, (a, b) in enumerate(zip(out["iter_regressed_lbs_garment_v"], want["iter_regressed_lbs_garment_v"])):
-        e = np.abs(a.cpu().numpy().reshape(b.shape) - b).max(-1)
+        fl = flipped_queries(prev, want["refine_ball_idx"][r])
+        total_flips += int(fl.sum())
+        flag = dilate(flag | fl)
+        e = np.abs(a.cpu().numpy().reshape(F_, Vg, 3) - b.reshape(F_, Vg, 3)).max(-1)     # (F, Vg)
         scale = max(1.0, float(np.abs(b).max()))
-        frac = float((e > 1e-5 * scale).mean())
-        print(f"[parity] {garment} refinement round {r}: max err {e.max():.3g}, vertices above 1e-5: {frac:.3g} (a ball-membership flip would show here)")
-        assert frac <= 0.02 and e.max() <= 5e-2 * scale, (r, frac, float(e.max()))
+        print(f"[parity] {garment} {size} refinement round {r}: vertices with a flipped ball query {int(fl.sum())} of {F_ * Vg}; flagged (4-hop) "
+              f"{int(flag.sum())}; max err unflagged {e[~flag].max():.3g}, flagged {e[flag].max() if flag.any() else 0.0:.3g}")
+        assert flag.mean() <= 0.05, "more than 5 % of the vertices are flagged: pick another seed"   # (each flip's ring grows by 4 hops per round)
+        assert e[~flag].max() <= 1e-5 * scale, (r, float(e[~flag].max()))                # EVERY unflagged vertex
+        if flag.any():
+            assert e[flag].max() <= 2e-3 * scale, (r, float(e[flag].max()))              # a flip moves a vertex by a bounded amount
+        prev = a.reshape(F_, Vg, 3)
+    # discrete differences are rare events (a point within fp32 rounding of a ball's surface): ~1e-5 of the queries at these sizes
+    assert total_flips <= max(2, 3e-5 * 3 * F_ * Vg) and int(knn_flipK.sum()) == 0, (total_flips, int(knn_flipK.sum()))
+    if size != "cfg4" and size != "cfg4_T30":
+        assert total_flips == 0, total_flips      # the small committed seeds have none at all
 
 
 @pytest.mark.parametrize("reduce_fn", ["sum", "mean"])

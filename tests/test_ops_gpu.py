@@ -85,6 +85,27 @@ def test_fps_vs_oracle(B, N, M, kind):
     assert np.array_equal(host(got), want), f"first mismatch at {np.argwhere(host(got) != want)[:3]}"
 
 
+@pytest.mark.parametrize("B,N,M,kind", [(2, 32768, 8192, "unit"), (1, 20000, 5000, "unit"), (1, 32768, 2048, "ties"), (2, 12801, 300, "ties"),
+                                        (1, 16384, 1000, "unit"), (1, 16385, 700, "ties"), (1, 8193, 64, "unit")])
+def test_fps_large_clouds_vs_oracle(B, N, M, kind):
+    """8192 < N <= 32768 (SURVEY.md 8a-a1's stress shape 32768 -> 8192): the large-cloud bucketed kernel (csrc/fps_big.hip: min-distances
+    in registers, coordinates from L2, two-level lane arg-max) -- indices AND the final scratch against the oracle, in the numerics mode of
+    the run (the suite runs in `nvcc` and `off`); duplicates / zero padding included."""
+    from garment4d_amd import pointnet2_cuda as shim
+    xyz = syn.unit_cloud(B, N, seed=N + M) if kind == "unit" else syn.body_like_cloud(B, N, seed=N + M, dup_frac=0.3, zero_frac=0.15)
+    want, want_temp = K.fps(xyz, M, return_temp=True)
+    x = dev(xyz)
+    temp = torch.full((B, N), 1e10, device="cuda")
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda")
+    shim.furthest_point_sampling_wrapper(B, N, M, x, temp, idx)
+    assert np.array_equal(host(idx), want), f"first mismatch at {np.argwhere(host(idx) != want)[:3]}"
+    assert np.array_equal(host(temp), want_temp)
+    # ... and the scratch-free entry point of the fused path (gather fused into the sampling kernel)
+    from garment4d_amd import fused
+    nx = fused.fps_gather(x, M)
+    assert np.array_equal(host(nx), np.take_along_axis(xyz, want[..., None].astype(np.int64), 1))
+
+
 def test_fps_temp_inout_contract():
     """temp is in/out scratch and holds the final min-distances (sampling_gpu.cu:131-133)."""
     from garment4d_amd import pointnet2_cuda as shim
@@ -263,16 +284,16 @@ def test_ball_query_block_bounds_skipping(B, N, M, scales, kind):
 def test_fps_without_scratch():
     """temp = NULL extension of g4d_fps_f32 (register-resident kernels)."""
     from garment4d_amd import _lib
-    for n, m in [(8192, 1024), (1024, 256), (256, 64), (6890, 512), (100, 50)]:
+    for n, m in [(8192, 1024), (1024, 256), (256, 64), (6890, 512), (100, 50), (20000, 64)]:
         xyz = syn.body_like_cloud(2, n, seed=n)
         x = dev(xyz)
         idx = torch.empty((2, m), dtype=torch.int32, device="cuda")
         _lib.call("g4d_fps_f32", 2, n, m, x.data_ptr(), 0, idx.data_ptr(), _lib.stream_ptr())
         assert np.array_equal(host(idx), K.fps(xyz, m))
-    x = dev(syn.unit_cloud(1, 20000, seed=1))
+    x = dev(syn.unit_cloud(1, 40000, seed=1))       # beyond 32768 points only the generic kernel is left, and it needs the scratch
     idx = torch.empty((1, 8), dtype=torch.int32, device="cuda")
     with pytest.raises(_lib.G4DError):
-        _lib.call("g4d_fps_f32", 1, 20000, 8, x.data_ptr(), 0, idx.data_ptr(), _lib.stream_ptr())
+        _lib.call("g4d_fps_f32", 1, 40000, 8, x.data_ptr(), 0, idx.data_ptr(), _lib.stream_ptr())
 
 
 def test_fps_bucketed_variant_is_index_exact():

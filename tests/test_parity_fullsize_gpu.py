@@ -107,16 +107,21 @@ def test_cfg3_encoder_bf16_full_size_vs_bf16_oracle(monkeypatch):
         _, logits, l_f, l_xyz = model.forward_fused(dev(xyz), channel_major=True, precision="bf16")
     for lvl in range(1, 4):
         assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl])
-    # bf16 operands: 2^-9 relative rounding per operand; the BN fold differs from the un-fused BN by fp32 rounding, which flips
-    # the bf16 rounding of an activation now and then and the flips compound over the ~15 layers below level 0.  Gate: maximum
-    # error within 4e-2 of the tensor scale (measured at this size: features 1e-2, logits -- the deepest tensor -- 2.6e-2, with a
-    # flat error distribution: q99.9 = 2.0e-2); the 99.9 % quantile is printed for the record
+    # Where the bound comes from.  Both sides round every MLP operand to bf16 (2^-9 relative); they differ only where an activation
+    # sits within fp32 rounding of a bf16 rounding boundary and falls on the other side (the BN fold of the fused path vs the un-fused
+    # BN of the oracle differ by an fp32 ulp).  One such flip changes that activation by one bf16 ulp = 2^-8 of its magnitude; through a
+    # layer it reaches an output as w * 2^-8 * a, i.e. <= 2^-8 of that output's own scale per flipped input, and kaiming-normal layers
+    # neither amplify nor damp it on average.  A value of the deepest tensor (the logits) sits behind L = 15 layers (3 SA x 3 + 3 FP x 2)
+    # on its longest path and sums contributions of independent flips in quadrature rather than linearly; the worst element over
+    # 65536 x 7 outputs is ~4.5 sigma.  With a flip probability of ~2^-9 x (fan-in <= 576) per layer input that gives
+    #     sigma ~ 2^-8 * sqrt(L * p_flip * fan_in) ~ 2^-8 * sqrt(15 * 1.1) ~ 1.6e-2 of scale for the typical worst path,
+    # measured: 2.6e-2 on the logits (q99.9 2.0e-2), 1e-2 on the feature tensors.  Gate: 3e-2 of the tensor scale (round 2 had 4e-2).
     def bf16_gate(name, got, want):
         mx, _, _, scale = stats(name, got, want)
         err = np.abs(got.detach().cpu().numpy() - want)
         q = float(np.quantile(err, 0.999))
         print(f"[parity] {name}: q99.9 {q:.3g}")
-        assert mx <= 4e-2 * max(scale, 1.0), (name, q, mx, scale)
+        assert mx <= 3e-2 * max(scale, 1.0), (name, q, mx, scale)
 
     for lvl in range(0, 4):
         bf16_gate(f"cfg3 l_features[{lvl}] (bf16 vs bf16-emulating oracle)", l_f[lvl], want_f[lvl])
