@@ -21,6 +21,16 @@ __device__ __forceinline__ void finish_tile(const LinearArgs &a, int cout, int l
     const bool ch_ok = ch < cout;
     constexpr int R = 16 * MT;  // rows per wave
     if constexpr (PS == 0) {
+        if (a.perm_rec) {   // wave-uniform: cell-ordered launch rows, outputs go to their original rows
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + mt * 16 + fq * 4 + r;
+                    if (ch_ok && row < a.rows) a.out[(size_t)out_row(a, row) * a.ldo + a.col0 + ch] = t[mt][r];
+                }
+            return;
+        }
         // one exec-mask region per tile instead of one per element: the row guard is needed in the last workgroup only
         float *o = a.out + (size_t)(row0 + fq * 4) * a.ldo + a.col0 + ch;
         if (row0 + R <= a.rows) {  // wave-uniform

@@ -31,7 +31,6 @@ struct ChainLayer {
     const float *shift;
     int kst;             // Kpad / 16: k-steps per channel tile in W
     int relu, cout;
-    int fmask;           // -1; 0 under the weight-streaming diagnostic (every fragment load reads fragment 0)
 };
 
 struct ChainArgs {
@@ -41,7 +40,6 @@ struct ChainArgs {
     float *tap_out;
     int tap_ld;
     int xcd_swz;     // workgroup -> row-block map: 1 = every XCD (blockIdx % 8) takes one CONTIGUOUS eighth of the row blocks
-    int dbg_wsame;   // diagnostic only (G4D_CHAIN_DBG_WSAME=1, wrong results): every weight fragment load reads fragment 0
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
@@ -99,7 +97,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TOUT][MT]) {
 constexpr int kWDepth = 6;
 
 __device__ __forceinline__ f32x4 load_wfrag(const ChainLayer &L, int ct, int ks, int lane) {
-    return *reinterpret_cast<const f32x4 *>(L.W + ((size_t)((ct * L.kst + ks) & L.fmask) * 64 + lane) * 4);
+    return *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
 }
 
 // the first kWDepth fragments of a chained layer (fragment f = ks * TOUT + ct), requested before the previous layer's epilogue
@@ -206,7 +204,7 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
 #pragma unroll
                         for (int e = 0; e < 4; ++e) b[mt][e] = fmaxf(__builtin_fmaf(b[mt][e], ps[e], pf[e]), 0.f);
                         if (a.in_tap && row0 + mt * 16 + fi < a.rows)
-                            *reinterpret_cast<f32x4 *>(a.in_tap + (size_t)(row0 + mt * 16 + fi) * a.in_tap_ld + k0) = b[mt];
+                            *reinterpret_cast<f32x4 *>(a.in_tap + (size_t)out_row(a, row0 + mt * 16 + fi) * a.in_tap_ld + k0) = b[mt];
                     }
                 } else {
                     b[mt] = *reinterpret_cast<const f32x4u *>(pa[mt] + k0);
@@ -309,7 +307,7 @@ __device__ __forceinline__ void tap_store(const ChainArgs &s, int cout, int lane
     for (int mt = 0; mt < MT; ++mt) {
         const int row = row0 + mt * 16 + fi;
         if (row >= s.in.rows) continue;
-        float *dst = s.tap_out + (size_t)row * s.tap_ld + fq * 4;
+        float *dst = s.tap_out + (size_t)out_row(s.in, row) * s.tap_ld + fq * 4;
         if (vec) {  // a lane's 4 channels are one aligned 16-byte store
 #pragma unroll
             for (int ct = 0; ct < TOUT; ++ct)
@@ -549,7 +547,7 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
                           int nlayers, const float *const *W, const float *const *scale, const float *const *shift,
                           const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
                           int tap_layer, float *tap_out, int tap_ld, const float *pre_scale, const float *pre_shift, float *in_tap,
-                          int in_tap_ld, const float *tab, int tab_ld, const float *tab_wx, g4d_stream_t stream) {
+                          int in_tap_ld, const float *tab, int tab_ld, const float *tab_wx, g4d_stream_t stream, const void *perm_grid = nullptr) {
     G4D_REQUIRE(mode == LOAD_DIRECT || mode == LOAD_GROUP || mode == LOAD_INTERP, "g4d_mlp_chain_f32: mode must be 0 (direct), 1 (group) or 2 (interp)");
     G4D_REQUIRE(rows >= 0 && rows < (1ll << 31) - 256 && K0 > 0, "g4d_mlp_chain_f32: bad sizes");
     if (rows == 0) return G4D_OK;
@@ -558,12 +556,17 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
     G4D_REQUIRE(pool >= 0 && pool <= 2, "g4d_mlp_chain_f32: pool must be 0|1|2");
     if (pool) G4D_REQUIRE((S == 4 || S == 8 || S == 16 || S == 32 || S == 64) && rows % S == 0, "g4d_mlp_chain_f32: pooling needs S in {4,8,16,32,64}");
     static const int xcd_swz = getenv("G4D_CHAIN_XCD") ? atoi(getenv("G4D_CHAIN_XCD")) : 1;          // A/B switch
-    static const int dbg_wsame = getenv("G4D_CHAIN_DBG_WSAME") ? atoi(getenv("G4D_CHAIN_DBG_WSAME")) : 0;
     ChainArgs s = {};
     s.in.rows = (int)rows; s.in.K = K0; s.in.out = out; s.in.ldo = ldo; s.in.col0 = col0; s.in.pool = pool; s.in.S = S > 0 ? S : 1;
     s.in.X = X; s.in.ldx = ldx;
     s.in.xyz = xyz; s.in.new_xyz = new_xyz; s.in.feats = feats; s.in.idx = idx; s.in.N = N; s.in.P = P; s.in.C = C; s.in.use_xyz = use_xyz;
     s.in.known_feats = known_feats; s.in.skip = skip; s.in.dist2 = dist2; s.in.nn_idx = nn_idx; s.in.C2 = C2; s.in.C1 = C1; s.in.m = m; s.in.n = n;
+    if (perm_grid) {
+        G4D_REQUIRE(mode == LOAD_INTERP && pool == 0 && n > 0 && rows % n == 0, "g4d_mlp_chain_*_cells_f32: cell-ordered rows need the interpolating loader, no pooling, whole clouds");
+        size_t off = 0, stride = 0;
+        grid_sorted_layout(n, &off, &stride);
+        s.in.perm_rec = reinterpret_cast<const unsigned char *>(perm_grid) + off; s.in.perm_stride = stride;
+    }
     s.tap_layer = tap_out ? tap_layer : -1; s.tap_out = tap_out; s.tap_ld = tap_ld;
     G4D_REQUIRE(s.tap_layer < nlayers - 1, "g4d_mlp_chain_f32: tap must be a hidden layer");
     if (tab && mode == LOAD_INTERP) {
@@ -587,9 +590,8 @@ static int chain_f32_impl(int mode, long long rows, int K0, const float *X, int 
         G4D_REQUIRE(Kpad[l] >= (l == 0 ? K0 : Cout[l - 1]), "g4d_mlp_chain_f32: Kpad of layer %d too small", l);
         s.layer[l].W = W[l]; s.layer[l].scale = scale[l]; s.layer[l].shift = shift[l];
         s.layer[l].kst = Kpad[l] / 16; s.layer[l].relu = relu[l]; s.layer[l].cout = Cout[l];
-        s.layer[l].fmask = dbg_wsame ? 0 : -1;
     }
-    s.xcd_swz = xcd_swz; s.dbg_wsame = dbg_wsame;
+    s.xcd_swz = xcd_swz;
     const int key = chain_key(nlayers, Cout);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // rows per wave (16 * MT).  Measured on the cfg2 stacks (scripts/time_stacks.py, G4D_CHAIN_MT sweep): 32 rows per wave win
@@ -640,6 +642,22 @@ extern "C" int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, con
     return chain_f32_impl(LOAD_INTERP, rows, C2, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, C2, 0, table, nullptr, dist2,
                           nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, pre_scale, pre_shift,
                           in_tap, in_tap_ld, nullptr, 0, nullptr, stream);
+}
+
+// g4d_mlp_chain_table_f32 over CELL-ORDERED rows: `unknown_grid` is the ball-grid workspace of the unknown cloud (g4d_ball_grid_build_f32 /
+// g4d_fps_gather_grid_f32), dist2 / nn_idx are in that order (g4d_three_nn_cells_sorted_f32), and row p of the launch is the cloud's p-th point
+// in cell order: the 64 rows of a workgroup are spatial neighbours whose three nearest known points largely coincide, so the table rows
+// they gather (3 x 512 B per row at the last FP level) hit in L1 instead of going to L2 each.  Outputs (out, tap_out, in_tap) land at the
+// rows' ORIGINAL positions; every value is bit-identical to g4d_mlp_chain_table_f32 on un-sorted inputs.
+extern "C" int g4d_mlp_chain_table_cells_f32(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx,
+                                             const void *unknown_grid, const float *pre_scale, const float *pre_shift, float *in_tap,
+                                             int in_tap_ld, int nlayers, const float *const *W, const float *const *scale,
+                                             const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo,
+                                             int col0, int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
+    G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift && unknown_grid, "g4d_mlp_chain_table_cells_f32: null pointer");
+    return chain_f32_impl(LOAD_INTERP, rows, C2, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, C2, 0, table, nullptr, dist2,
+                          nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, pre_scale, pre_shift,
+                          in_tap, in_tap_ld, nullptr, 0, nullptr, stream, unknown_grid);
 }
 
 // Set abstraction with the feature part of its first layer pre-contracted (pointnet2_utils.py:232-265 + the first SharedMLP layer):

@@ -47,7 +47,19 @@ struct LinearArgs {
     // first layer for source point j; the loader's row is relu((tab[j] + tab_wx . (x_j - q)) * pre_scale + pre_shift), tab_wx = [3][K]
     const float *tab, *tab_wx;
     int tab_ld;
+    // INTERP over CELL-ORDERED rows (register-chain kernel only): row p of the launch is the p-th point of its cloud's ball-grid order
+    // (dist2 / nn_idx are stored in that order); its skip features are read from, and its outputs written to, row perm(p) = the
+    // original index kept in the 4th dword of the cloud's 16-byte grid records (perm_rec + cloud * perm_stride bytes).  NULL: rows in place.
+    const unsigned char *perm_rec;
+    size_t perm_stride;
 };
+
+// output / skip row of launch row `row` (see LinearArgs::perm_rec)
+__device__ __forceinline__ int out_row(const LinearArgs &a, int row) {
+    if (!a.perm_rec) return row;
+    const int b = row / a.n, p = row - b * a.n;
+    return b * a.n + reinterpret_cast<const int *>(a.perm_rec + (size_t)b * a.perm_stride)[4 * p + 3];
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -92,7 +104,7 @@ __device__ __forceinline__ RowCtx<MODE> make_ctx(const LinearArgs &a, int row) {
         c.k0 = ((size_t)b * a.m + ix[0]) * ks;
         c.k1 = ((size_t)b * a.m + ix[1]) * ks;
         c.k2 = ((size_t)b * a.m + ix[2]) * ks;
-        c.sk = (size_t)row * a.C1;
+        c.sk = (size_t)(a.C1 ? out_row(a, row) : row) * a.C1;
     } else if constexpr (MODE == LOAD_CSR) {
         c.f = row / a.Vg;
         const int v = row - c.f * a.Vg;

@@ -186,7 +186,8 @@ template <int FM>
 // -- fail for most candidates instead of passing for most of them (64 unrelated queries x 4 candidates: ~80 % at K = 512).
 __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                            const float *__restrict__ known_all, float *__restrict__ dist2_all,
-                                                           int *__restrict__ idx_all, const unsigned char *__restrict__ qrec, size_t qstride) {
+                                                           int *__restrict__ idx_all, const unsigned char *__restrict__ qrec, size_t qstride,
+                                                           int sorted_out = 0) {
     __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];
     const int b = blockIdx.y;
     int p = blockIdx.x * 256 + threadIdx.x;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
     int orig = p;
     if (qrec) {
         const float4 r = reinterpret_cast<const float4 *>(qrec + (size_t)b * qstride)[min(p, n - 1)];
-        ux = r.x; uy = r.y; uz = r.z; orig = __float_as_int(r.w);
+        ux = r.x; uy = r.y; uz = r.z; orig = sorted_out ? p : __float_as_int(r.w);   // sorted_out: results stay in cell order
     } else {
         const float *u = unknown_all + ((size_t)b * n + min(p, n - 1)) * 3;
         ux = u[0]; uy = u[1]; uz = u[2];
@@ -474,6 +475,22 @@ extern "C" int g4d_three_nn_cells_f32(int b, int n, int m, const float *unknown,
     G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx,
                                                           reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride))
     return check_launch("g4d_three_nn_cells_f32");
+}
+
+// ... with the results LEFT in cell order: dist2 / idx row p of cloud b belong to the b-th cloud's p-th grid record (whose 4th dword is
+// the point's original index).  For consumers that walk the points in that order (g4d_mlp_chain_table_cells_f32).
+extern "C" int g4d_three_nn_cells_sorted_f32(int b, int n, int m, const void *unknown_grid, const float *known, float *dist2, int *idx,
+                                             g4d_stream_t stream) {
+    G4D_DIMS_OK("g4d_three_nn_cells_sorted_f32", b, n, m);
+    G4D_REQUIRE(b <= 65535, "g4d_three_nn_cells_sorted_f32: b > 65535 not supported");
+    if ((long long)b * n == 0) return G4D_OK;
+    G4D_REQUIRE(unknown_grid && dist2 && idx && known && m > 0, "g4d_three_nn_cells_sorted_f32: null pointer / empty known set");
+    size_t off = 0, stride = 0;
+    grid_sorted_layout(n, &off, &stride);
+    dim3 gridw((n + 255) / 256, b);
+    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, (const float *)nullptr, known, dist2,
+                                                          idx, reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride, 1))
+    return check_launch("g4d_three_nn_cells_sorted_f32");
 }
 
 extern "C" int g4d_three_interp_f32(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,

@@ -781,6 +781,8 @@ def three_nn_multi(pairs):
     return outs
 
 
+FP_WIDE_FUSED = os.environ.get("G4D_FP_WIDE_FUSED", "0") != "0"   # wide FP level: interpolation inside the first layer's loader (one launch fewer; A/B switch)
+FP_CELLS = os.environ.get("G4D_FP_CELLS", "1") != "0"   # last FP level: rows walked in the cell order of the unknown cloud's ball grid
 FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
 
 
@@ -822,7 +824,19 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
     C2 = known_feats_pm.shape[2]
     # nn: (dist2, idx) of three_nn(unknown, known) computed by the caller (three_nn_multi); unknown_grid: build_ball_grid(unknown, ...) of an
     # earlier SA level, if any
-    dist2, nn_idx = nn if nn is not None else three_nn(unknown, known, unknown_grid=unknown_grid)
+    # cell-ordered route (csrc/mlp_chain.hip, g4d_mlp_chain_table_cells_f32): search results stay in the cell order of the unknown cloud's
+    # ball grid and the table launch walks the points in that order (neighbouring rows share their nearest known points: L1 hits)
+    cells = (FP_CELLS and FP_TABLE and NN_CELLS and nn is None and unknown_grid is not None and C1 == 0 and n >= 4096 and 256 <= m < THREE_NN_GRID_MIN_M
+             and B > 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN)
+    if cells:
+        rest_ = layers[1:] + (pack_conv_stack(head) if head is not None else [])
+        cells = bool(rest_) and bool(_lib.lib().g4d_mlp_chain_supported(len(rest_), (ctypes.c_int * len(rest_))(*[L.Cout for L in rest_])))
+    if cells:
+        dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+        nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+        _lib.call("g4d_three_nn_cells_sorted_f32", B, n, m, unknown_grid[0].data_ptr(), known.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), stream)
+    else:
+        dist2, nn_idx = nn if nn is not None else three_nn(unknown, known, unknown_grid=unknown_grid)
 
     def first(L, pl, o, c0):
         _lib.call("g4d_interp_linear_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm),
@@ -846,7 +860,8 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
             if head is not None and nl > 1:
                 tap_layer, tap_t = nl - 2, out.view(B * n, -1)      # the FP output is a hidden layer of `rest`
             in_tap = out.view(B * n, -1) if (head is not None and nl == 1) else None     # ... or the loader's own output
-            _lib.call("g4d_mlp_chain_table_f32", B * n, n, m, L0.Cout, table.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(),
+            _lib.call(*(("g4d_mlp_chain_table_cells_f32", B * n, n, m, L0.Cout, table.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), unknown_grid[0].data_ptr())
+                        if cells else ("g4d_mlp_chain_table_f32", B * n, n, m, L0.Cout, table.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr())),
                       L0.scale.data_ptr(), L0.shift.data_ptr(), _ptr(in_tap), 0 if in_tap is None else in_tap.shape[-1], len(rest),
                       ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p),
                       ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p),
@@ -896,7 +911,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
             return out, logits
     if USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
-    elif layers[0].Cout > 64:
+    elif layers[0].Cout > 64 and not FP_WIDE_FUSED:
         # wide FP level: every 64-channel tile of the first layer would redo the interpolation -> materialise the
         # interpolated + concatenated rows once (a few MB), then plain DIRECT layers.  (Splitting the first layer here too -- table over
         # the known rows, its interpolation added in the LDS-tiled kernel's epilogue, skip columns only on the matrix pipe: 35 % fewer

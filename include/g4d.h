@@ -421,6 +421,20 @@ int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, const float 
                              const float *W2_frag1, int kpad2_1, const float *scale2_1, const float *shift2_1, const float *W3_frag1, int kpad3_1,
                              const float *scale3_1, const float *shift3_1, int col0_1, g4d_stream_t stream);
 
+/* ---- feature propagation over cell-ordered rows (round 3) ------------------------------------------------------------------------
+ * g4d_three_nn_cells_sorted_f32: g4d_three_nn_cells_f32 with the results LEFT in the cell order of `unknown_grid` (row p of cloud b
+ * belongs to that cloud's p-th grid record, whose 4th dword is the point's original index).
+ * g4d_mlp_chain_table_cells_f32: g4d_mlp_chain_table_f32 whose launch rows are those cell-ordered points: dist2 / nn_idx in cell order,
+ * outputs (out, tap_out, in_tap) written to the ORIGINAL rows; values bit-identical to the un-sorted pair of calls.  A workgroup's rows
+ * are then spatial neighbours and the three table rows each of them gathers hit in L1 (interpolate_gpu.cu:77-117 + the first SharedMLP
+ * layer of pointnet2_modules.py:127-156). */
+int g4d_three_nn_cells_sorted_f32(int b, int n, int m, const void *unknown_grid, const float *known, float *dist2, int *idx, g4d_stream_t stream);
+int g4d_mlp_chain_table_cells_f32(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx,
+                                  const void *unknown_grid, const float *pre_scale, const float *pre_shift, float *in_tap, int in_tap_ld,
+                                  int nlayers, const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
+                                  const int *Cout, const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
+                                  g4d_stream_t stream);
+
 /* ---- launch groups (round 3) --------------------------------------------------------------------------------------------------
  * Independent register-chain stacks (g4d_mlp_chain_f32 and its table variants) called between g4d_launch_group_begin() and
  * g4d_launch_group_end() on the same host thread are RECORDED instead of launched; _end() puts them on `stream` as ONE kernel launch

@@ -598,3 +598,37 @@ def test_launch_group_state_errors():
     with fused.launch_group() as g:      # an empty group launches nothing
         pass
     assert g.launches == 0
+
+
+@pytest.mark.parametrize("B,n,m,mlp,head_widths", [(8, 8192, 1024, [128, 128, 64], [32, 7]), (2, 5000, 300, [64, 64], None), (1, 4096, 256, [32, 32, 32], [16])])
+def test_fp_over_cell_ordered_rows_is_bit_identical(B, n, m, mlp, head_widths, monkeypatch):
+    """The last FP level with the unknown cloud's ball grid at hand: three_nn results stay in cell order and the table launch walks the
+    points in that order (g4d_three_nn_cells_sorted_f32 + g4d_mlp_chain_table_cells_f32), writing every output to its original row --
+    bit-identical to the un-sorted route, features and head outputs."""
+    from garment4d_amd import pytorch_utils as pt_utils
+    torch.manual_seed(n)
+    unknown = dev(syn.unit_cloud(B, n, seed=n))
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, mlp[0], device="cuda")
+    fp = PM.PointnetFPModule(mlp=list(mlp)).cuda().eval()
+    head = None
+    if head_widths:
+        blocks, c = [], mlp[-1]
+        for i, w in enumerate(head_widths):
+            last = i == len(head_widths) - 1
+            blocks.append(pt_utils.Conv1d(c, w, bn=not last, activation=None if last else torch.nn.ReLU(inplace=True)))
+            c = w
+        head = torch.nn.Sequential(*blocks).cuda().eval()
+    for mod in list(fp.modules()) + (list(head.modules()) if head is not None else []):
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+    grid = fused.build_ball_grid(unknown, 0.1)
+    outs = {}
+    with torch.no_grad():
+        for on in (True, False):
+            monkeypatch.setattr(fused, "FP_CELLS", on)
+            outs[on] = fused.fp_forward(fp, unknown, known, None, kf, head=head, unknown_grid=grid)
+    if head is not None:
+        assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    else:
+        assert torch.equal(outs[True], outs[False])
