@@ -15,10 +15,11 @@ L = fused.PackedLayer(W, torch.ones(64, device=dev), torch.zeros(64, device=dev)
 
 
 def run(K, R, ns):
-    graphs = []
+    graphs, keep = [], []
     for s in range(ns):
         x = torch.randn(R, 64, device=dev)
         y = torch.empty(R, 64, device=dev)
+        keep.append((x, y))   # the graphs hold raw pointers: the buffers must outlive them
 
         def chain():
             a, b = x, y
