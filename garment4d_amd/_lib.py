@@ -78,6 +78,7 @@ SIGNATURES = {
     "g4d_fps_gather_grid_f32": [_I, _I, _I, _vp, _vp, _vp, ctypes.c_float, _vp, _vp],
     "g4d_three_nn_cells_sorted_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_mlp_chain_table_cells_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
+    "g4d_search_multi_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_launch_group_begin": [],
     "g4d_launch_group_end": [_vp, _vp],
     "g4d_launch_group_abort": [],

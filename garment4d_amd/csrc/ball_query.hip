@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "g4d_common.h"
+#include "three_nn_body.h"
 
 namespace g4d {
 
@@ -191,6 +192,20 @@ template <int NS, int FM>
 __global__ void __launch_bounds__(256) ball_query_multi_kernel(const BqMulti q) {
     if ((int)blockIdx.x < q.blk0) ball_query_body<1, NS, FM>(q.n[0], q.m[0], q.a[0], q.new_xyz[0], q.xyz[0], blockIdx.x, blockIdx.y);
     else ball_query_body<1, NS, FM>(q.n[1], q.m[1], q.a[1], q.new_xyz[1], q.xyz[1], (int)blockIdx.x - q.blk0, blockIdx.y);
+}
+
+// The small searches of a step that depend on sampled coordinates only -- two ball queries and up to four three_nn problems (the inner
+// SA / FP levels of the encoder) -- in ONE launch: workgroups [0, bq_blocks) are ball-query tiles, the rest three_nn tiles.  Each of
+// these launches is a few microseconds of work and costs the many-streams regime about its own duration (launches of different
+// streams barely overlap when they are this short: profiles/r03_launch_cost_isolated_vs_16streams.txt).
+template <int NS, int FM>
+__global__ void __launch_bounds__(256) search_multi_kernel(const BqMulti q, const NNMulti nq, int bq_blocks) {
+    if ((int)blockIdx.x < bq_blocks) {
+        if ((int)blockIdx.x < q.blk0) ball_query_body<1, NS, FM>(q.n[0], q.m[0], q.a[0], q.new_xyz[0], q.xyz[0], blockIdx.x, blockIdx.y);
+        else ball_query_body<1, NS, FM>(q.n[1], q.m[1], q.a[1], q.new_xyz[1], q.xyz[1], (int)blockIdx.x - q.blk0, blockIdx.y);
+    } else {
+        three_nn_multi_role<FM>(nq, (int)blockIdx.x - bq_blocks, blockIdx.y);
+    }
 }
 
 // Sub-block-culled ball query for index-coherent clouds (g4d_ball_query_boxes_f32: the body / garment queries of
@@ -573,15 +588,12 @@ extern "C" int g4d_ball_query_f32(int b, int n, int m, float radius, int nsample
     return g4d_ball_query_msg_f32(b, n, m, 1, &radius, &nsample, new_xyz, xyz, ip, stream);
 }
 
-// Two ball queries (same batch size, same number of scales) in one launch; each output identical to g4d_ball_query_msg_f32's.
-extern "C" int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0,
-                                       const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1,
-                                       const float *new_xyz1, const float *xyz1, int *const *idx1, g4d_stream_t stream) {
+static int bq_multi_fill(g4d::BqMulti &q, int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0,
+                         const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1, const float *new_xyz1,
+                         const float *xyz1, int *const *idx1, const char *who) {
     using namespace g4d;
-    G4D_REQUIRE(b >= 0 && b <= 65535 && nscales >= 1 && nscales <= 4 && n0 > 0 && m0 > 0 && n1 > 0 && m1 > 0, "g4d_ball_query_msg2_f32: bad sizes");
-    G4D_REQUIRE(radii0 && nsamples0 && new_xyz0 && xyz0 && idx0 && radii1 && nsamples1 && new_xyz1 && xyz1 && idx1, "g4d_ball_query_msg2_f32: null pointer");
-    if (b == 0) return G4D_OK;
-    BqMulti q = {};
+    G4D_REQUIRE(b >= 0 && b <= 65535 && nscales >= 1 && nscales <= 4 && n0 > 0 && m0 > 0 && n1 > 0 && m1 > 0, "%s: bad sizes", who);
+    G4D_REQUIRE(radii0 && nsamples0 && new_xyz0 && xyz0 && idx0 && radii1 && nsamples1 && new_xyz1 && xyz1 && idx1, "%s: null pointer", who);
     const int ns[2] = {n0, n1}, ms[2] = {m0, m1};
     const float *rr[2] = {radii0, radii1};
     const int *nsm[2] = {nsamples0, nsamples1};
@@ -589,7 +601,7 @@ extern "C" int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const
     for (int k = 0; k < 2; ++k) {
         q.n[k] = ns[k]; q.m[k] = ms[k];
         for (int s = 0; s < nscales; ++s) {
-            G4D_REQUIRE(nsm[k][s] > 0 && ix[k][s], "g4d_ball_query_msg2_f32: bad scale %d of problem %d", s, k);
+            G4D_REQUIRE(nsm[k][s] > 0 && ix[k][s], "%s: bad scale %d of problem %d", who, s, k);
             q.a[k].radius2[s] = rr[k][s] * rr[k][s];
             q.a[k].radius2_max = s == 0 ? q.a[k].radius2[0] : (q.a[k].radius2[s] > q.a[k].radius2_max ? q.a[k].radius2[s] : q.a[k].radius2_max);
             q.a[k].nsample[s] = nsm[k][s];
@@ -598,6 +610,18 @@ extern "C" int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const
     }
     q.new_xyz[0] = new_xyz0; q.xyz[0] = xyz0; q.new_xyz[1] = new_xyz1; q.xyz[1] = xyz1;
     q.blk0 = (m0 + 3) / 4;
+    return G4D_OK;
+}
+
+// Two ball queries (same batch size, same number of scales) in one launch; each output identical to g4d_ball_query_msg_f32's.
+extern "C" int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0,
+                                       const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1,
+                                       const float *new_xyz1, const float *xyz1, int *const *idx1, g4d_stream_t stream) {
+    using namespace g4d;
+    BqMulti q = {};
+    if (const int rc = bq_multi_fill(q, b, nscales, n0, m0, radii0, nsamples0, new_xyz0, xyz0, idx0, n1, m1, radii1, nsamples1, new_xyz1, xyz1, idx1,
+                                     "g4d_ball_query_msg2_f32")) return rc;
+    if (b == 0) return G4D_OK;
     dim3 grid((unsigned)(q.blk0 + (m1 + 3) / 4), (unsigned)b);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define G4D_BQ2(NSV) G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((ball_query_multi_kernel<NSV, FM>), grid, dim3(256), 0, st, q))
@@ -609,4 +633,40 @@ extern "C" int g4d_ball_query_msg2_f32(int b, int nscales, int n0, int m0, const
     }
 #undef G4D_BQ2
     return check_launch("g4d_ball_query_msg2_f32");
+}
+
+// g4d_ball_query_msg2_f32 and g4d_three_nn_multi_f32 (count <= 4 problems) of the same batch in ONE launch (search_multi_kernel); every
+// output identical to the separate calls'.  The problems must not depend on each other's outputs.
+extern "C" int g4d_search_multi_f32(int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0,
+                                    const float *xyz0, int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1,
+                                    const float *new_xyz1, const float *xyz1, int *const *idx1, int nn_count, const int *nn_n, const int *nn_m,
+                                    const float *const *nn_unknown, const float *const *nn_known, float *const *nn_dist2, int *const *nn_idx,
+                                    g4d_stream_t stream) {
+    using namespace g4d;
+    BqMulti q = {};
+    if (const int rc = bq_multi_fill(q, b, nscales, n0, m0, radii0, nsamples0, new_xyz0, xyz0, idx0, n1, m1, radii1, nsamples1, new_xyz1, xyz1, idx1,
+                                     "g4d_search_multi_f32")) return rc;
+    G4D_REQUIRE(nn_count >= 1 && nn_count <= 4 && nn_n && nn_m && nn_unknown && nn_known && nn_dist2 && nn_idx, "g4d_search_multi_f32: bad three_nn arguments (1..4 problems)");
+    if (b == 0) return G4D_OK;
+    NNMulti nq = {};
+    int nblocks = 0;
+    for (int i = 0; i < nn_count; ++i) {
+        G4D_REQUIRE(nn_n[i] > 0 && nn_m[i] > 0 && nn_unknown[i] && nn_known[i] && nn_dist2[i] && nn_idx[i], "g4d_search_multi_f32: three_nn problem %d: empty or null", i);
+        nq.n[i] = nn_n[i]; nq.m[i] = nn_m[i]; nq.unknown[i] = nn_unknown[i]; nq.known[i] = nn_known[i]; nq.dist2[i] = nn_dist2[i]; nq.idx[i] = nn_idx[i];
+        nblocks += (nn_n[i] + 63) / 64;
+        nq.blk_end[i] = nblocks;
+    }
+    nq.count = nn_count;
+    const int bq_blocks = q.blk0 + (m1 + 3) / 4;
+    dim3 grid((unsigned)(bq_blocks + nblocks), (unsigned)b);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define G4D_SM(NSV) G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((search_multi_kernel<NSV, FM>), grid, dim3(256), 0, st, q, nq, bq_blocks))
+    switch (nscales) {
+        case 1: G4D_SM(1) break;
+        case 2: G4D_SM(2) break;
+        case 3: G4D_SM(3) break;
+        default: G4D_SM(4) break;
+    }
+#undef G4D_SM
+    return check_launch("g4d_search_multi_f32");
 }

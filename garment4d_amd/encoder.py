@@ -101,6 +101,7 @@ class Pointnet2MSGSEG(nn.Module):
             # ball queries of the two small inner levels can share one launch.
             SAs = list(self.SA_modules)
             pre_nx, pre_idx = {}, {}
+            pre_nn = None
             if (fused.BQ_MULTI and len(SAs) == 3 and all(sa.npoint is not None for sa in SAs) and SAs[0].npoint < fused.GRID_MIN_N
                     and len(SAs[1].groupers) == len(SAs[2].groupers) <= 4):
                 r0 = [g.radius for g in SAs[0].groupers]
@@ -114,9 +115,16 @@ class Pointnet2MSGSEG(nn.Module):
                 else:
                     pre_nx[1] = fused.fps_gather(pre_nx[0], SAs[1].npoint)
                     pre_nx[2] = fused.fps_gather(pre_nx[1], SAs[2].npoint)
-                pre_idx[1], pre_idx[2] = fused.ball_query_msg2(
-                    ([g.radius for g in SAs[1].groupers], [g.nsample for g in SAs[1].groupers], pre_nx[0], pre_nx[1]),
-                    ([g.radius for g in SAs[2].groupers], [g.nsample for g in SAs[2].groupers], pre_nx[1], pre_nx[2]))
+                bq = (([g.radius for g in SAs[1].groupers], [g.nsample for g in SAs[1].groupers], pre_nx[0], pre_nx[1]),
+                      ([g.radius for g in SAs[2].groupers], [g.nsample for g in SAs[2].groupers], pre_nx[1], pre_nx[2]))
+                nfp_ = len(self.FP_modules)
+                if fused.SEARCH_MULTI and fused.NN_MULTI and nfp_ == 3 and max(pre_nx[0].shape[1], pre_nx[1].shape[1]) < 4096:
+                    # ... and so can the three-NN searches of the inner FP levels (256 <- 64 and 1024 <- 256 points): they, too, depend
+                    # on the sampled coordinates only
+                    pre_idx[1], pre_idx[2], nn_out = fused.search_multi(bq[0], bq[1], [(pre_nx[1], pre_nx[2]), (pre_nx[0], pre_nx[1])])
+                    pre_nn = {-1: nn_out[0], -2: nn_out[1]}
+                else:
+                    pre_idx[1], pre_idx[2] = fused.ball_query_msg2(*bq)
             for li, sa in enumerate(self.SA_modules):
                 grid = None
                 radii = [g.radius for g in sa.groupers]
@@ -136,7 +144,9 @@ class Pointnet2MSGSEG(nn.Module):
         #  frames/s: its long workgroups and the short ones share a launch badly; it keeps its own)
         inner = [i for i in range(-1, -nfp, -1) if l_xyz[i - 1].shape[1] < 4096]
         pre = {}
-        if fused.NN_MULTI and 2 <= len(inner) <= 4:
+        if not fused.OVERLAP_SAMPLING and pre_nn is not None and sorted(inner) == sorted(pre_nn):
+            pre = pre_nn     # (searched together with the ball queries of SA levels 2 and 3, above)
+        elif fused.NN_MULTI and 2 <= len(inner) <= 4:
             pre = dict(zip(inner, fused.three_nn_multi([(l_xyz[i - 1], l_xyz[i]) for i in inner])))
         # the last FP level has no skip features: its first layer is a table over ITS known rows = the output rows of the level before,
         # which that level's chain launch can produce as one more layer

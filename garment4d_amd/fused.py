@@ -498,6 +498,31 @@ def ball_query_msg2(q0, q1):
     return o0, o1
 
 
+SEARCH_MULTI = os.environ.get("G4D_SEARCH_MULTI", "1") != "0"   # the inner levels' ball queries AND three-NN searches in one launch
+
+
+def search_multi(q0, q1, pairs):
+    """ball_query_msg2(q0, q1) and three_nn_multi(pairs) in ONE launch (g4d_search_multi_f32): returns (o0, o1, [(dist2, idx), ...])."""
+    (r0, s0, x0, c0), (r1, s1, x1, c1) = q0, q1
+    assert len(r0) == len(r1) and x0.shape[0] == x1.shape[0] and 1 <= len(pairs) <= 4
+    B, ns = x0.shape[0], len(r0)
+    dev = x0.device
+    o0 = [torch.empty((B, c0.shape[1], k), dtype=torch.int32, device=dev) for k in s0]
+    o1 = [torch.empty((B, c1.shape[1], k), dtype=torch.int32, device=dev) for k in s1]
+    outs = [(torch.empty((B, _chk(u).shape[1], 3), dtype=torch.float32, device=dev), torch.empty((B, u.shape[1], 3), dtype=torch.int32, device=dev))
+            for u, k in pairs]
+    FA, IA, PA = ctypes.c_float * ns, ctypes.c_int * ns, ctypes.c_void_p * ns
+    c = len(pairs)
+    IC, PC = ctypes.c_int * c, ctypes.c_void_p * c
+    vp = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _lib.call("g4d_search_multi_f32", B, ns, x0.shape[1], c0.shape[1], vp(FA(*[float(r) for r in r0])), vp(IA(*[int(k) for k in s0])), _chk(c0).data_ptr(),
+              _chk(x0).data_ptr(), vp(PA(*[o.data_ptr() for o in o0])), x1.shape[1], c1.shape[1], vp(FA(*[float(r) for r in r1])), vp(IA(*[int(k) for k in s1])),
+              _chk(c1).data_ptr(), _chk(x1).data_ptr(), vp(PA(*[o.data_ptr() for o in o1])), c, vp(IC(*[u.shape[1] for u, k in pairs])),
+              vp(IC(*[_chk(k).shape[1] for u, k in pairs])), vp(PC(*[u.data_ptr() for u, k in pairs])), vp(PC(*[k.data_ptr() for u, k in pairs])),
+              vp(PC(*[o[0].data_ptr() for o in outs])), vp(PC(*[o[1].data_ptr() for o in outs])), _lib.stream_ptr())
+    return o0, o1, outs
+
+
 def fps_gather(xyz, npoint, sidx=None, new_xyz=None):
     """new_xyz = xyz[furthest_point_sample(xyz, npoint)] (pointnet2_modules.py:32-35) -> (B,npoint,3).  `sidx` / `new_xyz`:
     optional pre-allocated outputs (the sampling chain of the encoder runs on a side stream into buffers owned by the main one)."""

@@ -435,6 +435,13 @@ int g4d_mlp_chain_table_cells_f32(long long rows, int n, int m, int C2, const fl
                                   const int *Cout, const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
                                   g4d_stream_t stream);
 
+/* g4d_ball_query_msg2_f32 + g4d_three_nn_multi_f32 (1..4 problems) of the same batch in ONE launch: the searches of the encoder's inner
+ * levels depend on the sampled coordinates only.  Outputs identical to the separate calls' (ball_query_gpu.cu:9-45, interpolate_gpu.cu:9-52). */
+int g4d_search_multi_f32(int b, int nscales, int n0, int m0, const float *radii0, const int *nsamples0, const float *new_xyz0, const float *xyz0,
+                         int *const *idx0, int n1, int m1, const float *radii1, const int *nsamples1, const float *new_xyz1, const float *xyz1,
+                         int *const *idx1, int nn_count, const int *nn_n, const int *nn_m, const float *const *nn_unknown,
+                         const float *const *nn_known, float *const *nn_dist2, int *const *nn_idx, g4d_stream_t stream);
+
 /* ---- launch groups (round 3) --------------------------------------------------------------------------------------------------
  * Independent register-chain stacks (g4d_mlp_chain_f32 and its table variants) called between g4d_launch_group_begin() and
  * g4d_launch_group_end() on the same host thread are RECORDED instead of launched; _end() puts them on `stream` as ONE kernel launch

@@ -49,5 +49,3 @@ def tiny(rows):
 
 bench(tiny(64), "transpose 64x32 (1 workgroup-ish)")
 bench(tiny(8192), "transpose 8192x32")
-bench(tiny(65536), "transpose 65536x32 (8 MB)")
-bench(tiny(524288), "transpose 524288x32 (67 MB)")

@@ -441,3 +441,22 @@ def test_fps_gather_grid_equals_the_two_launches(n, m, contraction_mode):
     a = fused.ball_query_msg([0.1, 0.2], [16, 32], xd, nx, grid=grid)
     s = fused.ball_query_msg([0.1, 0.2], [16, 32], xd, nx, grid=False)
     assert all(torch.equal(p, q) for p, q in zip(a, s))
+
+
+def test_search_multi_equals_the_separate_launches():
+    """g4d_search_multi_f32: the two multi-scale ball queries and the two three_nn searches of the encoder's inner levels in one launch --
+    every output bit-identical to g4d_ball_query_msg2_f32 / g4d_three_nn_multi_f32."""
+    from garment4d_amd import fused
+    B = 3
+    x0 = dev(syn.body_like_cloud(B, 1024, seed=3, dup_frac=0.2, zero_frac=0.1))
+    c0 = fused.fps_gather(x0, 256)
+    c1 = fused.fps_gather(c0, 64)
+    q0, q1 = ([0.1, 0.2], [16, 32], x0, c0), ([0.2, 0.4], [32, 64], c0, c1)
+    pairs = [(c0, c1), (x0, c0), (c1, c0)]
+    o0, o1, nn = fused.search_multi(q0, q1, pairs)
+    w0, w1 = fused.ball_query_msg2(q0, q1)
+    wn = fused.three_nn_multi(pairs)
+    for a, b in zip(o0 + o1, w0 + w1):
+        assert torch.equal(a, b)
+    for (d, i), (wd, wi) in zip(nn, wn):
+        assert torch.equal(d, wd) and torch.equal(i, wi)
