@@ -45,6 +45,7 @@ import torch  # noqa: E402
 B_CLOUDS, N_POINTS = 8, 8192
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -136,7 +137,7 @@ def pmc_sq(kernel_substr):
     return None
 
 
-def kernel_rooflines(model, cloud):
+def kernel_rooflines(model, cloud, precision="fp32"):
     """Instrumented eager pass: HIP events (on the stream the kernels are launched on = torch's current
     stream) around the two heaviest kernels.  Algorithmic bytes/flops per launch: DESIGN.md §Kernels."""
     from garment4d_amd import fused
@@ -207,6 +208,22 @@ def kernel_rooflines(model, cloud):
     t_full = timed(lambda: fused.mlp_stack(1, rows[1], 3 + C, layers, out1, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
     full = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (scale 1 alone, no table)", "avg_launch_us": t_full * 1e6, "achieved": flops_alg1 / t_full / 1e12,
             "frac": flops_alg1 / t_full / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    if precision == "bf16":
+        # BASELINE config 3: the same stack with bf16 operands on v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bf16.hip; the table routes are
+        # fp32-only, so all three layers run on the matrix pipe), against the dense bf16 peak
+        with fused.precision("bf16"):
+            t16 = timed(lambda: fused.mlp_stack(1, rows[1], 3 + C, layers, out1, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
+        kname = "mlp_chain_bf16_kernel<1, 1, 8, 8, 16, 0, 1>"
+        tr, sq = pmc_traffic(kname), pmc_sq(kname)
+        res["mlp"] = {"kernel": "mlp_chain_bf16_kernel<GROUP,8,8,16> (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64, bf16 operands / fp32 accumulate)",
+                      "bound": "mfma", "achieved": flops_alg1 / t16 / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": flops_alg1 / t16 / 1e12 / MFMA_BF16_PEAK_TFLOPS, "executed_flops": flops_alg1,
+                      "mfma_busy": None if sq is None else sq["mfma_busy"], "mfma_busy_source": None if sq is None else sq["source"],
+                      "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch", "traffic_source": None if tr is None else tr["source"],
+                      "avg_launch_us": t16 * 1e6, "fp32_full_chain": full,
+                      "note": "isolated launch on an idle chip; far from the bf16 matrix peak by construction: 4.9 GFLOP are 2 us of bf16 MFMA, the launch is "
+                              "bound by its gathers, the fp32 affine / conversion between layers and its ramp (DESIGN.md section 5)"}
+        return res
     scales = [k for k, (gr, L_) in enumerate(zip(sa3.groupers, packed)) if fused.sa_table_fits(L_, C, 1, 1, gr.nsample, Bc * Nn, Bc * P * gr.nsample)]
     if scales == [0, 1]:
         t_tab = timed(lambda: fused.sa_level_table(sa3, packed, f3, scales))
@@ -506,7 +523,7 @@ def main():
                     torch.cuda.synchronize()
                     ts.append(time.perf_counter() - t1)
             lat = float(np.median(ts[2:])) * 1e3
-        roof = kernel_rooflines(model, clouds[0]) if rank == 0 else None
+        roof = kernel_rooflines(model, clouds[0], args.precision) if rank == 0 else None
 
     if rank == 0:
         total_steps = args.steps * repeats
@@ -520,7 +537,8 @@ def main():
             "dtype": {"fp32": "f32", "bf16": "bf16 MLP operands / f32 accumulate, sampling, LBS",
                       "bf16x3": "f32 values; shared-MLP products as 6 bf16 x bf16 piece products of exact 3-way operand splits, f32 accumulate (fp32-accurate)"}[args.precision], "data": "synthetic",
             "latency_ms_single_stream": lat,
-            "config": {"workload": "cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32"
+            "config": {"workload": ("cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32" if args.precision == "fp32" else
+                                    f"cfg3 precision on the cfg2 step: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head), shared-MLP operands {args.precision}")
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),
                        "frames_per_step": B_CLOUDS, "batches_in_flight": ns, "hipgraph": graphs is not None,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
