@@ -39,6 +39,7 @@ struct ChainArgs {
     int tap_layer;   // hidden layer whose activations are also written to HBM (-1: none)
     float *tap_out;
     int tap_ld;
+    int dbg_off;     // debug builds: first stamp slot of this role (scripts/dbg_chain_phases2.py)
     int xcd_swz;     // workgroup -> row-block map: 1 = every XCD (blockIdx % 8) takes one CONTIGUOUS eighth of the row blocks
 };
 
@@ -95,6 +96,10 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TOUT][MT]) {
 // Here fragment f + kWDepth is requested before the MFMAs of fragment f are issued (the empty asm with a memory clobber keeps
 // the compiler from sinking the load back down), i.e. kWDepth KB per wave stay in flight.
 constexpr int kWDepth = 6;
+constexpr int kDeepTab = 8;   // table rows of up to this many 16-column k-steps are requested whole, up front (GROUP table loader)
+#ifndef G4D_NO_DEEP_TAB
+#define G4D_NO_DEEP_TAB 0
+#endif
 
 __device__ __forceinline__ f32x4 load_wfrag(const ChainLayer &L, int ct, int ks, int lane) {
     return *reinterpret_cast<const f32x4 *>(L.W + ((size_t)(ct * L.kst + ks) * 64 + lane) * 4);
@@ -110,7 +115,8 @@ __device__ __forceinline__ void preload_ring(const ChainLayer &L, int lane, f32x
 
 #ifdef G4D_CHAIN_DEBUG
 __device__ long long g_chain_dbg[8 * 4096];  // per wave (first 4096): 8 clock stamps (scripts/dbg_chain_phases.py)
-#define G4D_CSTAMP(i) { const int gw_ = blockIdx.x * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && gw_ < 4096) g_chain_dbg[gw_ * 8 + (i)] = (long long)__builtin_readcyclecounter(); }
+__shared__ int g_dbg_bid;
+#define G4D_CSTAMP(i) { const int gw_ = g_dbg_bid * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && gw_ < 4096) g_chain_dbg[gw_ * 8 + (i)] = (long long)__builtin_readcyclecounter(); }
 #else
 #define G4D_CSTAMP(i)
 #endif
@@ -232,6 +238,85 @@ __device__ __forceinline__ void first_layer(const LinearArgs &a, const ChainLaye
                 for (int e = 0; e < 4; ++e) b[mt][e] = load_elem<MODE>(a, ctx[mt], rowc[mt], k0 + e);
         }
     };
+    if constexpr (MODE == LOAD_GROUP) {
+        if (a.tab && TOUT <= kDeepTab && a.K == 16 * TOUT && !G4D_NO_DEEP_TAB) {   // wave-uniform: table as wide as this layer's output (c, c, 2c stacks)
+            constexpr int KS = TOUT <= kDeepTab ? TOUT : 1;   // k-steps, compile-time: the loops below are straight-line code
+            // Table loader: this "first layer" is the SECOND layer's contraction fed by relu(affine(table[j] + Wx (x_j - q))).  In-kernel
+            // stamps (SA level 3, 128-wide table, scripts/dbg_chain_phases2.py) put 36k of a wave's 82k cycles here for 8k cycles of
+            // MFMA issue when gathers and weights were requested one k-step ahead.  A table row is at most 8 k-steps, so ALL of it is
+            // requested up front (4 registers per k-step and row tile: one gather latency instead of eight) and turned into operands in
+            // place; the k-steps then run as straight-line code off a weight-fragment ring, exactly like a chained layer.
+            // Round 3 measurements that bound what is left (same script; 16-batch bench in parentheses):
+            //   * no weight loads at all anywhere in the chain kernels (wrong results, timing only): 34.7k -> 35.7k frames/s -- weight
+            //     delivery (L2 -> registers, ring depth, an LDS-shared ring) is worth < 3 %; ring depth 12 / 16: 34.3k / 33.4k;
+            //   * each workgroup walking 2 / 4 row tiles in a loop (warm instruction cache from the second tile on: 67k -> 57k cycles
+            //     per tile alone on a SIMD): 28.1k / 28.9k frames/s -- the waves it takes off the SIMDs cost more than the fetches;
+            //   * of two waves sharing a SIMD the older one wins MFMA arbitration (its tile takes 55k cycles, the younger one's 73k):
+            //     co-resident waves de-phase by themselves, which is why staggering them by hand measured neutral.
+            G4D_CSTAMP(5)
+            f32x4 raw[KS][MT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) raw[ks][mt] = *reinterpret_cast<const f32x4u *>(pa[mt] + ks * 16 + fq * 4);
+            // weights: the same fragment ring as chain_layer (kWDepth KB per wave in flight all the time); requested a k-step at a time
+            // (a burst of TOUT fragments, then a full drain before the step's MFMAs) the same loads took 3-4k cycles per step
+            f32x4 wring[kWDepth];
+#pragma unroll
+            for (int f = 0; f < kWDepth; ++f)
+                if (f < KS * TOUT) wring[f] = load_wfrag(L, f % TOUT, f / TOUT, lane);
+            // operands: relu(affine(table row + Wx (x_j - q))) in place, the arithmetic of load_b's table branch operation for operation
+            f32x4 cwx, cwy, cwz, cps, cpf;
+            auto load_small = [&](int ks) {
+                const int k0 = ks * 16 + fq * 4;
+                cwx = *reinterpret_cast<const f32x4 *>(a.tab_wx + k0); cwy = *reinterpret_cast<const f32x4 *>(a.tab_wx + a.K + k0);
+                cwz = *reinterpret_cast<const f32x4 *>(a.tab_wx + 2 * a.K + k0);
+                cps = *reinterpret_cast<const f32x4 *>(a.pre_scale + k0); cpf = *reinterpret_cast<const f32x4 *>(a.pre_shift + k0);
+            };
+            load_small(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4 wx = cwx, wy = cwy, wz = cwz, ps = cps, pf = cpf;
+                if (ks + 1 < KS) load_small(ks + 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = raw[ks][mt][e] + __builtin_fmaf(wz[e], gdz[mt], __builtin_fmaf(wy[e], gdy[mt], wx[e] * gdx[mt]));
+                        raw[ks][mt][e] = fmaxf(__builtin_fmaf(v, ps[e], pf[e]), 0.f);
+                    }
+            }
+            G4D_CSTAMP(6)
+            constexpr int G = (MT == 1 && TOUT % 2 == 0) ? 2 : 1;
+            static_assert(kWDepth % 2 == 0, "the ring is consumed G fragments at a time");
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int ct = 0; ct < TOUT; ct += G) {
+                    const int f = ks * TOUT + ct;
+                    f32x4 w[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        w[g] = wring[(f + g) % kWDepth];
+                        if (f + g + kWDepth < KS * TOUT)
+                            wring[(f + g) % kWDepth] = load_wfrag(L, (f + g + kWDepth) % TOUT, (f + g + kWDepth) / TOUT, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[ct + g][mt] = LAST ? mfma4(raw[ks][mt][e], w[g][e], acc[ct + g][mt]) : mfma4(w[g][e], raw[ks][mt][e], acc[ct + g][mt]);
+                }
+#ifdef G4D_CHAIN_DEBUG
+                if (ks == 0) { G4D_CSTAMP(7) }
+#endif
+            }
+            return;
+        }
+    }
     f32x4 wn[TOUT], bn[MT];
 #pragma unroll
     for (int ct = 0; ct < TOUT; ++ct) wn[ct] = load_wfrag(L, ct, 0, lane);
@@ -338,6 +423,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs &s, int bid, int nb, 
         wg = x * q + min(x, r) + (wg >> 3);
     }
     const int row0 = (wg * 4 + wave) * (16 * MT);
+#ifdef G4D_CHAIN_DEBUG
+    __syncthreads();
+    if (threadIdx.x == 0) g_dbg_bid = bid + s.dbg_off;
+    __syncthreads();
+#endif
     G4D_CSTAMP(0)
     f32x4 h1[T1][MT];
     f32x4 ring[kWDepth];  // weight fragments in flight for the next chained layer (requested BEFORE the current layer's epilogue)
@@ -490,10 +580,12 @@ static bool chain_launch_pair(const ChainRole &A, const ChainRole &B, hipStream_
     if (A.mode != LOAD_GROUP || B.mode != LOAD_GROUP) return false;
     const long long na = role_blocks(A), nb = role_blocks(B);
     if (na + nb >= (1ll << 31)) return false;
+    ChainArgs bs = B.s;
+    bs.dbg_off = (int)na;
     const dim3 grid((unsigned)(na + nb)), block(256);
 #define G4D_PAIR(KA, MA, KB, MB, ...)                                                                                   \
     if (A.key == KA && A.mt == MA && B.key == KB && B.mt == MB) {                                                       \
-        hipLaunchKernelGGL((mlp_chain_pair_kernel<LOAD_GROUP, __VA_ARGS__>), grid, block, 0, st, A.s, B.s, (int)na);    \
+        hipLaunchKernelGGL((mlp_chain_pair_kernel<LOAD_GROUP, __VA_ARGS__>), grid, block, 0, st, A.s, bs, (int)na);    \
         return true;                                                                                                    \
     }
     G4D_PAIR(4080000, 2, 2040000, 1, 4, 8, 0, 0, 2, 2, 4, 0, 0, 1)     // SA level 2 of Pointnet2MSGSEG at B = 8: 64-128 on 65536 rows + 32-64 on 32768
