@@ -67,18 +67,25 @@ __global__ void __launch_bounds__(256) three_nn_multi_kernel(const NNMulti q) {
 // sliced kernel restarts K at every slice (256 points: an insert is needed at nearly every step, and all 4 candidates went through
 // it together: ~60 of the ~85 instructions per step); scanning the whole set lets K grow to m and the per-candidate tests skip
 // half of the inserts.
-template <int FM>
 // `qrec` (optional): the unknown cloud as (x, y, z, original index) records in CELL ORDER -- the `sorted` array of its ball-grid
 // workspace (ball_grid.hip), one array of n records per cloud at stride qstride bytes.  The 64 queries of a wave are then neighbours:
 // a known point is close to all of them or to none, so the wave-uniform tests around the inserts -- which pass when ANY lane improves
 // -- fail for most candidates instead of passing for most of them (64 unrelated queries x 4 candidates: ~80 % at K = 512).
+// SPLIT = 2 | 4: the workgroup owns 256 / SPLIT queries instead of 256 and its waves scan one contiguous 1/SPLIT of every staged chunk each;
+// the SPLIT top-3 lists are merged through LDS under (distance, index) -- the scan's own result, because a strict `<` scan in
+// index order keeps, among equal distances, the lowest indices.  4096 waves instead of 1024 on the last FP level (one per SIMD before).
+template <int FM, int SPLIT>
 __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                            const float *__restrict__ known_all, float *__restrict__ dist2_all,
                                                            int *__restrict__ idx_all, const unsigned char *__restrict__ qrec, size_t qstride,
-                                                           int sorted_out = 0) {
+                                                           int sorted_out) {
     __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];
+    constexpr int QPB = 256 / SPLIT;   // queries per workgroup
+    __shared__ float sd[SPLIT > 1 ? SPLIT - 1 : 1][QPB][3];
+    __shared__ int si[SPLIT > 1 ? SPLIT - 1 : 1][QPB][3];
     const int b = blockIdx.y;
-    int p = blockIdx.x * 256 + threadIdx.x;
+    const int slice = (int)threadIdx.x / QPB, ql = (int)threadIdx.x % QPB;   // wave-uniform slice (QPB is a multiple of 64)
+    int p = (int)blockIdx.x * QPB + ql;
     const float *known = known_all + (size_t)b * m * 3;
     float ux, uy, uz;
     int orig = p;
@@ -102,7 +109,9 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
         }
         __syncthreads();
         const int jn = (cm + 3) & ~3;   // block-uniform trip count
-        for (int j = 0; j < jn; j += 4) {
+        const int qlen = SPLIT > 1 ? (((jn / SPLIT) + 3) & ~3) : jn;   // this wave's share of the chunk (wave-uniform bounds)
+        const int jlo = slice * qlen, jhi = min(jlo + qlen, jn);
+        for (int j = jlo; j < jhi; j += 4) {
             const float4 kx = *reinterpret_cast<const float4 *>(&skx[j]), ky = *reinterpret_cast<const float4 *>(&sky[j]),
                          kz = *reinterpret_cast<const float4 *>(&skz[j]);
             const float d0 = dist2<FM>(ux - kx.x, uy - ky.x, uz - kz.x);   // interpolate_gpu.cu:33 under the contraction contract
@@ -116,6 +125,21 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
             if (__builtin_amdgcn_ballot_w64(d3 < b3) != 0ull) nn_insert(d3, base + j + 3, b1, b2, b3, i1, i2, i3);
         }
     }
+    if constexpr (SPLIT > 1) {
+        if (slice > 0) {
+            sd[slice - 1][ql][0] = b1; sd[slice - 1][ql][1] = b2; sd[slice - 1][ql][2] = b3;
+            si[slice - 1][ql][0] = i1; si[slice - 1][ql][1] = i2; si[slice - 1][ql][2] = i3;
+        }
+        __syncthreads();
+        if (slice > 0) return;
+#pragma unroll
+        for (int w = 0; w < SPLIT - 1; ++w)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = sd[w][ql][c];
+                if (d < __builtin_inff()) nn_insert_lex(d, si[w][ql][c], b1, b2, b3, i1, i2, i3);
+            }
+    }
     if (p < n) {
         float *d2o = dist2_all + ((size_t)b * n + orig) * 3;
         int *ix = idx_all + ((size_t)b * n + orig) * 3;
@@ -123,6 +147,27 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
         ix[0] = i1; ix[1] = i2; ix[2] = i3;
     }
 }
+
+// Measured on cfg2's last FP level (8 x 8192 queries <- 1024 known, cell-ordered): 49.3 / 29.2 / 24.6 us alone for SPLIT = 1 / 2 / 4 and a
+// single batch's latency 1.073 / 1.053 / 1.041 ms -- but the 20-batch mix drops from 34.7k to 34.5k / 34.1k frames/s: the split scans cost
+// more wave time in total (every slice restarts its running third distance), and wave time is what the mix is short of.  So: split only
+// when the launch would leave SIMDs empty (fewer than 1024 waves un-split); G4D_NN_SPLIT = 1 | 2 | 4 overrides.
+static int nn_wide_split(long long queries) {
+    static const int v = [] { const char *e = getenv("G4D_NN_SPLIT"); return e ? atoi(e) : 0; }();
+    if (v == 1 || v == 2 || v == 4) return v;
+    return queries < 65536 ? 4 : 1;
+}
+#define G4D_NN_WIDE_LAUNCH(n_, b_, st_, ...)                                                                                                  \
+    if (nn_wide_split((long long)(n_) * (b_)) == 4) {                                                                                                               \
+        dim3 gridw(((n_) + 63) / 64, (b_));                                                                                                   \
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((three_nn_wide_kernel<FM, 4>), gridw, dim3(256), 0, st_, __VA_ARGS__))         \
+    } else if (nn_wide_split((long long)(n_) * (b_)) == 2) {                                                                                                        \
+        dim3 gridw(((n_) + 127) / 128, (b_));                                                                                                 \
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((three_nn_wide_kernel<FM, 2>), gridw, dim3(256), 0, st_, __VA_ARGS__))         \
+    } else {                                                                                                                                  \
+        dim3 gridw(((n_) + 255) / 256, (b_));                                                                                                 \
+        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((three_nn_wide_kernel<FM, 1>), gridw, dim3(256), 0, st_, __VA_ARGS__))         \
+    }
 
 // out[b,c,p] = w0*pts[b,c,i0] + w1*pts[b,c,i1] + w2*pts[b,c,i2]   (left-to-right, unfused)
 __global__ void __launch_bounds__(256) three_interp_kernel(int c, int m, int n, const float *__restrict__ points,
@@ -320,8 +365,7 @@ extern "C" int g4d_three_nn_f32(int b, int n, int m, const float *unknown, const
     G4D_REQUIRE(unknown && dist2 && idx && (known || m == 0), "g4d_three_nn_f32: null pointer");
     static const int wide_min_n = [] { const char *e = getenv("G4D_NN_WIDE_MIN_N"); return e ? atoi(e) : 4096; }();
     if (n >= wide_min_n && m >= 256) {   // 64 queries per wave over the whole known set: see three_nn_wide_kernel
-        dim3 gridw((n + 255) / 256, b);
-        G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx, (const unsigned char *)nullptr, (size_t)0))
+        G4D_NN_WIDE_LAUNCH(n, b, G4D_STREAM(stream), n, m, unknown, known, dist2, idx, (const unsigned char *)nullptr, (size_t)0, 0)
         return check_launch("g4d_three_nn_f32");
     }
     dim3 grid((n + 63) / 64, b);
@@ -359,9 +403,7 @@ extern "C" int g4d_three_nn_cells_f32(int b, int n, int m, const float *unknown,
     G4D_REQUIRE(unknown && dist2 && idx && known, "g4d_three_nn_cells_f32: null pointer");
     size_t off = 0, stride = 0;
     grid_sorted_layout(n, &off, &stride);
-    dim3 gridw((n + 255) / 256, b);
-    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, unknown, known, dist2, idx,
-                                                          reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride))
+    G4D_NN_WIDE_LAUNCH(n, b, G4D_STREAM(stream), n, m, unknown, known, dist2, idx, reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride, 0)
     return check_launch("g4d_three_nn_cells_f32");
 }
 
@@ -375,9 +417,7 @@ extern "C" int g4d_three_nn_cells_sorted_f32(int b, int n, int m, const void *un
     G4D_REQUIRE(unknown_grid && dist2 && idx && known && m > 0, "g4d_three_nn_cells_sorted_f32: null pointer / empty known set");
     size_t off = 0, stride = 0;
     grid_sorted_layout(n, &off, &stride);
-    dim3 gridw((n + 255) / 256, b);
-    G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL(three_nn_wide_kernel<FM>, gridw, dim3(256), 0, G4D_STREAM(stream), n, m, (const float *)nullptr, known, dist2,
-                                                          idx, reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride, 1))
+    G4D_NN_WIDE_LAUNCH(n, b, G4D_STREAM(stream), n, m, (const float *)nullptr, known, dist2, idx, reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride, 1)
     return check_launch("g4d_three_nn_cells_sorted_f32");
 }
 

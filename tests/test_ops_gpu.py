@@ -8,6 +8,8 @@ from garment4d_amd import pointnet2_utils as PU
 from garment4d_amd import synthetic as syn
 from oracle import pointnet2_oracle as K
 
+ROOT = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("contraction_mode")]   # every test runs in both numerics modes
 TOL = dict(rtol=1e-5, atol=1e-5)
 
@@ -460,3 +462,32 @@ def test_search_multi_equals_the_separate_launches():
         assert torch.equal(a, b)
     for (d, i), (wd, wi) in zip(nn, wn):
         assert torch.equal(d, wd) and torch.equal(i, wi)
+
+
+@pytest.mark.parametrize("split", ["1", "2", "4"])
+def test_three_nn_wide_split_variants_are_identical(split):
+    """The known set split over 1 / 2 / 4 waves (G4D_NN_SPLIT) gives the scan's own result -- distances and indices bit for bit -- on a
+    cloud with duplicated points (equal distances: the merge must keep the lowest indices, interpolate_gpu.cu:31-42) and a ragged size.
+    Runs in a subprocess: the switch is read once per process."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, torch, sys
+        sys.path.insert(0, %r)
+        from garment4d_amd import _lib, synthetic as syn
+        sys.path.insert(0, %r)
+        from oracle import pointnet2_oracle as O
+        B, n, m = 2, 4133, 777
+        u = syn.body_like_cloud(B, n, seed=5, dup_frac=0.05, zero_frac=0.01).astype(np.float32)
+        k = np.ascontiguousarray(u[:, ::5][:, :m]); k[:, 100:140] = k[:, 60:100]   # duplicated known points: ties
+        ut, kt = torch.from_numpy(u).cuda(), torch.from_numpy(k).cuda()
+        d2 = torch.empty(B, n, 3, device="cuda"); ix = torch.empty(B, n, 3, dtype=torch.int32, device="cuda")
+        _lib.call("g4d_three_nn_f32", B, n, m, ut.data_ptr(), kt.data_ptr(), d2.data_ptr(), ix.data_ptr(), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        O.set_contraction(_lib.lib().g4d_get_distance_contraction())
+        rd, ri = O.three_nn(u, k)
+        assert np.array_equal(ri, ix.cpu().numpy()) and np.array_equal(rd, np.sqrt(d2.cpu().numpy()))
+        print("ok")
+    ''') % (ROOT, ROOT)
+    env = dict(os.environ, G4D_NN_SPLIT=split)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
