@@ -17,7 +17,7 @@ Multi-GPU: frames are independent -> each rank processes its ow
 collective, weak scaling; value = frames of all ranks / max-over-ranks time.
 
 Timed region: the K steps are repeated R times back to back (`repeats` in the output; R chosen so that the region lasts
->= 0.5 s whatever --steps is, so a short driver run is not a single wave of 16 batches); ms_per_step = time / (K * R).
+>= 0.5 s whatever --steps is, so a short driver run is not a single wave of batches); ms_per_step = time / (K * R).
 Inputs: every step first copies a fresh batch from a rotating pool of distinct clouds (> 256 MB, i.e. larger than the MALL)
 into the stream's input buffer, so the path reads inputs that are cold in every cache -- the copy is inside the timed region.
 
@@ -35,7 +35,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 16 batches in flight on 16
-# streams, 4 queues serialise them four deep (11.8k frames/s); 32 queues let every stream own one (17.9k).  Must be
+# streams, 4 queues serialise them four deep (11.8k frames/s, round 1); 32 queues let every stream own one (17.9k).
+# Past ~24 streams they share queues again and the step collapses (profiles/r03_dispatch_cost_by_streams.txt).  Must be
 # set before the runtime initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
@@ -256,13 +257,13 @@ def kernel_rooflines(model, cloud, precision="fp32"):
                                       "tflops_equivalent": flops_alg / (t + t_tab) / 1e12,
                                       "frac_equivalent": flops_alg / (t + t_tab) / 1e12 / MFMA_F32_PEAK_TFLOPS},
                       "full_chain": full,
-                      "note": "isolated launches on an idle chip; inside the 16-batch bench the same launch runs concurrently with others"}
+                      "note": "isolated launches on an idle chip; inside the many-batch bench the same launch runs concurrently with others"}
     else:
         tr = pmc_traffic("mlp_chain_kernel<1, 8, 8, 16")
         res["mlp"] = dict(full, kernel=full["kernel"] + " (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", bound="mfma",
                           peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
                           traffic_source=None if tr is None else tr["source"],
-                          note="isolated launch on an idle chip; inside the 16-batch bench the same launch runs concurrently with others")
+                          note="isolated launch on an idle chip; inside the many-batch bench the same launch runs concurrently with others")
     return res
 
 

@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
                                                            int sorted_out) {
     __shared__ __attribute__((aligned(16))) float skx[kNNChunk], sky[kNNChunk], skz[kNNChunk];
     constexpr int QPB = 256 / SPLIT;   // queries per workgroup
-    __shared__ float sd[SPLIT > 1 ? SPLIT - 1 : 1][QPB][3];
-    __shared__ int si[SPLIT > 1 ? SPLIT - 1 : 1][QPB][3];
+    __shared__ float sd[SPLIT > 1 ? SPLIT - 1 : 1][SPLIT > 1 ? QPB : 1][3];   // the slices' top-3 lists (none un-split)
+    __shared__ int si[SPLIT > 1 ? SPLIT - 1 : 1][SPLIT > 1 ? QPB : 1][3];
     const int b = blockIdx.y;
     const int slice = (int)threadIdx.x / QPB, ql = (int)threadIdx.x % QPB;   // wave-uniform slice (QPB is a multiple of 64)
     int p = (int)blockIdx.x * QPB + ql;
