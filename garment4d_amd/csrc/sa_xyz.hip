@@ -41,10 +41,32 @@ __device__ __forceinline__ F3s ld3(const float *base, unsigned elem) {
     return *reinterpret_cast<const F3s *>(reinterpret_cast<const char *>(base) + (elem << 2));
 }
 
-template <int C1, int C2, int C3>
-__device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int bx, int nblocks) {
+// max over the 16 rows of FOUR row-major tiles at once.  v_c (c = 0..3) holds, in lane (fi, fq), a value already reduced over that lane's
+// rows 4 fq + r; what is left is the max over the four 16-lane rows of the wave, per tile.  v_permlane16_swap(a, b) leaves
+// {a.row0, b.row0, a.row2, b.row2} / {a.row1, b.row1, a.row3, b.row3}, so ONE swap + ONE max halves two tiles at once and parks them in
+// alternating rows; v_permlane32_swap does the same for the two halves of the wave.  Result: lane 16 c + fi = max over all 16 rows of
+// tile c at column fi -- 64 different outputs in one register (one 256-byte store) after 3 swaps + 3 max, where reducing the tiles one by
+// one (lane_xor16 / lane_xor32: copies, swap, select, max per step) took ~40 instructions and four quarter-wave stores.
+__device__ __forceinline__ float pool4_rows_max(float v0, float v1, float v2, float v3) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+    const float m01 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));   // rows: tile 0 (fq 0|1), tile 1 (fq 0|1), tile 0 (fq 2|3), tile 1 (fq 2|3)
+    const float m23 = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(m01), __float_as_uint(m23), false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));              // rows: tile 0, tile 1, tile 2, tile 3
+}
+
+// One stack over the passes `first, first + stride, ...` of a wave (a pass = 32 consecutive grouped rows).  LOGS / MAXP are compile-time:
+// with the pooling mode and window resolved at run time the epilogue was ~45 % of the loop's VALU instructions (both max and sum
+// computed and selected, a branch maze per channel tile; 5.0 VALU instructions per MFMA, SQ counters at 240 clouds per launch), and at
+// ~5 VALU per 32-cycle MFMA the two waves of a SIMD cannot keep the matrix pipe busy (0.41).
+template <int C1, int C2, int C3, int LOGS, bool MAXP>
+__device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int stride) {
     constexpr int T1 = C1 / 16, T2 = C2 / 16, T3 = C3 / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int S = 1 << LOGS;
+    static_assert(S == 16 || S == 32, "16 or 32 samples");
+    static_assert(T3 == 2 || T3 == 4, "32 or 64 output channels");
+    const int lane = threadIdx.x & 63;
     const int fi = lane & 15, fq = lane >> 4;
     // ---- weights into registers, once per wave
     float w1[T1][4][3], s1[T1][4], h1s[T1][4];
@@ -76,9 +98,7 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int bx, int nblo
     for (int ct = 0; ct < T3; ++ct) { s3[ct] = a.sc3[ct * 16 + fi]; h3s[ct] = a.sh3[ct * 16 + fi]; }
 
     const int rows = (int)a.rows;            // < 2^31 (launcher)
-    const int npass = (rows + 31) >> 5;      // 32 rows per pass; S >= 16 divides 32 or is a multiple of it
-    const bool is_max = a.pool == 1;
-    const float inv = is_max ? 1.f : 1.f / (float)a.S;
+    const int npass = (rows + 31) >> 5;      // 32 rows per pass; S = 16 divides it, S = 32 is it
     // Two-level software pipeline over the wave's passes (the gather is two dependent loads: index -> coordinates): while pass k is on
     // the VALU / MFMA, the coordinates of pass k + 1 are in flight and so are the indices of pass k + 2.
     struct Rows { F3s px[2], pq[2]; };
@@ -88,7 +108,7 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int bx, int nblo
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) v[mt] = a.idx[min(min(pass, npass - 1) * 32 + mt * 16 + fi, rows - 1)];   // unconditional (see load_rows)
     };
-    const int nq = (int)(a.rows >> a.logS);
+    const int nq = (int)(a.rows >> LOGS);
     auto load_rows = [&](int pass, const int (&v)[2], Rows &rw) {
         // No `if (pass < npass)` around these loads: past the end the last pass is read again and never used.  A conditional block
         // makes the number of loads in flight unknown at the join, and the wait for the CURRENT pass's rows (older than these)
@@ -96,14 +116,13 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int bx, int nblo
         pass = min(pass, npass - 1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int qi = __builtin_amdgcn_readfirstlane(min((pass * 32 + mt * 16) >> a.logS, nq - 1));   // S >= 16: a tile belongs to one query
+            const int qi = __builtin_amdgcn_readfirstlane(min((pass * 32 + mt * 16) >> LOGS, nq - 1));   // S >= 16: a tile belongs to one query
             const int f = qi / a.p;
             rw.px[mt] = ld3(a.xyz, (unsigned)(f * a.n + v[mt]) * 3u);
             rw.pq[mt] = ld3(a.new_xyz, (unsigned)qi * 3u);
         }
     };
-    const int stride = nblocks * 4;
-    int pass = bx * 4 + wave;
+    int pass = first;
     load_idx(pass, ivn);
     load_rows(pass, ivn, cur);
     load_idx(pass + stride, ivn);
@@ -162,48 +181,98 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int bx, int nblo
                     for (int ct = 0; ct < T3; ++ct)
                         acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[mt][ks][e], w3[ct][ks][e], acc[mt][ct], 0, 0, 0);
         // ---- affine + ReLU + pool over the S rows of each neighbourhood
+        if constexpr (MAXP) {
+            // max_r relu(y_r) = relu(max_r y_r) exactly, so the ReLU is applied once per output; v[mt][ct] = this lane's four rows of tile mt
+            float v[2][T3];
 #pragma unroll
-        for (int ct = 0; ct < T3; ++ct) {
-            float v[2];
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float y[4];
+                for (int ct = 0; ct < T3; ++ct) {
+                    const float y0 = __builtin_fmaf(acc[mt][ct][0], s3[ct], h3s[ct]), y1 = __builtin_fmaf(acc[mt][ct][1], s3[ct], h3s[ct]),
+                                y2 = __builtin_fmaf(acc[mt][ct][2], s3[ct], h3s[ct]), y3 = __builtin_fmaf(acc[mt][ct][3], s3[ct], h3s[ct]);
+                    v[mt][ct] = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+                }
+            if constexpr (S == 32) {   // the two tiles of the pass are one neighbourhood: out row = pass
+                float x[T3];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = fmaxf(__builtin_fmaf(acc[mt][ct][r], s3[ct], h3s[ct]), 0.f);
-                float x = is_max ? fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])) : ((y[0] + y[1]) + (y[2] + y[3]));
-                const float x16 = lane_xor16(x);
-                x = is_max ? fmaxf(x, x16) : x + x16;
-                const float x32 = lane_xor32(x);
-                x = is_max ? fmaxf(x, x32) : x + x32;
-                v[mt] = x;      // the 16 rows of tile mt, in every lane
-            }
-            const int ch = ct * 16 + fi;
-            if (a.S == 16) {
-                if (lane < 16) {
+                for (int ct = 0; ct < T3; ++ct) x[ct] = fmaxf(v[0][ct], v[1][ct]);
+                float *o = a.out + (size_t)pass * a.ldo + a.col0;
+                if constexpr (T3 == 4) {
+                    o[lane] = fmaxf(pool4_rows_max(x[0], x[1], x[2], x[3]), 0.f);                       // lane = channel: one 256-byte store
+                } else {
+                    const float m = fmaxf(pool4_rows_max(x[0], x[1], x[0], x[1]), 0.f);                 // rows: tile 0, tile 1, tile 0, tile 1
+                    if (lane < 32) o[lane] = m;
+                }
+            } else {                   // S == 16: tile mt is neighbourhood 2 pass + mt
+                if constexpr (T3 == 2) {
+                    const float m = fmaxf(pool4_rows_max(v[0][0], v[0][1], v[1][0], v[1][1]), 0.f);     // lanes 0..31: tile 0's 32 channels, 32..63: tile 1's
+                    const int g = 2 * pass + (lane >> 5);
+                    if (g < nq) a.out[(size_t)g * a.ldo + a.col0 + (lane & 31)] = m;
+                } else {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        const int first_row = row0 + mt * 16;
-                        if (first_row < rows) a.out[(size_t)(first_row >> 4) * a.ldo + a.col0 + ch] = v[mt] * inv;
+                        const float m = fmaxf(pool4_rows_max(v[mt][0], v[mt][1], v[mt][2], v[mt][3]), 0.f);
+                        if (2 * pass + mt < nq) a.out[(size_t)(2 * pass + mt) * a.ldo + a.col0 + lane] = m;
                     }
                 }
-            } else {   // S == 32: the two tiles of the pass are one neighbourhood
-                const float x = is_max ? fmaxf(v[0], v[1]) : v[0] + v[1];
-                if (lane < 16 && row0 < rows) a.out[(size_t)(row0 >> 5) * a.ldo + a.col0 + ch] = x * inv;
+            }
+        } else {   // mean pooling: the ReLU does not commute with the sum
+            constexpr float inv = 1.f / (float)S;
+#pragma unroll
+            for (int ct = 0; ct < T3; ++ct) {
+                float v[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(__builtin_fmaf(acc[mt][ct][r], s3[ct], h3s[ct]), 0.f);
+                    float x = (y[0] + y[1]) + (y[2] + y[3]);
+                    x = x + lane_xor16(x);
+                    x = x + lane_xor32(x);
+                    v[mt] = x;      // the 16 rows of tile mt, in every lane
+                }
+                const int ch = ct * 16 + fi;
+                if constexpr (S == 16) {
+                    if (lane < 16) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const int first_row = row0 + mt * 16;
+                            if (first_row < rows) a.out[(size_t)(first_row >> 4) * a.ldo + a.col0 + ch] = v[mt] * inv;
+                        }
+                    }
+                } else {
+                    if (lane < 16 && row0 < rows) a.out[(size_t)(row0 >> 5) * a.ldo + a.col0 + ch] = (v[0] + v[1]) * inv;
+                }
             }
         }
     }
 }
 
 template <int C1, int C2, int C3>
-__global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
-    sa_xyz_body<C1, C2, C3>(a, blockIdx.x, gridDim.x);
+__device__ __forceinline__ void sa_xyz_dispatch(const SaXyzArgs &a, int first, int stride) {
+    if (a.pool == 1) {
+        if (a.S == 16) sa_xyz_body<C1, C2, C3, 4, true>(a, first, stride);
+        else sa_xyz_body<C1, C2, C3, 5, true>(a, first, stride);
+    } else {
+        if (a.S == 16) sa_xyz_body<C1, C2, C3, 4, false>(a, first, stride);
+        else sa_xyz_body<C1, C2, C3, 5, false>(a, first, stride);
+    }
 }
 
-// Both xyz-only scales of an MSG level (16-16-32 at 16 samples and 32-32-64 at 32) in ONE launch: the first nb0 workgroups run the narrow
-// stack, the rest the wide one, each a persistent pool of its own (a launch costs the 16-batch mix 3-5 us; the narrow stack alone is 7 us).
-__global__ void __launch_bounds__(256, 2) sa_xyz_pair_kernel(const SaXyzArgs a0, const SaXyzArgs a1, int nb0) {
-    if ((int)blockIdx.x < nb0) sa_xyz_body<16, 16, 32>(a0, blockIdx.x, nb0);
-    else sa_xyz_body<32, 32, 64>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+template <int C1, int C2, int C3>
+__global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
+    sa_xyz_dispatch<C1, C2, C3>(a, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4);
+}
+
+// Both xyz-only scales of an MSG level (16-16-32 at 16 samples and 32-32-64 at 32, max pool) in ONE launch.  Every wave takes its share
+// of the wide stack's passes, then its share of the narrow one's (weights re-loaded in between): one persistent pool.  (Two pools sized
+// by MFMA work -- round 2 -- left 32 % of the wave slots empty at the end, the narrow stack's passes being costlier per MFMA: 1.36
+// resident waves per SIMD of 2, SQ counters at 240 clouds per launch.)
+template <bool MAXP>
+__global__ void __launch_bounds__(256, 2) sa_xyz_pair_kernel(const SaXyzArgs a0, const SaXyzArgs a1) {
+    const int first = blockIdx.x * 4 + (threadIdx.x >> 6), stride = gridDim.x * 4;
+    sa_xyz_body<32, 32, 64, 5, MAXP>(a1, first, stride);
+    sa_xyz_body<16, 16, 32, 4, MAXP>(a0, first, stride);
 }
 
 }  // namespace g4d
@@ -251,18 +320,14 @@ extern "C" int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, c
     if (int rc = sa_xyz_fill(a1, b, n, p, nsample1, xyz, new_xyz, idx1, 32, 32, 64, W1_1, ldw1_1, scale1_1, shift1_1, W2_frag1, kpad2_1, scale2_1, shift2_1,
                              W3_frag1, kpad3_1, scale3_1, shift3_1, pool, out, ldo, col0_1)) return rc;
     if (a0.rows == 0) return G4D_OK;
-    // workgroups in proportion to the MFMA work of the two stacks (per row: 16*16 + 16*32 vs 32*32 + 32*64), two persistent workgroups per CU in all
+    G4D_REQUIRE(nsample0 == 16 && nsample1 == 32, "g4d_sa_xyz_mlp3_pair_f32: scale 0 takes 16 samples, scale 1 takes 32");
+    // one persistent pool, two workgroups per CU (two waves per SIMD), never more waves than the wide stack has passes
     static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
-    const long long w0 = a0.rows * (16 * 16 + 16 * 32), w1 = a1.rows * (32 * 32 + 32 * 64);
-    const int total = 256 * bpc;
-    long long nb0 = (total * w0 + (w0 + w1) / 2) / (w0 + w1);
-    const long long want0 = ((a0.rows + 31) / 32 + 3) / 4, want1 = ((a1.rows + 31) / 32 + 3) / 4;
-    if (nb0 < 1) nb0 = 1;
-    if (nb0 > want0) nb0 = want0;
-    long long nb1 = total - nb0;
-    if (nb1 > want1) nb1 = want1;
-    if (nb1 < 1) nb1 = 1;
-    hipLaunchKernelGGL(sa_xyz_pair_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a0, a1, (int)nb0);
+    const long long want = ((a1.rows + 31) / 32 + 3) / 4;
+    const unsigned grid = (unsigned)(want < 256 * bpc ? want : 256 * bpc);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (pool == 1) hipLaunchKernelGGL(sa_xyz_pair_kernel<true>, dim3(grid), dim3(256), 0, st, a0, a1);
+    else hipLaunchKernelGGL(sa_xyz_pair_kernel<false>, dim3(grid), dim3(256), 0, st, a0, a1);
     return check_launch("g4d_sa_xyz_mlp3_pair_f32");
 }
 

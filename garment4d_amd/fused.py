@@ -701,7 +701,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
         if (USE_SA_XYZ and SA_XYZ_PAIR and C == 0 and len(packed) == 2 and current_precision() == "fp32" and B * N * 12 < 2 ** 32
                 and all(int(g.use_xyz) for g in sa.groupers) and all(len(L_) == 3 and all(L.relu for L in L_) for L_ in packed)
                 and [L.Cout for L in packed[0]] == [16, 16, 32] and [L.Cout for L in packed[1]] == [32, 32, 64]
-                and all(g.nsample in (16, 32) for g in sa.groupers)):
+                and [g.nsample for g in sa.groupers] == [16, 32]):
             # both xyz-only scales of the level in one launch (csrc/sa_xyz.hip, sa_xyz_pair_kernel)
             args = []
             c0 = 0
