@@ -54,11 +54,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=160)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=20, help="independent batches in flight per GPU (16 / 18 / 20 / 22 / 24 measured: 34.0k / 33.7k / 34.6k / 34.0k / 31.6k frames/s)")
+    ap.add_argument("--coalesce", type=int, default=30, help="B = 8 steps gathered into one call of the executor (garment4d_amd/pipeline.py): 30 = the "
+                                                              "reference's own fold of (8 clips, 30 frames) into one batch, modules/mesh_encoder.py:133")
+    ap.add_argument("--streams", type=int, default=2, help="calls in flight per GPU, each a captured hipGraph on its own stream (profiles/r04_coalesce_by_streams.txt)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per sample the CPU oracle is timed on with all cores")
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of the timed region (the K steps are repeated)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum length of the timed region (the K steps are repeated)")
     ap.add_argument("--input-pool-mb", type=float, default=320.0, help="distinct input clouds rotated through, in MB (0 = replay the "
                                                                        "same resident batches: MALL-warm inputs)")
     ap.add_argument("--no-lbs", action="store_true")
@@ -69,38 +71,26 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(device, streams, with_lbs, pool_mb=0.0):
+def build_workload(device, with_lbs, pool_mb):
+    """(model, lbs inputs, pool of distinct input batches, pool of (betas, pose) pairs).  The steps rotate through `pool`: distinct B = 8
+    batches generated on the device (uniform clouds, as syn.unit_cloud), more than the MALL holds."""
     from garment4d_amd import synthetic as syn
     from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=0).to(device).eval()
-    clouds = [torch.from_numpy(syn.unit_cloud(B_CLOUDS, N_POINTS, seed=1 + s)).to(device) for s in range(streams)]
-    pool = None
-    if pool_mb > 0:  # distinct batches the steps rotate through: generated on the device (uniform clouds, as syn.unit_cloud)
-        nb = int(np.ceil(pool_mb * 1e6 / (B_CLOUDS * N_POINTS * 12)))
-        g = torch.Generator(device=device).manual_seed(12345)
-        pool = torch.rand((nb, B_CLOUDS, N_POINTS, 3), generator=g, device=device, dtype=torch.float32)
-    lbs_in = None
+    nb = max(2, int(np.ceil(pool_mb * 1e6 / (B_CLOUDS * N_POINTS * 12))))
+    g = torch.Generator(device=device).manual_seed(12345)
+    pool = torch.rand((nb, B_CLOUDS, N_POINTS, 3), generator=g, device=device, dtype=torch.float32)
+    lbs_in = pose_pool = None
     if with_lbs:
         from garment4d_amd import lbs as G
         P = syn.smpl_like_params(seed=40)
         smpl = {k: torch.from_numpy(v).to(device) for k, v in P.items()}
-        poses = []
-        for s in range(streams):
+        pose_pool = []
+        for s in range(32):
             betas, pose = syn.smpl_like_pose(B_CLOUDS, seed=100 + s)
-            poses.append((torch.from_numpy(betas).to(device), torch.from_numpy(pose).to(device)))
-        lbs_in = (G, smpl, poses)
-    return model, clouds, lbs_in, pool
-
-
-def one_step(model, cloud, lbs_in, slot, precision="fp32"):
-    out = model.forward_fused(cloud, precision=precision)
-    if lbs_in is not None:
-        G, smpl, poses = lbs_in
-        betas, pose = poses[slot]
-        v, j = G.lbs(betas, pose, smpl["v_template"], smpl["shapedirs"], smpl["posedirs"], smpl["J_regressor"],
-                     smpl["parents"], smpl["lbs_weights"], pose2rot=True)
-        return out[1], v
-    return out[1], None
+            pose_pool.append((torch.from_numpy(betas).to(device), torch.from_numpy(pose).to(device)))
+        lbs_in = (G, smpl, pose_pool)
+    return model, lbs_in, pool, pose_pool
 
 
 def pmc_traffic(kernel_substr):
@@ -442,29 +432,17 @@ def main():
     except ImportError:
         with_lbs = False
     ns = max(1, args.streams)
-    model, clouds, lbs_in, pool = build_workload(dev, ns, with_lbs, args.input_pool_mb)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
-    npool = 0 if pool is None else pool.shape[0]
+    kco = max(1, args.coalesce)
+    model, lbs_in, pool, pose_pool = build_workload(dev, with_lbs, args.input_pool_mb)
+    npool = pool.shape[0]
+    from garment4d_amd.pipeline import StepPipeline
+    smpl = None if lbs_in is None else lbs_in[1]
 
     with torch.no_grad():
-        # eager warm-up (also packs weights, sets kernel attributes)
-        for w in range(max(args.warmup, 1)):
-            s = w % ns
-            with torch.cuda.stream(streams[s]):
-                one_step(model, clouds[s], lbs_in, s, args.precision)
-        torch.cuda.synchronize()
-        graphs = None
-        if not args.no_graph:
-            graphs = []
-            for s in range(ns):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=streams[s]):
-                    one_step(model, clouds[s], lbs_in, s, args.precision)
-                graphs.append(g)
-            for s in range(ns):  # one untimed replay each
-                with torch.cuda.stream(streams[s]):
-                    graphs[s].replay()
-            torch.cuda.synchronize()
+        # the executor: `ns` calls in flight, each the hot path on 8 * kco clouds as one captured hipGraph on its own stream; its constructor
+        # runs every call once eagerly (packs weights, sets kernel attributes) and captures it
+        pipe = StepPipeline(model, smpl, clouds_per_step=B_CLOUDS, n_points=N_POINTS, coalesce=kco, streams=ns, precision=args.precision,
+                            device=dev, use_graph=not args.no_graph)
 
         def barrier():
             torch.cuda.synchronize()
@@ -473,25 +451,28 @@ def main():
             torch.cuda.synchronize()
 
         def run_steps(first, count):
-            """`count` steps, round-robin over the streams; each takes the next batch of the input pool (a device-to-device copy
-            on the step's own stream, inside the timed region) and runs the whole hot path on it."""
+            """`count` B = 8 steps handed to the executor one at a time; each is the next batch of the input pool (device-to-device copies
+            into the call's input buffers on the call's stream, inside the timed region); a call goes out when `kco` steps are in it."""
             for k in range(first, first + count):
-                s = k % ns
-                with torch.cuda.stream(streams[s]):
-                    if pool is not None:
-                        clouds[s].copy_(pool[k % npool], non_blocking=True)
-                    if graphs is not None:
-                        graphs[s].replay()
-                    else:
-                        one_step(model, clouds[s], lbs_in, s, args.precision)
+                if pose_pool is None:
+                    pipe.submit(pool[k % npool], inputs_ready=True)
+                else:
+                    bt, ps = pose_pool[k % len(pose_pool)]
+                    pipe.submit(pool[k % npool], bt, ps, inputs_ready=True)
+
+        run_steps(0, max(args.warmup, 1))                # W untimed warm-up steps (the executor has already run every call once)
+        pipe.synchronize()
 
         # The K-step block is repeated R times; R grows until the timed region lasts >= --min-seconds (all ranks agree on R and on
-        # "long enough" through the max-reduced time).  Only the last, long-enough run is reported.
+        # "long enough" through the max-reduced time).  Only the last, long-enough run is reported.  Every step submitted inside the region
+        # is finished inside it: a last, partially filled call is flushed (it then runs on stale clouds as well -- R is chosen so that K * R
+        # is a multiple of the coalescing factor and nothing is wasted in the reported run).
         def timed_block(repeats):
             barrier()
             t0 = time.perf_counter()
             for r in range(repeats):
                 run_steps(r * args.steps, args.steps)
+            pipe.synchronize()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if dist is not None:
@@ -501,30 +482,57 @@ def main():
             barrier()
             return dt
 
-        timed_block(1)                                   # untimed: first replays after capture
-        repeats = 1
+        unit = kco // int(np.gcd(kco, args.steps))       # repeats that make K * R a multiple of the coalescing factor
+        repeats = unit
+        timed_block(repeats)                             # untimed: first replays after capture
         while True:
             dt = timed_block(repeats)
-            if dt >= args.min_seconds or repeats >= 1 << 16:
+            if dt >= args.min_seconds or repeats >= 1 << 20:
                 break
-            repeats = max(repeats + 1, int(np.ceil(repeats * args.min_seconds / max(dt, 1e-6) * 1.15)))
+            repeats = max(repeats + unit, int(np.ceil(repeats * args.min_seconds / max(dt, 1e-6) * 1.15 / unit)) * unit)
+        # per-rank rate of the reported run (rank 0 prints the spread: a straggling GPU shows here first)
+        my_dt = None
+        if dist is not None:
+            barrier()
+            t0 = time.perf_counter()
+            for r in range(unit):
+                run_steps(r * args.steps, args.steps)
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            my_dt = time.perf_counter() - t0
+            rates = torch.tensor([unit * args.steps * B_CLOUDS / my_dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            gl = [torch.zeros_like(rates) for _ in range(world)]
+            dist.all_gather(gl, rates)
+            per_rank = [float(t.item()) for t in gl]
+        else:
+            per_rank = None
 
-        # single-batch latency: one graph alone on an otherwise idle chip (what a caller that cannot batch sees)
-        lat = None
+        # single-batch latency: ONE B = 8 step alone on an otherwise idle chip (what a caller that cannot batch sees) -- a captured graph of
+        # the path on 8 clouds, not the coalesced call
+        lat = lat_call = None
         if rank == 0:
-            ts = []
-            with torch.cuda.stream(streams[0]):
+            one = StepPipeline(model, smpl, clouds_per_step=B_CLOUDS, n_points=N_POINTS, coalesce=1, streams=1, precision=args.precision,
+                               device=dev, use_graph=not args.no_graph)
+
+            def alone(pp, nsub):
+                ts = []
                 for i in range(12):
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    if graphs is not None:
-                        graphs[0].replay()
-                    else:
-                        one_step(model, clouds[0], lbs_in, 0, args.precision)
+                    run = run_steps if pp is pipe else None
+                    for k in range(nsub):
+                        if pose_pool is None:
+                            pp.submit(pool[k % npool], inputs_ready=True)
+                        else:
+                            pp.submit(pool[k % npool], *pose_pool[k % len(pose_pool)], inputs_ready=True)
+                    pp.synchronize()
                     torch.cuda.synchronize()
                     ts.append(time.perf_counter() - t1)
-            lat = float(np.median(ts[2:])) * 1e3
-        roof = kernel_rooflines(model, clouds[0], args.precision) if rank == 0 else None
+                return float(np.median(ts[2:])) * 1e3
+            lat = alone(one, 1)
+            lat_call = alone(pipe, kco)                  # one coalesced call alone (includes its kco input copies)
+            del one
+        roof = kernel_rooflines(model, pool[0], args.precision) if rank == 0 else None
 
     if rank == 0:
         total_steps = args.steps * repeats
@@ -537,16 +545,21 @@ def main():
             "timed_seconds": dt, "ms_per_step": dt / total_steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MLP operands / f32 accumulate, sampling, LBS",
                       "bf16x3": "f32 values; shared-MLP products as 6 bf16 x bf16 piece products of exact 3-way operand splits, f32 accumulate (fp32-accurate)"}[args.precision], "data": "synthetic",
-            "latency_ms_single_stream": lat,
+            "latency_ms_single_stream": lat, "latency_frames_per_s": None if not lat else B_CLOUDS / (lat * 1e-3),
+            "latency_ms_one_call": lat_call, "frames_per_s_by_rank": per_rank,
             "config": {"workload": ("cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32" if args.precision == "fp32" else
                                     f"cfg3 precision on the cfg2 step: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head), shared-MLP operands {args.precision}")
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),
-                       "frames_per_step": B_CLOUDS, "batches_in_flight": ns, "hipgraph": graphs is not None,
+                       "frames_per_step": B_CLOUDS, "coalesce": kco, "clouds_per_call": B_CLOUDS * kco, "calls_in_flight": ns,
+                       "batches_in_flight": ns * kco, "hipgraph": not args.no_graph,
+                       "executor": "garment4d_amd.pipeline.StepPipeline: steps are submitted one B=8 batch at a time; `coalesce` consecutive steps run as "
+                                   "one call on 8*coalesce clouds (bit-identical per cloud), `calls_in_flight` calls overlap on their own streams",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "inputs": (f"rotating pool of {npool} distinct batches = {npool * B_CLOUDS * N_POINTS * 12 / 1e6:.0f} MB (> 256 MB MALL), "
-                                  "copied in on the step's stream inside the timed region") if pool is not None
-                                 else f"{ns} resident batches replayed (MALL-warm inputs)",
-                       "note": f"a step lasts longer than ms_per_step: {ns} batches overlap (single-batch latency: latency_ms_single_stream)",
+                       "inputs": (f"rotating pool of {npool} distinct batches = {npool * B_CLOUDS * N_POINTS * 12 / 1e6:.0f} MB"
+                                  f"{' (> 256 MB MALL)' if npool * B_CLOUDS * N_POINTS * 12 > 256e6 else ''}, each step's batch (and its betas / pose) copied "
+                                  "into the call's input buffers on the call's stream inside the timed region"),
+                       "note": f"a step lasts longer than ms_per_step: {ns} calls of {kco} steps overlap (one B=8 step alone: latency_ms_single_stream; "
+                               "one coalesced call alone: latency_ms_one_call)",
                        "device": torch.cuda.get_device_name(dev),
                        "collective_backend": None if dist is None else f"{args.backend} world_size={dist.get_world_size()} (barrier + max-reduce of the time only)",
                        "launcher": "self (bench.py re-executed under torch.distributed.run)" if os.environ.get("G4D_BENCH_SELF_LAUNCHED") else

@@ -12,6 +12,8 @@
 // are read once per batch of up to 8 frames; per-frame algorithmic traffic is 24 B/vertex + 64 B/joint.
 // lbs_pose_blend splits the 207 pose features over 4 k-slices x 64 columns per workgroup so that ~1300 waves stream
 // posedirs; lbs_skin runs one thread per (frame, vertex) with the frame's 24 joint transforms in LDS.
+#include <cstdlib>
+
 #include "g4d_common.h"
 
 namespace g4d {
@@ -295,7 +297,6 @@ __global__ void __launch_bounds__(64 * kOneKS) lbs_one_kernel(int B, int V, int 
     float *sG = sL + kFB * kOneJ * 12;                     // [kFB][kOneJ][12]
     float *sRed = sG + kFB * kOneJ * 12;                   // [kOneKS][kFB * 3][64]
     const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b0 = blockIdx.y * kFB, nf = min(kFB, B - b0);
     const int NC = NB + (J - 1) * 9;
     const size_t E = (size_t)V * 3;
     const int v = blockIdx.x * 64 + l;
@@ -325,8 +326,14 @@ __global__ void __launch_bounds__(64 * kOneKS) lbs_one_kernel(int B, int V, int 
     }
     const float t0 = v_template[(size_t)vc * 3 + 0], t1 = v_template[(size_t)vc * 3 + 1], t2 = v_template[(size_t)vc * 3 + 2];
 
-    // (2) frame w: rotations, joints, coefficients, chain (wave-local)
+    // Frame groups of 8: blockIdx.y takes groups blockIdx.y, blockIdx.y + gridDim.y, ... with the blend rows, weights and template of its 64
+    // vertices held in registers throughout (many frames per call -- the executor's 240: every group used to be a workgroup of its own that
+    // re-read the 17.9 MB of blend rows; per frame the arithmetic is the same whatever the grouping, so results do not depend on the batch size)
     const int f = w;
+    const int ngroups = (B + kFB - 1) / kFB;
+  for (int grp = blockIdx.y; grp < ngroups; grp += gridDim.y) {
+    const int b0 = grp * kFB, nf = min(kFB, B - b0);
+    // (2) frame w: rotations, joints, coefficients, chain (wave-local)
     for (int i = l; i < kOneRows * kFB; i += 64) sC[(size_t)w * kOneRows * kFB + i] = 0.f;   // 1/8 of the table each
     lds_barrier();   // LDS only: __syncthreads() would wait for the loads above
     float *R_ = sR + (size_t)f * kOneJ * 9, *J_ = sJ + (size_t)f * kOneJ * 3, *L_ = sL + (size_t)f * kOneJ * 12, *G_ = sG + (size_t)f * kOneJ * 12;
@@ -442,6 +449,8 @@ __global__ void __launch_bounds__(64 * kOneKS) lbs_one_kernel(int B, int V, int 
         o[1] = fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7];
         o[2] = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
     }
+    __syncthreads();   // the next group overwrites the coefficient table, the transforms and the partial sums
+  }
 }
 
 }  // namespace g4d
@@ -551,7 +560,6 @@ extern "C" int g4d_lbs_one_f32(int b, int v, int j, int nb, int pose2rot, const 
                                const int *parents, const float *lbs_weights, float *A_out, float *posed_joints, float *verts,
                                g4d_stream_t stream) {
     G4D_REQUIRE(b >= 0 && v > 0 && g4d_lbs_one_supported(j, nb), "g4d_lbs_one_f32: need V > 0, J <= 32 and NB + 9 (J - 1) <= 224 (use g4d_lbs_fused_f32)");
-    G4D_REQUIRE((b + kFB - 1) / kFB <= 65535, "g4d_lbs_one_f32: too many frames for one launch");
     if (b == 0) return G4D_OK;
     G4D_REQUIRE(betas && pose && v_template && blend_dirs && J_template && J_shapedirs && parents && lbs_weights && A_out && verts,
                 "g4d_lbs_one_f32: null pointer");
@@ -559,7 +567,13 @@ extern "C" int g4d_lbs_one_f32(int b, int v, int j, int nb, int pose2rot, const 
     static unsigned long long attr = 0;
     const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(lbs_one_kernel), lds, attr, "g4d_lbs_one_f32");
     if (rc) return rc;
-    hipLaunchKernelGGL(lbs_one_kernel, dim3((v + 63) / 64, (b + kFB - 1) / kFB), dim3(64 * kOneKS), lds, G4D_S(stream), b, v, j, nb, pose2rot,
+    // frame groups per vertex tile: all of them side by side while that still leaves under ~3 workgroups per CU, else a share each
+    const int vt = (v + 63) / 64, ngroups = (b + kFB - 1) / kFB;
+    static const int gy_env = getenv("G4D_LBS_ONE_GROUPS") ? atoi(getenv("G4D_LBS_ONE_GROUPS")) : 0;   // tuning hook
+    int gy = ngroups;
+    if (gy_env > 0) gy = gy_env < ngroups ? gy_env : ngroups;
+    else if ((long long)vt * ngroups > 768) { gy = (768 + vt - 1) / vt; if (gy > ngroups) gy = ngroups; if (gy < 1) gy = 1; }
+    hipLaunchKernelGGL(lbs_one_kernel, dim3(vt, gy), dim3(64 * kOneKS), lds, G4D_S(stream), b, v, j, nb, pose2rot,
                        betas, betas_bstride, pose, v_template, blend_dirs, J_template, J_shapedirs, parents, lbs_weights, A_out, posed_joints, verts);
     return check_launch("g4d_lbs_one_f32");
 }

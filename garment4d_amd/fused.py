@@ -235,7 +235,10 @@ class precision:
         return False
 
 
-_BF16_MIN_ROWS = 8192  # below 128 workgroups of 64 rows the one-launch bf16 stack leaves the chip idle: stay on the fp32 path
+# Launches below this many rows stay on the fp32 kernels in bf16 mode.  0 since round 4: the precision of a cloud's result must not depend on
+# how many clouds share the call (the executor coalesces steps: FP level 3 has 2048 rows at 8 clouds, 8192 at 32 -- it used to switch
+# precision in between; tests/test_pipeline_gpu.py).  Was 8192 (below 128 workgroups of 64 rows the one-launch bf16 stack leaves the chip idle).
+_BF16_MIN_ROWS = int(os.environ.get("G4D_BF16_MIN_ROWS", "0"))
 
 
 def _use_bf16(rows):

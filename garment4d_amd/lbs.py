@@ -36,9 +36,11 @@ import os
 
 USE_FUSED_LBS = True   # lbs() on the fused kernels; False: the five-step path that follows lbs.py line by line
 USE_ONE_LAUNCH = os.environ.get("G4D_LBS_ONE", "1") != "0"   # fused route: one launch (g4d_lbs_one_f32) instead of three (g4d_lbs_fused_f32)
-# ... up to this many frames.  Measured (scripts/time_lbs.py, V = 6890): 8 frames 28.2 -> 16.8 us, 16: 31.5 -> 19.7, 24: 34.5 -> 33.0,
-# 64: 57.6 -> 67.5, 240: 159 -> 212 (every 8-frame group re-reads the blend rows and repeats the per-frame chain in each workgroup)
-ONE_LAUNCH_MAX_B = int(os.environ.get("G4D_LBS_ONE_MAX_B", "16"))
+# ... for any number of frames: the kernel walks the 8-frame groups with the blend rows of its 64 vertices in registers (round 4; before, every
+# group was a workgroup of its own that re-read the 17.9 MB of blend rows and the three-launch route took over above 16 frames -- with a
+# DIFFERENT partition of the blend sum, so a frame's vertices depended on the batch it was in; now they do not:
+# tests/test_pipeline_gpu.py).  G4D_LBS_ONE_MAX_B restores a limit (the three-launch route beyond it).
+ONE_LAUNCH_MAX_B = int(os.environ.get("G4D_LBS_ONE_MAX_B", str(1 << 30)))
 _const_cache = {}
 
 
