@@ -114,9 +114,10 @@ __device__ __forceinline__ void preload_ring(const ChainLayer &L, int lane, f32x
 }
 
 #ifdef G4D_CHAIN_DEBUG
-__device__ long long g_chain_dbg[8 * 4096];  // per wave (first 4096): 8 clock stamps (scripts/dbg_chain_phases.py)
+__device__ long long g_chain_dbg[8 * 4096];  // per wave (4096 of them, from row block g_chain_dbg_base on): 8 clock stamps (scripts/dbg_chain_phases.py)
+__device__ int g_chain_dbg_base = 0;         // first recorded row block: a window in the MIDDLE of a large launch shows the steady state (scripts/dbg_chain_steady.py)
 __shared__ int g_dbg_bid;
-#define G4D_CSTAMP(i) { const int gw_ = g_dbg_bid * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && gw_ < 4096) g_chain_dbg[gw_ * 8 + (i)] = (long long)__builtin_readcyclecounter(); }
+#define G4D_CSTAMP(i) { const int gw_ = (g_dbg_bid - g_chain_dbg_base) * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && gw_ >= 0 && gw_ < 4096) g_chain_dbg[gw_ * 8 + (i)] = (long long)__builtin_readcyclecounter(); }
 #else
 #define G4D_CSTAMP(i)
 #endif
@@ -476,6 +477,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs &s, int bid, int nb, 
     G4D_CSTAMP(4)
 }
 
+// (Round 4: a row-block loop around chain_body -- persistent workgroups, arguments re-read per iteration so that nothing is hoisted --
+//  measured SLOWER at 240 clouds per launch: SA level 3 scale 1 912 vs 873 us, the last FP level 846 vs 810, SA level 2's pair 746 vs 700, and
+//  the loop's codegen cost the single-iteration form 5-8 % as well.  Workgroup turnover is not what these launches wait for; the exposed
+//  latencies inside a row block are (scripts/dbg_chain_steady.py) -- sa_table.hip is the form that removes them.)
 template <int MODE, int T1, int T2, int T3, int T4, int MT>
 __global__ void __launch_bounds__(256) mlp_chain_kernel(const ChainArgs s) {
     __shared__ float xch[4 * 256];  // pooling partials of the 4 waves when a group spans waves (<= 256 channels)
@@ -517,6 +522,9 @@ static int chain_key(int nlayers, const int *Cout) {
 extern "C" int g4d_chain_debug_read(long long *host_out) {  // 8 x 4096 cycle stamps of the last launch
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g4d::g_chain_dbg), sizeof(long long) * 8 * 4096);
 }
+extern "C" int g4d_chain_debug_base(int first_block) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g4d::g_chain_dbg_base), &first_block, sizeof(int));
+}
 #endif
 
 extern "C" int g4d_mlp_chain_supported(int nlayers, const int *Cout) {
@@ -541,6 +549,12 @@ static int chain_launch_one(int mode, int key, int mt, const ChainArgs &s, hipSt
     else launch_chain<T1, T2, T3, T4, 1>(mode, s, st);              \
     break;
     switch (key) {
+#ifdef G4D_CHAIN_FEW   // development builds (-S listings): the instantiations of the cfg2 step only
+        case 8160000: G4D_CHAIN(8, 16, 0, 0)
+        case 4080000: G4D_CHAIN(4, 8, 0, 0)
+        case 16080800: G4D_CHAIN(16, 8, 8, 0)
+        default: G4D_CHAIN(8, 4, 2, 1)
+#else
         case 1010200: G4D_CHAIN(1, 1, 2, 0)
         case 2020400: G4D_CHAIN(2, 2, 4, 0)
         case 4040800: G4D_CHAIN(4, 4, 8, 0)
@@ -561,6 +575,7 @@ static int chain_launch_one(int mode, int key, int mt, const ChainArgs &s, hipSt
         case 4080000: G4D_CHAIN(4, 8, 0, 0)
         case 8160000: G4D_CHAIN(8, 16, 0, 0)
         default: G4D_CHAIN(8, 4, 2, 1)
+#endif
     }
 #undef G4D_CHAIN
     return check_launch("g4d_mlp_chain_f32");
@@ -763,6 +778,14 @@ extern "C" int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S
                                              const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool,
                                              float *out, int ldo, int col0, g4d_stream_t stream) {
     G4D_REQUIRE(table && Kt > 0, "g4d_mlp_chain_group_table_f32: null table");
+    if (xyz && new_xyz && idx && tab_wx && pre_scale && pre_shift && W && scale && shift && Kpad && Cout && relu && out && tab_ld >= Kt && tab_ld % 4 == 0 &&
+        (reinterpret_cast<size_t>(table) & 15) == 0 && P > 0 && N > 0) {
+        // large launches: the persistent, software-pipelined kernel (sa_table.hip; bit-identical results).  Inside a launch group it simply goes out
+        // on its own -- merging launches pays only while they are small.
+        const int rc = sa_table_try(rows, N, P, S, xyz, new_xyz, idx, table, tab_ld, Kt, tab_wx, pre_scale, pre_shift, nlayers, W, scale, shift, Kpad,
+                                    Cout, relu, pool, out, ldo, col0, reinterpret_cast<hipStream_t>(stream));
+        if (rc != -1) return rc;
+    }
     return chain_f32_impl(LOAD_GROUP, rows, Kt, nullptr, 0, N, P, S, 0, 1, xyz, new_xyz, nullptr, idx, 0, 0, 0, 0, nullptr, nullptr, nullptr,
                           nullptr, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, -1, nullptr, 0, pre_scale, pre_shift, nullptr, 0,
                           table, tab_ld, tab_wx, stream);

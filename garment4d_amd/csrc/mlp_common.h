@@ -66,6 +66,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // gemm_stream.hip: persistent row-streaming GEMM for tall DIRECT launches; returns false when the launch is not its kind
 bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc);
 
+// sa_table.hip: persistent, software-pipelined form of g4d_mlp_chain_group_table_f32 for large launches (same arguments); -1 = not its kind
+int sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld, int Kt,
+                 const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
+                 const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, hipStream_t st);
+
 template <int MODE>
 struct RowCtx {  // per-thread, per-row state reused across K chunks
     bool valid;

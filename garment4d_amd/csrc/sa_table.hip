@@ -1,0 +1,317 @@
+// Set-abstraction scale behind a pre-contracted first layer, PERSISTENT and software-pipelined (round 4): the large-launch form of
+// g4d_mlp_chain_group_table_f32 (QueryAndGroup + SharedMLP + max pool, pointnet2_modules.py:40-53 / pointnet2_utils.py:232-265; the
+// feature part of the first layer is the per-source-point table of fused.sa_level_table).
+//
+// Why: in-kernel cycle stamps in the MIDDLE of a 240-cloud launch of the register-chain kernel (scripts/dbg_chain_steady.py, SA level 2
+// scale 1: 384 MFMAs = 12.3k cycles of matrix pipe per 32-row wave) show a wave living 34k cycles: 8.6k until its row contexts exist
+// (kernel arguments -> neighbour index -> coordinates / table row: three dependent round trips), 2.6k until the rows have arrived, ~2k at
+// each layer seam and 4.8k in the epilogue, most of it the per-layer scale / shift vectors being fetched from L2 at the moment they are
+// needed.  With 2-3 such waves per SIMD the matrix pipe is 53 % busy.  A loop over row blocks alone does not help (measured: slower) --
+// what has to go is the exposed latency.  Here
+//   * a workgroup is resident for the whole launch; every per-layer constant (xyz weights, the loader's affine, scale / shift of both
+//     layers) and, for the 32- / 64-wide stacks, both weight matrices sit in LDS, loaded once;
+//   * a wave walks its row blocks with a two-level prefetch (as sa_xyz.hip): while block k is on the VALU / matrix pipe, the table rows
+//     and coordinates of block k + 1 are in flight and so are the indices of block k + 2;
+//   * a pooling group never spans waves: a wave takes whole neighbourhoods (for 64 samples: four 16-row blocks with a running maximum),
+//     so there is no barrier after the start-up copy; the pooled tiles leave through the four-tile swap reduction of sa_xyz.hip,
+//     64 channels per store.
+// Arithmetic and summation order are those of mlp_chain.hip's table loader and chained layers: results are bit-identical.
+#include <cstdlib>
+
+#include "mlp_common.h"
+
+namespace g4d {
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct SaTabArgs {
+    int rows, N, P;                      // rows = B * P * S grouped rows; N source points per cloud, P centroids per cloud
+    const float *xyz, *new_xyz;
+    const int *idx;
+    const float *tab;                    // (B * N, tab_ld): feature part of the first layer per source point
+    int tab_ld;
+    const float *wx, *ps, *pf;           // [3][C] xyz columns of the first layer (transposed); [C] its affine
+    const float *W2, *sc2, *sh2;         // fragment order [tile][k-step][64][4]
+    const float *W3, *sc3, *sh3;         // (T k-steps per channel tile: Kpad == C)
+    float *out;
+    int ldo, col0;
+};
+
+__device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, float v3) {   // sa_xyz.hip: lane 16 c + fi = max over the 16 rows of tile c
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+    const float m01 = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const float m23 = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(m01), __float_as_uint(m23), false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+
+constexpr int kRing = 4;   // weight fragments requested ahead of their MFMAs (LDS: ~130 cycles; L2: see kRingG)
+constexpr int kRingG = 6;
+
+// C: table / hidden width (layers C -> C -> 2C), S samples per neighbourhood, MT row tiles of 16 per block, WLDS: weights in LDS
+template <int C, int S, int MT, bool WLDS>
+__global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
+    constexpr int T = C / 16, T3 = 2 * T;
+    constexpr int R = 16 * MT;                       // rows per block
+    constexpr int G = S > R ? S / R : 1;             // blocks per neighbourhood (running maximum across them)
+    constexpr int GP = S < R ? R / S : 1;            // neighbourhoods per block
+    static_assert(S == 16 || S == 32 || S == 64, "16 / 32 / 64 samples");
+    static_assert(G * R == S || GP * S == R, "a block is a whole number of neighbourhoods or vice versa");
+    constexpr int NCONST = 11 * C;                   // wx 3C | ps C | pf C | sc2 C | sh2 C | sc3 2C | sh3 2C
+    constexpr int NW2 = C * C, NW3 = 2 * C * C;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_wx = smem, *s_ps = smem + 3 * C, *s_pf = s_ps + C, *s_sc2 = s_pf + C, *s_sh2 = s_sc2 + C, *s_sc3 = s_sh2 + C, *s_sh3 = s_sc3 + 2 * C;
+    float *s_w2 = smem + NCONST, *s_w3 = s_w2 + NW2;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * C; i += 256) s_wx[i] = a.wx[i];
+    for (int i = tid; i < C; i += 256) { s_ps[i] = a.ps[i]; s_pf[i] = a.pf[i]; s_sc2[i] = a.sc2[i]; s_sh2[i] = a.sh2[i]; }
+    for (int i = tid; i < 2 * C; i += 256) { s_sc3[i] = a.sc3[i]; s_sh3[i] = a.sh3[i]; }
+    if constexpr (WLDS) {   // fragment order, tiles packed back to back ([tile][T k-steps][64][4]: the host's layout has kst >= T k-steps per tile)
+        for (int i = tid; i < NW2 / 4; i += 256) {
+            const int frag = i >> 6, l = i & 63, ct = frag / T, ks = frag - ct * T;
+            reinterpret_cast<f32x4 *>(s_w2)[i] = *reinterpret_cast<const f32x4 *>(a.W2 + ((size_t)(ct * T + ks) * 64 + l) * 4);
+        }
+        for (int i = tid; i < NW3 / 4; i += 256) {
+            const int frag = i >> 6, l = i & 63, ct = frag / T, ks = frag - ct * T;
+            reinterpret_cast<f32x4 *>(s_w3)[i] = *reinterpret_cast<const f32x4 *>(a.W3 + ((size_t)(ct * T + ks) * 64 + l) * 4);
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fq = lane >> 4;
+    const int nblk = (a.rows + R - 1) / R;           // 16 MT-row blocks of the launch
+    const int nunit = (nblk + G - 1) / G;            // a wave's unit of work: G consecutive blocks = whole neighbourhoods
+    const int nwaves = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
+    const int nq = a.rows / S;
+
+    // block of iteration `it` of this wave (past the wave's last block: clamped -- read again, never used)
+    auto block_of = [&](int it) {
+        const int unit = wg + (it / G) * nwaves;
+        return min(unit * G + it % G, nblk - 1);
+    };
+    struct Rows { f32x4 raw[T][MT]; float px[MT], py[MT], pz[MT], cx[MT], cy[MT], cz[MT]; };
+    auto load_idx = [&](int blk, int (&v)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) v[mt] = a.idx[min(blk * R + mt * 16 + fi, a.rows - 1)];
+    };
+    auto load_rows = [&](int blk, const int (&v)[MT], Rows &rw) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int q = __builtin_amdgcn_readfirstlane(min((blk * R + mt * 16) / S, nq - 1));   // S >= 16: a tile belongs to one neighbourhood
+            const int b = q / a.P;
+            const size_t pt = (size_t)b * a.N + v[mt];
+            const float *tr = a.tab + pt * a.tab_ld + fq * 4;
+#pragma unroll
+            for (int ks = 0; ks < T; ++ks) rw.raw[ks][mt] = *reinterpret_cast<const f32x4u *>(tr + ks * 16);
+            const float *pp = a.xyz + pt * 3;
+            rw.px[mt] = pp[0]; rw.py[mt] = pp[1]; rw.pz[mt] = pp[2];
+            const float *cc = a.new_xyz + (size_t)q * 3;
+            rw.cx[mt] = cc[0]; rw.cy[mt] = cc[1]; rw.cz[mt] = cc[2];
+        }
+    };
+    // a weight fragment = 1 KB, lane l takes bytes [16 l, 16 l + 16).  From L2 (WLDS false): uniform base (SGPRs, bumped per fragment by scalar
+    // adds) + ONE lane offset register; written any other way the 192 fragment addresses of the 128-wide stack are loop invariants that the
+    // compiler computes once and keeps (512 registers + scratch)
+    unsigned lane16 = (unsigned)lane * 4u;   // (made opaque at the top of every iteration of the block loop, below)
+    // (the launcher guarantees T k-steps per channel tile in the host's layout, Kpad == C: fragment offsets are compile-time constants)
+    auto wfrag = [&](const float *gw, const float *sw, int ct, int ks) -> f32x4 {
+        if constexpr (WLDS) return *reinterpret_cast<const f32x4 *>(sw + ((ct * T + ks) * 64 + lane) * 4);
+        else return *reinterpret_cast<const f32x4 *>(gw + (ct * T + ks) * 256 + lane16);
+    };
+    constexpr int RD = WLDS ? kRing : kRingG;
+
+    const int my_units = wg < nunit ? (nunit - wg + nwaves - 1) / nwaves : 0;
+    const int iters = my_units * G;
+    if (iters == 0) return;
+    int ivn[MT];
+    Rows cur, nxt;
+    load_idx(block_of(0), ivn);
+    load_rows(block_of(0), ivn, cur);
+    load_idx(block_of(1), ivn);
+    float pm[T3];                                    // running maximum of the neighbourhood across its blocks (G > 1)
+    for (int it = 0; it < iters; ++it) {
+        const int blk = block_of(it);
+        if constexpr (!WLDS) asm volatile("" : "+v"(lane16));   // no hoisted fragment addresses
+        load_rows(block_of(it + 1), ivn, nxt);       // level 2 of the next block
+        load_idx(block_of(it + 2), ivn);             // level 1 of the one after
+        // ---- first layer: relu(affine(table row + Wx (x_j - q))), the arithmetic of mlp_chain.hip's table loader, one k-step at a time
+        //      in front of that k-step's share of layer 2 (transposed: A = weights, B = activations -- lane (fi, fq) ends with channels
+        //      16 ct + 4 fq + r of row fi).  Fragment (ks, ct): every accumulator sees k ascending, as in the chain kernel.
+        float gx[MT], gy[MT], gz[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { gx[mt] = cur.px[mt] - cur.cx[mt]; gy[mt] = cur.py[mt] - cur.cy[mt]; gz[mt] = cur.pz[mt] - cur.cz[mt]; }
+        f32x4 h2[T][MT];
+#pragma unroll
+        for (int ct = 0; ct < T; ++ct)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) h2[ct][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            constexpr int F = T * T;
+            f32x4 ring[RD];
+#pragma unroll
+            for (int f = 0; f < RD; ++f)
+                if (f < F) ring[f] = wfrag(a.W2, s_w2, f % T, f / T);
+#pragma unroll
+            for (int ks = 0; ks < T; ++ks) {
+                const int k0 = ks * 16 + fq * 4;
+                const f32x4 wx = *reinterpret_cast<const f32x4 *>(s_wx + k0), wy = *reinterpret_cast<const f32x4 *>(s_wx + C + k0),
+                            wz = *reinterpret_cast<const f32x4 *>(s_wx + 2 * C + k0);
+                const f32x4 ps = *reinterpret_cast<const f32x4 *>(s_ps + k0), pf = *reinterpret_cast<const f32x4 *>(s_pf + k0);
+                f32x4 h1[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = cur.raw[ks][mt][e] + __builtin_fmaf(wz[e], gz[mt], __builtin_fmaf(wy[e], gy[mt], wx[e] * gx[mt]));
+                        h1[mt][e] = fmaxf(__builtin_fmaf(v, ps[e], pf[e]), 0.f);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < T; ++ct) {
+                    const int f = ks * T + ct;
+                    const f32x4 w = ring[f % RD];
+                    if (f + RD < F) ring[f % RD] = wfrag(a.W2, s_w2, (f + RD) % T, (f + RD) / T);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) h2[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], h1[mt][e], h2[ct][mt], 0, 0, 0);
+                }
+            }
+        }
+        cur = nxt;
+        f32x4 ring3[RD];                             // layer 3's first fragments, requested before the seam
+        constexpr int F3 = T * T3;
+#pragma unroll
+        for (int f = 0; f < RD; ++f)
+            if (f < F3) ring3[f] = wfrag(a.W3, s_w3, f % T3, f / T3);
+#pragma unroll
+        for (int ct = 0; ct < T; ++ct) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(s_sc2 + ct * 16 + fq * 4), sh = *reinterpret_cast<const f32x4 *>(s_sh2 + ct * 16 + fq * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[ct][mt][r] = fmaxf(__builtin_fmaf(h2[ct][mt][r], sc[r], sh[r]), 0.f);
+        }
+        // ---- layer 3, normal orientation (A = activations, B = weights): lane (fi, fq) holds rows 4 fq + r of channel 16 ct + fi
+        f32x4 acc[T3][MT];
+#pragma unroll
+        for (int ct = 0; ct < T3; ++ct)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < F3; ++f) {
+            const int ks = f / T3, ct = f % T3;
+            const f32x4 w = ring3[f % RD];
+            if (f + RD < F3) ring3[f % RD] = wfrag(a.W3, s_w3, (f + RD) % T3, (f + RD) / T3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[ks][mt][e], w[e], acc[ct][mt], 0, 0, 0);
+        }
+        // ---- affine, max over the rows, ReLU once per output (max_r relu(y_r) = relu(max_r y_r) exactly)
+        float v[T3][MT];
+#pragma unroll
+        for (int ct = 0; ct < T3; ++ct) {
+            const float sc = s_sc3[ct * 16 + fi], sh = s_sh3[ct * 16 + fi];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float y0 = __builtin_fmaf(acc[ct][mt][0], sc, sh), y1 = __builtin_fmaf(acc[ct][mt][1], sc, sh),
+                            y2 = __builtin_fmaf(acc[ct][mt][2], sc, sh), y3 = __builtin_fmaf(acc[ct][mt][3], sc, sh);
+                v[ct][mt] = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+            }
+        }
+        if constexpr (GP > 1) {                      // S == 16, MT == 2: tile mt is neighbourhood 2 blk + mt
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int g = blk * GP + mt;
+#pragma unroll
+                for (int c4 = 0; c4 < T3 / 4; ++c4) {
+                    const float m = fmaxf(pool4_rows_max_t(v[c4 * 4][mt], v[c4 * 4 + 1][mt], v[c4 * 4 + 2][mt], v[c4 * 4 + 3][mt]), 0.f);
+                    if (g < nq) a.out[(size_t)g * a.ldo + a.col0 + c4 * 64 + lane] = m;
+                }
+            }
+        } else {
+            float x[T3];
+#pragma unroll
+            for (int ct = 0; ct < T3; ++ct) {
+                x[ct] = v[ct][0];
+#pragma unroll
+                for (int mt = 1; mt < MT; ++mt) x[ct] = fmaxf(x[ct], v[ct][mt]);
+            }
+            const int j = it % G;
+            if constexpr (G > 1) {
+#pragma unroll
+                for (int ct = 0; ct < T3; ++ct) pm[ct] = j == 0 ? x[ct] : fmaxf(pm[ct], x[ct]);
+            }
+            if (j == G - 1) {
+                const int g = blk / G;
+#pragma unroll
+                for (int c4 = 0; c4 < T3 / 4; ++c4) {
+                    float m;
+                    if constexpr (G > 1) m = pool4_rows_max_t(pm[c4 * 4], pm[c4 * 4 + 1], pm[c4 * 4 + 2], pm[c4 * 4 + 3]);
+                    else m = pool4_rows_max_t(x[c4 * 4], x[c4 * 4 + 1], x[c4 * 4 + 2], x[c4 * 4 + 3]);
+                    if (g < nq) a.out[(size_t)g * a.ldo + a.col0 + c4 * 64 + lane] = fmaxf(m, 0.f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace g4d
+
+using namespace g4d;
+
+template <int C, int S, int MT, bool WLDS>
+static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
+    const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0));
+    static unsigned long long attr = 0;
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sa_table_kernel<C, S, MT, WLDS>), lds, attr, "g4d_sa_table");
+        if (rc) return rc;
+    }
+    static const int resident = [] {
+        const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0));
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sa_table_kernel<C, S, MT, WLDS>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return per_cu * 256;
+        return per_cu * prop.multiProcessorCount;
+    }();
+    constexpr int R = 16 * MT, G = S > R ? S / R : 1;
+    const long long nunit = ((a.rows + R - 1) / R + G - 1) / G;
+    const long long want = (nunit + 3) / 4;
+    const unsigned grid = (unsigned)(want < resident ? want : resident);
+    hipLaunchKernelGGL((sa_table_kernel<C, S, MT, WLDS>), dim3(grid), dim3(256), lds, st, a);
+    return check_launch("g4d_sa_table");
+}
+
+// Takes the launch if it is one of the instantiated shapes and large enough to pipeline (several row blocks per resident wave);
+// returns -1 when it is not (the caller then runs the register-chain kernel), else the launch status.
+int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld,
+                      int Kt, const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W,
+                      const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
+                      int ldo, int col0, hipStream_t st) {
+    static const int on = getenv("G4D_SA_TABLE_PERSISTENT") ? atoi(getenv("G4D_SA_TABLE_PERSISTENT")) : 1;          // A/B switch
+    static const long long min_rows = getenv("G4D_SA_TABLE_MIN_ROWS") ? atoll(getenv("G4D_SA_TABLE_MIN_ROWS")) : 262144;   // ~4 blocks of 32 rows per resident wave
+    if (!on || pool != 1 || nlayers != 2 || rows < min_rows || rows >= (1ll << 31) - 64 || rows % S != 0) return -1;
+    if (!(Kt == 32 || Kt == 64 || Kt == 128) || Cout[0] != Kt || Cout[1] != 2 * Kt || !relu[0] || !relu[1] || Kpad[0] != Kt || Kpad[1] != Kt) return -1;
+    if ((long long)(rows / S / P) * N >= (1ll << 31)) return -1;
+    SaTabArgs a;
+    a.rows = (int)rows; a.N = N; a.P = P; a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.tab = table; a.tab_ld = tab_ld;
+    a.wx = tab_wx; a.ps = pre_scale; a.pf = pre_shift;
+    a.W2 = W[0]; a.sc2 = scale[0]; a.sh2 = shift[0];
+    a.W3 = W[1]; a.sc3 = scale[1]; a.sh3 = shift[1];
+    a.out = out; a.ldo = ldo; a.col0 = col0;
+    if (Kt == 32 && S == 16) return sa_table_launch<32, 16, 2, true>(a, st);
+    if (Kt == 32 && S == 32) return sa_table_launch<32, 32, 2, true>(a, st);
+    if (Kt == 64 && S == 32) return sa_table_launch<64, 32, 2, true>(a, st);
+    if (Kt == 64 && S == 64) return sa_table_launch<64, 64, 2, true>(a, st);
+    if (Kt == 64 && S == 16) return sa_table_launch<64, 16, 1, true>(a, st);
+    static const int wide = getenv("G4D_SA_TABLE_128") ? atoi(getenv("G4D_SA_TABLE_128")) : 1;   // A/B switch: the 128-wide stack (weights streamed from L2: 192 KB do not fit LDS)
+    if (wide && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, false>(a, st);
+    if (wide && Kt == 128 && S == 32) return sa_table_launch<128, 32, 1, false>(a, st);
+    return -1;
+}
