@@ -746,6 +746,11 @@ extern "C" int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, con
                                        const int *Cout, const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out,
                                        int tap_ld, g4d_stream_t stream) {
     G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift, "g4d_mlp_chain_table_f32: null pointer");
+    if (W && scale && shift && Kpad && Cout && relu && out) {   // large launches of the last-level stack: fp_table.hip (bit-identical)
+        const int rc = fp_table_try(rows, n, m, C2, table, dist2, nn_idx, nullptr, 0, pre_scale, pre_shift, in_tap, nlayers, W, scale, shift, Kpad, Cout, relu,
+                                    out, ldo, col0, tap_layer, tap_out, tap_ld, reinterpret_cast<hipStream_t>(stream));
+        if (rc != -1) return rc;
+    }
     return chain_f32_impl(LOAD_INTERP, rows, C2, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, C2, 0, table, nullptr, dist2,
                           nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, pre_scale, pre_shift,
                           in_tap, in_tap_ld, nullptr, 0, nullptr, stream);
@@ -762,6 +767,14 @@ extern "C" int g4d_mlp_chain_table_cells_f32(long long rows, int n, int m, int C
                                              const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo,
                                              int col0, int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
     G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift && unknown_grid, "g4d_mlp_chain_table_cells_f32: null pointer");
+    if (W && scale && shift && Kpad && Cout && relu && out && n > 0) {   // large launches of the last-level stack: fp_table.hip (bit-identical)
+        size_t off = 0, stride = 0;
+        grid_sorted_layout(n, &off, &stride);
+        const int rc = fp_table_try(rows, n, m, C2, table, dist2, nn_idx, reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride, pre_scale,
+                                    pre_shift, in_tap, nlayers, W, scale, shift, Kpad, Cout, relu, out, ldo, col0, tap_layer, tap_out, tap_ld,
+                                    reinterpret_cast<hipStream_t>(stream));
+        if (rc != -1) return rc;
+    }
     return chain_f32_impl(LOAD_INTERP, rows, C2, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, C2, 0, table, nullptr, dist2,
                           nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, pre_scale, pre_shift,
                           in_tap, in_tap_ld, nullptr, 0, nullptr, stream, unknown_grid);

@@ -66,6 +66,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // gemm_stream.hip: persistent row-streaming GEMM for tall DIRECT launches; returns false when the launch is not its kind
 bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc);
 
+// fp_table.hip: persistent, software-pipelined form of g4d_mlp_chain_table(_cells)_f32 for the 128 -> 64 -> 32 -> <= 16 stack; -1 = not its kind
+int fp_table_try(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx, const void *perm_rec,
+                 size_t perm_stride, const float *pre_scale, const float *pre_shift, float *in_tap, int nlayers, const float *const *W,
+                 const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo,
+                 int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
+
 // sa_table.hip: persistent, software-pipelined form of g4d_mlp_chain_group_table_f32 for large launches (same arguments); -1 = not its kind
 int sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld, int Kt,
                  const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
