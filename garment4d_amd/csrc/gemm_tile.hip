@@ -1,0 +1,137 @@
+// Y = act((X . W^T) * scale + shift) for TALL direct launches with a deep contraction (the wide feature-propagation level of a
+// coalesced call: 61440 rows x [576 -> 512 -> 256]; the per-source-point tables of the SA / FP levels) -- pytorch_utils.py:5-32 as one
+// GEMM per layer.  Round 4: mlp.hip's linear_kernel tiles 64 rows x 64 channels; every 32-deep k chunk then moves 16 KB through L2
+// for 262 kFLOP (the A rows are re-read by every 64-channel column block, W by every row block: 9 TB/s of L2 traffic at the rate the
+// matrix pipe could run) and every wave re-reads the whole A tile from LDS (5 ds_read_b128 per 16 MFMAs): 60 % of the fp32 MFMA peak at
+// 240 clouds per call.  Here the block tile is 128 x 128 (half the L2 traffic per flop), a wave owns 64 x 64 of it (16 accumulator tiles:
+// 8 ds_read_b128 per 64 MFMAs), and workgroups that share a row block run next to each other on ONE XCD (its L2 serves the A rows to all
+// column blocks).  Operand order, k order and epilogue are linear_kernel's: results are bit-identical.
+#include <cstdlib>
+
+#include "mlp_common.h"
+
+namespace g4d {
+
+namespace {
+constexpr int TM = 128, TN = 128, TK = 32, TLD = TK + 4;   // LDS row stride 36 floats: ds_read_b128 fragment reads spread over all banks
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, int nrow_blk, int ncol_blk, int cpad) {
+    extern __shared__ __attribute__((aligned(16))) float g_smem[];
+    float *sA = g_smem;                         // [2][TM * TLD]
+    float *sB = g_smem + 2 * TM * TLD;          // [2][TN * TLD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // workgroup -> (row block, column block): blocks are dispatched round-robin over the 8 XCDs; XCD x takes row blocks x, x + 8, ... and
+    // runs all column blocks of a row block back to back
+    int rb, cb;
+    {
+        const int b = blockIdx.x, x = b & 7, slot = b >> 3;
+        rb = (slot / ncol_blk) * 8 + x;
+        cb = slot % ncol_blk;
+        if (rb >= nrow_blk) return;
+    }
+    const int row0 = rb * TM, n0 = cb * TN;
+    // staging map: thread -> rows lr + 32 p (p = 0..3), 4 consecutive k at lk
+    const int lr = t >> 3, lk = (t & 7) * 4;
+    const float *xrow[4], *wrow[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        xrow[p] = a.X + (size_t)min(row0 + lr + 32 * p, a.rows - 1) * a.ldx + lk;     // rows past the end: clamped, never stored
+        wrow[p] = a.W + (size_t)min(n0 + lr + 32 * p, cpad - 1) * a.Kpad + lk;        // channels past the padded width: clamped, never stored
+    }
+    // K and ldx are multiples of 4 and X is 16-byte aligned (launcher): a lane's four columns are all inside the row or all past its end.
+    // Branch-free on purpose: a load inside a conditional block makes the number of loads in flight unknown at the join and the compiler
+    // then waits for the prefetch of the NEXT chunk (vmcnt(0)) in front of this chunk's MFMAs.
+    auto load_x = [&](int p, int k) -> f32x4 {
+        const bool in = k + lk < a.K;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow[p] + (in ? k : 0));
+        return in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunk = a.Kpad / TK;
+    f32x4 ra[4], rb4[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { ra[p] = load_x(p, 0); rb4[p] = *reinterpret_cast<const f32x4 *>(wrow[p]); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<f32x4 *>(&sA[(lr + 32 * p) * TLD + lk]) = ra[p];
+        *reinterpret_cast<f32x4 *>(&sB[(lr + 32 * p) * TLD + lk]) = rb4[p];
+    }
+    __syncthreads();
+    const int fi = lane & 15, fq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;    // the wave's 64 x 64 quadrant
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nchunk;
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { ra[p] = load_x(p, (c + 1) * TK); rb4[p] = *reinterpret_cast<const f32x4 *>(wrow[p] + (c + 1) * TK); }
+        }
+        const float *cA = sA + cur * TM * TLD + (wr * 64 + fi) * TLD + fq * 4;
+        const float *cB = sB + cur * TN * TLD + (wc * 64 + fi) * TLD + fq * 4;
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 16) {
+            f32x4 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { af[i] = *reinterpret_cast<const f32x4 *>(cA + i * 16 * TLD + kk); bf[i] = *reinterpret_cast<const f32x4 *>(cB + i * 16 * TLD + kk); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<f32x4 *>(&sA[nxt * TM * TLD + (lr + 32 * p) * TLD + lk]) = ra[p];
+                *reinterpret_cast<f32x4 *>(&sB[nxt * TN * TLD + (lr + 32 * p) * TLD + lk]) = rb4[p];
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue.  C/D layout of the 16x16 MFMA: column (channel) = lane & 15, rows = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = n0 + wc * 64 + j * 16 + fi;
+        const int chc = min(ch, cpad - 1);
+        const float sc = a.scale[chc], sh = a.shift[chc];
+        const bool ch_ok = ch < a.Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = __builtin_fmaf(acc[i][j][r], sc, sh);
+                if (a.relu) y = fmaxf(y, 0.f);
+                const int row = row0 + wr * 64 + i * 16 + fq * 4 + r;
+                if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = y;
+            }
+    }
+}
+
+// Used by launch_linear (mlp.hip) for DIRECT launches without pooling, after gemm_stream_try: true when the launch was taken.
+// Measured at 61440 rows (scripts/time_gemm.py; linear_kernel / this kernel / torch.mm = hipBLASLt, TFLOP/s): 576 -> 512: 85 / 91 / 98;
+// 512 -> 256: 84 / 88 / 114; 256 -> 256: 82 / 82 / 106; 192 -> 192: 78 / 58 / 97 (a half-empty second column block) -- taken only where it wins.
+bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
+    static const int enabled = [] { const char *e = getenv("G4D_GEMM_TILE"); return e ? atoi(e) : 1; }();
+    static const long long min_rows = [] { const char *e = getenv("G4D_GEMM_TILE_MIN_ROWS"); return e ? atoll(e) : 32768ll; }();
+    if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < 256 || a.Cout < 256 || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
+    const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
+    static unsigned long long attr = 0;
+    *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_tile_kernel), lds, attr, "g4d_linear_f32(tile)");
+    if (*rc) return true;
+    const int cpad = (a.Cout + 63) / 64 * 64;   // the packed weight / scale / shift are padded to 64 channels
+    const int nrow = (a.rows + TM - 1) / TM, ncol = (a.Cout + TN - 1) / TN;
+    const long long blocks = (long long)((nrow + 7) / 8) * 8 * ncol;   // XCD-major numbering: row blocks rounded up to a multiple of 8
+    if (blocks >= (1ll << 31)) return false;
+    hipLaunchKernelGGL(gemm_tile_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
+    *rc = check_launch("g4d_linear_f32(tile)");
+    return true;
+}
+
+}  // namespace g4d

@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(256) transpose_kernel(int R, int Cc, const flo
 static int launch_linear(int mode, const LinearArgs &a, hipStream_t s) {
     if (mode == LOAD_DIRECT) {
         int rc = G4D_OK;
-        if (gemm_stream_try(a, s, &rc)) return rc;   // tall, un-pooled, Cout a multiple of 128: the row-streaming GEMM
+        if (gemm_stream_try(a, s, &rc)) return rc;   // tall, un-pooled, Cout a multiple of 128, K <= 128: the row-streaming GEMM
+        if (gemm_tile_try(a, s, &rc)) return rc;     // tall, un-pooled, deep: 128 x 128 tiles (gemm_tile.hip)
     }
     const int nb = (a.Cout + BN - 1) / BN;
     // 32-row tiles when 64-row tiles would not even give two workgroups per CU (and no fused pooling is asked for)

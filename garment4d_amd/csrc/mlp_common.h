@@ -65,6 +65,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // gemm_stream.hip: persistent row-streaming GEMM for tall DIRECT launches; returns false when the launch is not its kind
 bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc);
+// gemm_tile.hip: 128 x 128-tile GEMM for tall DIRECT launches with a deep contraction; same contract
+bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc);
 
 // fp_table.hip: persistent, software-pipelined form of g4d_mlp_chain_table(_cells)_f32 for the 128 -> 64 -> 32 -> <= 16 stack; -1 = not its kind
 int fp_table_try(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx, const void *perm_rec,
