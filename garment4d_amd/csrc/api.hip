@@ -35,6 +35,45 @@ int distance_contraction() {
 }
 }  // namespace g4d
 
+// ---- run-time tuning switches of the large-launch kernels (A/B experiments and tests that must drive a small shape through a kernel that would
+// otherwise only see large ones).  A value set here wins over the environment variable of the same name in upper case with a G4D_ prefix
+// (G4D_SA_TABLE_MIN_ROWS, ...), which wins over the built-in default.  Process-wide, like the distance contraction mode.
+namespace g4d {
+namespace {
+struct Tune { const char *key; long long value; int state; };   // state: 0 unset, 1 from the environment / default (cached), 2 set by g4d_tuning_set
+Tune g_tune[] = {{"sa_table_persistent", 0, 0}, {"sa_table_min_rows", 0, 0}, {"sa_table_128", 0, 0}, {"fp_table_persistent", 0, 0},
+                 {"fp_table_min_rows", 0, 0}, {"gemm_tile", 0, 0}, {"gemm_tile_min_rows", 0, 0}};
+}
+long long tuning(const char *key, long long dflt) {
+    for (Tune &t : g_tune) {
+        if (strcmp(t.key, key)) continue;
+        if (__atomic_load_n(&t.state, __ATOMIC_ACQUIRE) == 0) {
+            char env[64] = "G4D_";
+            size_t n = 4;
+            for (const char *c = key; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+            env[n] = 0;
+            const char *e = getenv(env);
+            t.value = e && *e ? atoll(e) : dflt;
+            __atomic_store_n(&t.state, 1, __ATOMIC_RELEASE);
+        }
+        return t.value;
+    }
+    return dflt;
+}
+}  // namespace g4d
+
+extern "C" int g4d_tuning_set(const char *key, long long value) {
+    if (key)
+        for (g4d::Tune &t : g4d::g_tune)
+            if (!strcmp(t.key, key)) {
+                t.value = value;
+                __atomic_store_n(&t.state, 2, __ATOMIC_RELEASE);
+                return G4D_OK;
+            }
+    g4d::set_error("g4d_tuning_set: unknown key '%s'", key ? key : "(null)");
+    return G4D_EINVAL;
+}
+
 extern "C" int g4d_version(void) { return 200; /* 0.2.0: round 2 (g4d_ball_query_boxes_f32 takes 16-point sub-block bounds; new entry points, see include/g4d.h) */ }
 extern "C" const char *g4d_last_error(void) { return g4d::g_err; }
 
@@ -47,4 +86,43 @@ extern "C" int g4d_set_distance_contraction(int mode) {
     }
     __atomic_store_n(&g4d::g_contract, mode, __ATOMIC_RELAXED);
     return prev;
+}
+
+// ---- g4d_copy_segments_f32: up to 4 device-to-device copies in ONE launch (the executor's per-step input hand-over: cloud, betas, pose --
+// three runtime copy kernels cost a coalesced call of 30 steps 90 launches, ~0.5 ms of its 6)
+namespace g4d {
+struct CopySegs { float *dst[4]; const float *src[4]; long long n[4]; long long first_block[5]; };
+__global__ void __launch_bounds__(256) copy_segments_kernel(const CopySegs c, int nseg) {
+    int s = 0;
+    while (s + 1 < nseg && (long long)blockIdx.x >= c.first_block[s + 1]) ++s;
+    const long long i0 = ((long long)blockIdx.x - c.first_block[s]) * 1024 + threadIdx.x * 4;
+    float *d = c.dst[s];
+    const float *p = c.src[s];
+    const long long n = c.n[s];
+    if (i0 + 3 < n && ((reinterpret_cast<size_t>(d) | reinterpret_cast<size_t>(p)) & 15) == 0) {
+        *reinterpret_cast<float4 *>(d + i0) = *reinterpret_cast<const float4 *>(p + i0);
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (i0 + e < n) d[i0 + e] = p[i0 + e];
+    }
+}
+}  // namespace g4d
+
+extern "C" int g4d_copy_segments_f32(int nseg, float *const *dst, const float *const *src, const long long *nfloats, g4d_stream_t stream) {
+    G4D_REQUIRE(nseg >= 0 && nseg <= 4 && (nseg == 0 || (dst && src && nfloats)), "g4d_copy_segments_f32: 0..4 segments");
+    g4d::CopySegs c = {};
+    long long blocks = 0;
+    int k = 0;
+    for (int i = 0; i < nseg; ++i) {
+        G4D_REQUIRE(nfloats[i] >= 0 && (nfloats[i] == 0 || (dst[i] && src[i])), "g4d_copy_segments_f32: bad segment %d", i);
+        if (nfloats[i] == 0) continue;
+        c.dst[k] = dst[i]; c.src[k] = src[i]; c.n[k] = nfloats[i]; c.first_block[k] = blocks;
+        blocks += (nfloats[i] + 1023) / 1024;
+        ++k;
+    }
+    if (k == 0) return G4D_OK;
+    c.first_block[k] = blocks;
+    G4D_REQUIRE(blocks < (1ll << 31), "g4d_copy_segments_f32: too large");
+    hipLaunchKernelGGL(g4d::copy_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c, k);
+    return g4d::check_launch("g4d_copy_segments_f32");
 }

@@ -200,8 +200,8 @@ int g4d::fp_table_try(long long rows, int n, int m, int C2, const float *table, 
                       size_t perm_stride, const float *pre_scale, const float *pre_shift, float *in_tap, int nlayers, const float *const *W,
                       const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo,
                       int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st) {
-    static const int on = getenv("G4D_FP_TABLE_PERSISTENT") ? atoi(getenv("G4D_FP_TABLE_PERSISTENT")) : 1;          // A/B switch
-    static const long long min_rows = getenv("G4D_FP_TABLE_MIN_ROWS") ? atoll(getenv("G4D_FP_TABLE_MIN_ROWS")) : 262144;
+    const int on = (int)tuning("fp_table_persistent", 1);          // A/B switch
+    const long long min_rows = tuning("fp_table_min_rows", 262144);
     if (!on || rows < min_rows || rows >= (1ll << 31) - 64 || C2 != kC1 || nlayers != 3 || in_tap || col0 != 0 || tap_layer != 0 || !tap_out) return -1;
     if (Cout[0] != kC2 || Cout[1] != kC3 || Cout[2] > kC4 || Cout[2] < 1 || Kpad[0] != kC1 || Kpad[1] != kC2 || Kpad[2] != kC3 || !relu[0] || !relu[1]) return -1;
     if (n < 16 || m <= 0 || rows % n != 0 || (rows / n) * (long long)m * kC1 >= (1ll << 32) || tap_ld % 4 != 0 || (reinterpret_cast<size_t>(tap_out) & 15) != 0 ||

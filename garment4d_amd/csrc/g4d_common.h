@@ -61,6 +61,7 @@ void grid_sorted_layout(int n, size_t *offset_bytes, size_t *stride_bytes);   //
 size_t grid_bytes_per_cloud(int n);
 size_t grid_records_offset(int n);  // byte offset of the float4 records inside a cloud's workspace
 
+long long tuning(const char *key, long long dflt);   // api.hip: run-time switch (g4d_tuning_set) > environment G4D_<KEY> > default
 int distance_contraction();  // api.hip: the process-wide G4D_CONTRACT_* mode (0, 1 or 2)
 inline int knn_shape(int mode) { return mode == 0 ? 0 : 2; }  // the accumulate loop contracts to the chain shape
 

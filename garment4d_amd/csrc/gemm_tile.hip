@@ -118,8 +118,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
 // Measured at 61440 rows (scripts/time_gemm.py; linear_kernel / this kernel / torch.mm = hipBLASLt, TFLOP/s): 576 -> 512: 85 / 91 / 98;
 // 512 -> 256: 84 / 88 / 114; 256 -> 256: 82 / 82 / 106; 192 -> 192: 78 / 58 / 97 (a half-empty second column block) -- taken only where it wins.
 bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
-    static const int enabled = [] { const char *e = getenv("G4D_GEMM_TILE"); return e ? atoi(e) : 1; }();
-    static const long long min_rows = [] { const char *e = getenv("G4D_GEMM_TILE_MIN_ROWS"); return e ? atoll(e) : 32768ll; }();
+    const int enabled = (int)tuning("gemm_tile", 1);
+    const long long min_rows = tuning("gemm_tile_min_rows", 32768);
     if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < 256 || a.Cout < 256 || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
     const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
     static unsigned long long attr = 0;

@@ -294,8 +294,8 @@ int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, con
                       int Kt, const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W,
                       const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
                       int ldo, int col0, hipStream_t st) {
-    static const int on = getenv("G4D_SA_TABLE_PERSISTENT") ? atoi(getenv("G4D_SA_TABLE_PERSISTENT")) : 1;          // A/B switch
-    static const long long min_rows = getenv("G4D_SA_TABLE_MIN_ROWS") ? atoll(getenv("G4D_SA_TABLE_MIN_ROWS")) : 262144;   // ~4 blocks of 32 rows per resident wave
+    const int on = (int)tuning("sa_table_persistent", 1);                 // A/B switch
+    const long long min_rows = tuning("sa_table_min_rows", 262144);       // ~4 blocks of 32 rows per resident wave
     if (!on || pool != 1 || nlayers != 2 || rows < min_rows || rows >= (1ll << 31) - 64 || rows % S != 0) return -1;
     if (!(Kt == 32 || Kt == 64 || Kt == 128) || Cout[0] != Kt || Cout[1] != 2 * Kt || !relu[0] || !relu[1] || Kpad[0] != Kt || Kpad[1] != Kt) return -1;
     if ((long long)(rows / S / P) * N >= (1ll << 31)) return -1;
@@ -310,7 +310,7 @@ int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, con
     if (Kt == 64 && S == 32) return sa_table_launch<64, 32, 2, true>(a, st);
     if (Kt == 64 && S == 64) return sa_table_launch<64, 64, 2, true>(a, st);
     if (Kt == 64 && S == 16) return sa_table_launch<64, 16, 1, true>(a, st);
-    static const int wide = getenv("G4D_SA_TABLE_128") ? atoi(getenv("G4D_SA_TABLE_128")) : 1;   // A/B switch: the 128-wide stack (weights streamed from L2: 192 KB do not fit LDS)
+    const int wide = (int)tuning("sa_table_128", 1);   // A/B switch: the 128-wide stack (weights streamed from L2: 192 KB do not fit LDS)
     if (wide && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, false>(a, st);
     if (wide && Kt == 128 && S == 32) return sa_table_launch<128, 32, 1, false>(a, st);
     return -1;

@@ -24,8 +24,11 @@ hipGraph + streams: the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
 the calls serialise; set GPU_MAX_HW_QUEUES >= `streams` in the environment BEFORE the runtime initialises (i.e. before `import
 torch`), as bench.py does.  `streams` <= 4 needs nothing.
 """
+import ctypes
+
 import torch
 
+from . import _lib
 from . import lbs as G
 
 
@@ -132,10 +135,18 @@ class StepPipeline:
         if not inputs_ready:
             s.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s.stream):
-            s.cloud[sl].copy_(cloud, non_blocking=True)
-            if self.smpl is not None:
-                s.betas[sl].copy_(betas, non_blocking=True)
-                s.pose[sl].copy_(pose.reshape(s.pose[sl].shape), non_blocking=True)
+            # one launch for the step's inputs (g4d_copy_segments_f32): three runtime copies per step are 90 launches per 30-step call
+            pairs = [(s.cloud[sl], cloud)] if self.smpl is None else [(s.cloud[sl], cloud), (s.betas[sl], betas), (s.pose[sl], pose)]
+            ok = all(src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.numel() == dst.numel() for dst, src in pairs)
+            if ok:
+                n = len(pairs)
+                PA, LA = ctypes.c_void_p * n, ctypes.c_longlong * n
+                _lib.call("g4d_copy_segments_f32", n, ctypes.cast(PA(*[d.data_ptr() for d, _ in pairs]), ctypes.c_void_p),
+                          ctypes.cast(PA(*[x.data_ptr() for _, x in pairs]), ctypes.c_void_p),
+                          ctypes.cast(LA(*[d.numel() for d, _ in pairs]), ctypes.c_void_p), _lib.stream_ptr())
+            else:   # host tensors, other dtypes / strides: the runtime's copies
+                for dst, src in pairs:
+                    dst.copy_(src.reshape(dst.shape), non_blocking=True)
         fut = StepFuture(self, s, s.fill, s.gen)
         s.fill += 1
         if s.fill == self.k:

@@ -301,6 +301,16 @@ int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const float *know
 /* batched matrix transpose (b, r, c) -> (b, c, r): channel-major <-> point-major at the API boundary. */
 int g4d_transpose_f32(int b, int r, int c, const float *in, float *out, g4d_stream_t stream);
 
+/* Run-time tuning switch of the large-launch kernels: keys "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "fp_table_persistent",
+ * "fp_table_min_rows", "gemm_tile", "gemm_tile_min_rows" (each also an environment variable G4D_<KEY IN UPPER CASE>, read on first use).
+ * Process-wide; for A/B measurements and tests -- every setting computes the same bits. */
+int g4d_tuning_set(const char *key, long long value);
+
+/* Up to 4 contiguous device-to-device copies (dst[i][0 .. nfloats[i]) = src[i][...]) in one launch -- the executor of
+ * garment4d_amd/pipeline.py hands a step's cloud, betas and pose over with it (the reference moves them with three .cuda() copies per
+ * batch, train_temporal.py:239-254).  dst / src / nfloats are HOST arrays of nseg entries. */
+int g4d_copy_segments_f32(int nseg, float *const *dst, const float *const *src, const long long *nfloats, g4d_stream_t stream);
+
 /* ---- SMPL linear blend skinning (garment4d_amd/csrc/lbs.hip; reference: smplx/smplx/lbs.py) ------------- */
 
 /* v_shaped (B,V,3) = v_template (V,3) + shapedirs (V,3,NB) . betas (B,NB)       lbs.py:205, blend_shapes :288-309.

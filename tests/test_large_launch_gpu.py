@@ -1,0 +1,133 @@
+"""The large-launch kernels of round 4 -- sa_table.hip, fp_table.hip, gemm_tile.hip, the frame-group loop of lbs_one_kernel and
+g4d_copy_segments_f32 -- take a launch only from a row count on where pipelining pays (a coalesced call of the executor).  Each must
+compute the SAME BITS as the kernel it replaces there, so these tests switch it on and off on shapes chosen for their edges (row counts
+that are not a multiple of the block, neighbourhood windows 16 / 32 / 64, clouds whose size is not a multiple of 16 so that tiles straddle
+two clouds, column blocks cut by the output width) by lowering its row threshold through g4d_tuning_set, and compare with torch.equal."""
+import contextlib
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from garment4d_amd import _lib, fused, lbs as L, pointnet2_modules as PM, pytorch_utils as pt_utils, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def tuning(**kv):
+    """g4d_tuning_set for the duration of the block; restores the defaults of this file's keys afterwards."""
+    defaults = {"sa_table_persistent": 1, "sa_table_min_rows": 262144, "sa_table_128": 1, "fp_table_persistent": 1, "fp_table_min_rows": 262144,
+                "gemm_tile": 1, "gemm_tile_min_rows": 32768}
+    try:
+        for k, v in kv.items():
+            _lib.call("g4d_tuning_set", k.encode(), int(v))
+        yield
+    finally:
+        for k in kv:
+            _lib.call("g4d_tuning_set", k.encode(), defaults[k])
+
+
+def _seed_bn(mod):
+    for m in mod.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    return mod.cuda().eval()
+
+
+@pytest.mark.parametrize("B,N,P,C,mlps,nsamples", [
+    (3, 1024, 255, 96, [[96, 32, 32, 64], [96, 64, 64, 128]], [16, 32]),     # SA level 2's widths; 255 centroids: an odd number of 16-row neighbourhoods
+    (5, 256, 61, 192, [[192, 64, 64, 128], [192, 128, 128, 256]], [32, 64]),  # SA level 3's widths: 64 samples = four blocks with a running maximum
+    (2, 500, 77, 40, [[40, 64, 64, 128], [40, 32, 32, 64]], [64, 32]),        # 64-wide over 64 samples, 32-wide over 32
+    (1, 300, 19, 24, [[24, 64, 64, 128], [24, 128, 128, 256]], [16, 32]),     # 64-wide over 16 samples (one tile per block), 128-wide over 32
+])
+def test_sa_table_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, mlps, nsamples):
+    torch.manual_seed(B * 10 + C)
+    xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=N)).cuda()
+    fpm = torch.randn(B, N, C, device="cuda")
+    sa = _seed_bn(PM.PointnetSAModuleMSG(npoint=P, radii=[0.2 + 0.1 * i for i in range(len(mlps))], nsamples=nsamples, mlps=[list(m) for m in mlps]))
+    outs = {}
+    with torch.no_grad():
+        for on in (0, 1):
+            with tuning(sa_table_persistent=on, sa_table_min_rows=0):
+                outs[on] = fused.sa_forward(sa, xyz, fpm)[1]
+    assert torch.equal(outs[0], outs[1])
+    want = sa(xyz, fused.to_channel_major(fpm))[1]
+    np.testing.assert_allclose(fused.to_channel_major(outs[1]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cells", [True, False])
+@pytest.mark.parametrize("B,n,m", [(2, 8192, 1024), (3, 5000, 300), (1, 4100, 257)])
+def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, monkeypatch):
+    """Last FP level + head (128 -> [128] -> 64 -> 32 -> 7) in place and over cell-ordered rows; n = 5000 / 4100: 16-row tiles straddle clouds."""
+    torch.manual_seed(n)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 128, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    head = _seed_bn(torch.nn.Sequential(pt_utils.Conv1d(64, 32, bn=True), torch.nn.Dropout(), pt_utils.Conv1d(32, 7, activation=None)))
+    grid = fused.build_ball_grid(unknown, 0.1)
+    monkeypatch.setattr(fused, "FP_CELLS", cells)
+    outs = {}
+    with torch.no_grad():
+        for on in (0, 1):
+            with tuning(fp_table_persistent=on, fp_table_min_rows=0):
+                outs[on] = fused.fp_forward(fp, unknown, known, None, kf, head=head, unknown_grid=grid)
+    assert torch.equal(outs[0][0], outs[1][0]), "FP features differ"
+    assert torch.equal(outs[0][1], outs[1][1]), "head outputs differ"
+    feats = fp(unknown, known, None, fused.to_channel_major(kf))
+    np.testing.assert_allclose(fused.to_channel_major(outs[1][0]).cpu().numpy(), feats.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,K,Cout,relu,col0,extra", [(4096, 576, 512, True, 0, 0), (5001, 512, 256, True, 0, 0), (4100, 256, 384, False, 3, 9), (3000, 260, 256, True, 0, 0)])
+def test_tile_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra):
+    """csrc/gemm_tile.hip against linear_kernel: the same k order, so EQUAL; row counts that are not a multiple of 128, an output window inside
+    a wider matrix, K = 260 (Kpad = 288: the last chunk is mostly padding)."""
+    g = torch.Generator().manual_seed(rows % 97)
+    x = torch.randn(rows, K, generator=g).cuda()
+    W = (torch.randn(Cout, K, generator=g) / K ** 0.5).cuda()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    layer = fused.PackedLayer(W, sc, sh, relu=relu)
+    ldo = col0 + Cout + extra
+    outs = [torch.full((rows, ldo), 7.0, device="cuda") for _ in range(2)]
+    for on in (0, 1):
+        with tuning(gemm_tile=on, gemm_tile_min_rows=0):
+            fused.linear(x, layer, out=outs[on], col0=col0)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[1][:, :col0] == 7.0).all() and (outs[1][:, col0 + Cout:] == 7.0).all()
+    ref = (x.double() @ W.double().T) * sc.double() + sh.double()
+    ref = torch.relu(ref) if relu else ref
+    torch.testing.assert_close(outs[1][:, col0:col0 + Cout].double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 8, 9, 37, 240])
+def test_lbs_one_launch_does_not_depend_on_the_batch(B, monkeypatch):
+    """lbs_one_kernel walks the 8-frame groups of any batch; a frame's vertices must not depend on which batch it arrives in (the executor
+    coalesces steps) nor on how the groups are spread over workgroups."""
+    P = {k: torch.from_numpy(v).cuda() for k, v in syn.smpl_like_params(seed=3).items()}
+    betas, pose = (torch.from_numpy(a).cuda() for a in syn.smpl_like_pose(B, seed=B))
+    args = (P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"])
+    v, j = L.lbs(betas, pose, *args)
+    for f in sorted({0, B // 2, B - 1}):
+        v1, j1 = L.lbs(betas[f:f + 1].contiguous(), pose[f:f + 1].contiguous(), *args)
+        assert torch.equal(v[f:f + 1], v1) and torch.equal(j[f:f + 1], j1), f"frame {f} of {B}"
+    monkeypatch.setattr(L, "ONE_LAUNCH_MAX_B", 0)     # the three-launch route partitions the blend sum differently: close, not equal
+    v3, j3 = L.lbs(betas, pose, *args)
+    torch.testing.assert_close(v, v3, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(j, j3, rtol=1e-5, atol=1e-5)
+
+
+def test_copy_segments():
+    g = torch.Generator().manual_seed(0)
+    srcs = [torch.randn(n, generator=g).cuda() for n in (8 * 8192 * 3, 80, 576, 1025)]
+    dsts = [torch.full((n.numel() + 5,), -1.0, device="cuda") for n in srcs]
+    PA, LA = ctypes.c_void_p * 4, ctypes.c_longlong * 4
+    _lib.call("g4d_copy_segments_f32", 4, ctypes.cast(PA(*[d.data_ptr() + 4 for d in dsts]), ctypes.c_void_p),      # destinations 4 bytes off a 16-byte boundary
+              ctypes.cast(PA(*[s.data_ptr() for s in srcs]), ctypes.c_void_p), ctypes.cast(LA(*[s.numel() for s in srcs]), ctypes.c_void_p), _lib.stream_ptr())
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d[1:1 + s.numel()], s) and float(d[0]) == -1.0 and (d[1 + s.numel():] == -1.0).all()
+    with pytest.raises(_lib.G4DError):
+        _lib.call("g4d_copy_segments_f32", 5, 0, 0, 0, _lib.stream_ptr())
+    with pytest.raises(_lib.G4DError):
+        _lib.call("g4d_tuning_set", b"no_such_key", 1)
