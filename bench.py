@@ -128,133 +128,142 @@ def pmc_sq(kernel_substr):
     return None
 
 
-def kernel_rooflines(model, cloud, precision="fp32"):
-    """Instrumented eager pass: HIP events (on the stream the kernels are launched on = torch's current
-    stream) around the two heaviest kernels.  Algorithmic bytes/flops per launch: DESIGN.md §Kernels."""
-    from garment4d_amd import fused
-    res = {}
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # fp32 VALU lane-operations per second (un-packed): 39.3e12
 
-    def timed(fn, iters=10, reps=6):
-        """seconds per launch: `reps` launches back to back between each event pair -- with one launch per pair the interval also
-        holds the host's enqueue latency of that launch (4-6 us through ctypes), which rocprofv3's kernel durations do not"""
-        fn()
-        torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for a, b in evs:
-            a.record()
-            for _ in range(reps):
-                fn()
-            b.record()
-        torch.cuda.synchronize()
-        return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3 / reps  # seconds
 
-    # 1. FPS level 1 (8192 -> 1024): the dominant kernel by summed GPU time.  One launch = B clouds, one workgroup per cloud,
-    #    1023 strictly dependent rounds: LATENCY-bound (SURVEY 8d regime 1).  Algorithmic bytes = xyz in + idx out (the fused
-    #    path passes temp=NULL: no scratch traffic); the HBM fraction is reported because the contract asks for it -- the
-    #    meaningful figure is us_per_round.
-    # Timed through the entry point the encoder calls (g4d_fps_gather_grid_f32 -> fps_bucket_grid_kernel: the sampling role above plus
-    # one cell-grid workgroup per cloud riding in the same launch, which ends long before the sampling does).
-    xyz_dev = cloud
-    idx_dev = torch.empty((B_CLOUDS, 1024), dtype=torch.int32, device=cloud.device)
-    nx_dev = torch.empty((B_CLOUDS, 1024, 3), dtype=torch.float32, device=cloud.device)
-    from garment4d_amd import _lib
-    rmax = max(g.radius for g in model.SA_modules[0].groupers)
-    ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B_CLOUDS, N_POINTS), 16), dtype=torch.uint8, device=cloud.device)
-    t = timed(lambda: _lib.call("g4d_fps_gather_grid_f32", B_CLOUDS, N_POINTS, 1024, xyz_dev.data_ptr(), idx_dev.data_ptr(), nx_dev.data_ptr(),
-                                float(rmax), ws.data_ptr(), _lib.stream_ptr()))
-    fps_bytes = B_CLOUDS * (12 * N_POINTS + 4 * 1024 + 12 * 1024)   # cloud in, picks + their coordinates out
-    grid_bytes = B_CLOUDS * (12 * N_POINTS + 16 * N_POINTS)        # the grid role: cloud in, (x, y, z, index) records out (+ cell offsets)
-    tr = pmc_traffic("fps_bucket_grid_kernel")
-    res["fps"] = {"kernel": "fps_bucket_grid_kernel<FM> via g4d_fps_gather_grid_f32 (8192->1024 + gather, B=8; second role: the clouds' cell grids)",
-                  "bound": "latency", "achieved": fps_bytes / t / 1e9,
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps_bytes / t / 1e9 / HBM_PEAK_GBS,
-                  "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
-                  "traffic_source": None if tr is None else tr["source"], "algorithmic_bytes": fps_bytes, "grid_role_bytes": grid_bytes,
-                  "avg_launch_us": t * 1e6, "rounds_per_launch": 1023, "us_per_round": t * 1e6 / 1023,
-                  "rounds_per_s_per_cloud": 1023 / t,
-                  "note": "serial-dependency bound: 1023 dependent rounds per launch, one workgroup per cloud (8 of 256 CUs); "
-                          "neither HBM nor MFMA limits it (frac is against HBM only because the contract wants a number) -- DESIGN.md section 5"}
-    # 2. heaviest MFMA launch of a step: SA level 3 -- both scales, [195 -> 64 -> 64 -> 128] over B*64*32 grouped rows and
-    #    [195 -> 128 -> 128 -> 256] over B*64*64, each + max pool -- as ONE launch (mlp_chain_pair_kernel: fused.launch_group in
-    #    fused.sa_forward).  The path the encoder takes: the feature part of both first layers is contracted once per SOURCE point (one
-    #    table launch over the B*256 points of the level), and the pair launch runs relu(affine(table[j] + Wx (x_j - q))) in its loader and
-    #    the remaining two layers of each scale on the matrix pipe.  `achieved` / `frac` = the MFMA flops that launch EXECUTES over its
-    #    duration (matrix-pipe utilisation); `mfma_busy` = the same thing as the SQ counters see it (profiles/r*_pmc_sq*.csv);
-    #    `algorithmic` = the two layer stacks as the reference computes them (2 * rows * sum K_l C_l, un-padded) over the launch + the
-    #    table launch; `full_chain` = scale 1 alone on the three-layer chain kernel (G4D_SA_TABLE=0), what this object described in round 1.
-    sa3 = model.SA_modules[2]
-    packed = [fused.pack_conv_stack(mm) for mm in sa3.mlps]
-    Bc, Nn, P, C = B_CLOUDS, 256, 64, 192
-    nsamples = [g_.nsample for g_ in sa3.groupers]
-    g = torch.Generator(device="cpu").manual_seed(0)
-    xyz3 = torch.rand(Bc, Nn, 3, generator=g).to(cloud.device)
-    new3 = xyz3[:, :P].contiguous()
-    f3 = torch.randn(Bc, Nn, C, generator=g).to(cloud.device)
-    idxs = [torch.randint(0, Nn, (Bc, P, S_), generator=g, dtype=torch.int32).to(cloud.device) for S_ in nsamples]
-    rows = [Bc * P * S_ for S_ in nsamples]
-    flops_alg = sum(2.0 * r * sum(L.K * L.Cout for L in L_) for r, L_ in zip(rows, packed))
-    layers, S, idx3 = packed[1], nsamples[1], idxs[1]
-    out1 = torch.empty(Bc * P, layers[-1].Cout, device=cloud.device)
-    flops_alg1 = 2.0 * rows[1] * sum(L.K * L.Cout for L in layers)
-    t_full = timed(lambda: fused.mlp_stack(1, rows[1], 3 + C, layers, out1, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
-    full = {"kernel": "mlp_chain_kernel<GROUP,8,8,16> (scale 1 alone, no table)", "avg_launch_us": t_full * 1e6, "achieved": flops_alg1 / t_full / 1e12,
-            "frac": flops_alg1 / t_full / 1e12 / MFMA_F32_PEAK_TFLOPS}
-    if precision == "bf16":
-        # BASELINE config 3: the same stack with bf16 operands on v_mfma_f32_16x16x32_bf16 (csrc/mlp_chain_bf16.hip; the table routes are
-        # fp32-only, so all three layers run on the matrix pipe), against the dense bf16 peak
-        with fused.precision("bf16"):
-            t16 = timed(lambda: fused.mlp_stack(1, rows[1], 3 + C, layers, out1, pool=1, S=S, group=(Nn, P, C, 1, xyz3, new3, f3, idx3)))
-        kname = "mlp_chain_bf16_kernel<1, 1, 8, 8, 16, 0, 1>"
-        tr, sq = pmc_traffic(kname), pmc_sq(kname)
-        res["mlp"] = {"kernel": "mlp_chain_bf16_kernel<GROUP,8,8,16> (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64, bf16 operands / fp32 accumulate)",
-                      "bound": "mfma", "achieved": flops_alg1 / t16 / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": flops_alg1 / t16 / 1e12 / MFMA_BF16_PEAK_TFLOPS, "executed_flops": flops_alg1,
-                      "mfma_busy": None if sq is None else sq["mfma_busy"], "mfma_busy_source": None if sq is None else sq["source"],
-                      "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch", "traffic_source": None if tr is None else tr["source"],
-                      "avg_launch_us": t16 * 1e6, "fp32_full_chain": full,
-                      "note": "isolated launch on an idle chip; far from the bf16 matrix peak by construction: 4.9 GFLOP are 2 us of bf16 MFMA, the launch is "
-                              "bound by its gathers, the fp32 affine / conversion between layers and its ramp (DESIGN.md section 5)"}
-        return res
-    scales = [k for k, (gr, L_) in enumerate(zip(sa3.groupers, packed)) if fused.sa_table_fits(L_, C, 1, 1, gr.nsample, Bc * Nn, Bc * P * gr.nsample)]
-    if scales == [0, 1]:
-        t_tab = timed(lambda: fused.sa_level_table(sa3, packed, f3, scales))
-        table, toffs = fused.sa_level_table(sa3, packed, f3, scales)
-        out3 = torch.empty(Bc, P, sum(L_[-1].Cout for L_ in packed), device=cloud.device)
-        launches = []
+def launch_table(model, smpl, pose_pool, pool, kco, precision):
+    """One coalesced call (8 * kco clouds) launched eagerly on one stream with HIP events around every C-ABI call (the events sit on the stream
+    the kernels are launched on: torch's current stream) -> (rows of the per-launch table, the `roofline*` objects built from it).
 
-        def level():
-            with fused.launch_group() as grp:
-                c0 = 0
-                for k in scales:
-                    fused.sa_scale_mlp(xyz3, new3, f3, idxs[k], packed[k], 1, 1, out3, c0, table=(table, *toffs[k]))
-                    c0 += packed[k][-1].Cout
-            launches.append(grp.launches)
+    Per launch: microseconds (median of 3 passes), the same per B = 8 step, and -- where SURVEY 8(d) defines one -- the launch's algorithmic
+    work against the peak that bounds it:  mfma = the MFMA flops the launch executes / 157.3 TFLOP/s fp32 (2.5 PFLOP/s with bf16 operands);
+    latency = the sampling chain (dependent rounds; HBM bytes reported for completeness); valu = distance evaluations of the brute-force
+    search x 7 lane-operations each / 39.3e12 lane-operations per second; hbm = bytes moved / 8 TB/s."""
+    from garment4d_amd import _lib, fused, lbs as G
+    B = B_CLOUDS * kco
+    n = pool.shape[0]
+    cloud = torch.cat([pool[i % n] for i in range(kco)], 0).contiguous()
+    betas = pose = None
+    if smpl is not None:
+        betas = torch.cat([pose_pool[i % len(pose_pool)][0] for i in range(kco)], 0).contiguous()
+        pose = torch.cat([pose_pool[i % len(pose_pool)][1] for i in range(kco)], 0).contiguous()
 
-        t = timed(level)
-        flops_exec = sum(2.0 * rows[k] * sum(L.K * L.Cout for L in packed[k][1:]) for k in scales)
-        merged = launches[-1] == 1
-        kname = "mlp_chain_pair_kernel<1, 8, 16, 0, 0, 1, 4, 8, 0, 0, 1>" if merged else "mlp_chain_kernel<1, 8, 16"
-        tr, sq = pmc_traffic(kname), pmc_sq(kname)
-        res["mlp"] = {"kernel": ("mlp_chain_pair_kernel<GROUP | 8,16 | 4,8>" if merged else "mlp_chain_kernel<GROUP,8,16> + <GROUP,4,8> (two launches)") +
-                                ", table loaders (SA3: 32768 rows x [195,128,128,256] + 16384 rows x [195,64,64,128], max pool; feature part of the first "
-                                "layers pre-contracted per source point)", "bound": "mfma", "launches": launches[-1],
-                      "achieved": flops_exec / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": flops_exec / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "executed_flops": flops_exec,
-                      "mfma_busy": None if sq is None else sq["mfma_busy"], "mfma_busy_source": None if sq is None else sq["source"],
-                      "traffic": None if tr is None else tr["bytes"], "traffic_unit": "bytes/launch",
-                      "traffic_source": None if tr is None else tr["source"], "avg_launch_us": t * 1e6,
-                      "algorithmic": {"flops": flops_alg, "table_launch_us": t_tab * 1e6,
-                                      "tflops_equivalent": flops_alg / (t + t_tab) / 1e12,
-                                      "frac_equivalent": flops_alg / (t + t_tab) / 1e12 / MFMA_F32_PEAK_TFLOPS},
-                      "full_chain": full,
-                      "note": "isolated launches on an idle chip; inside the many-batch bench the same launch runs concurrently with others"}
-    else:
-        tr = pmc_traffic("mlp_chain_kernel<1, 8, 8, 16")
-        res["mlp"] = dict(full, kernel=full["kernel"] + " (SA3 scale 1: 32768 rows x [195,128,128,256] + max over 64)", bound="mfma",
-                          peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
-                          traffic_source=None if tr is None else tr["source"],
-                          note="isolated launch on an idle chip; inside the many-batch bench the same launch runs concurrently with others")
-    return res
+    def call():
+        model.forward_fused(cloud, precision=precision)
+        if smpl is not None:
+            G.lbs(betas, pose, smpl["v_template"], smpl["shapedirs"], smpl["posedirs"], smpl["J_regressor"], smpl["parents"], smpl["lbs_weights"], pose2rot=True)
+
+    call()
+    torch.cuda.synchronize()
+    passes = []
+    for _ in range(3):
+        with _lib.timed_calls() as t:
+            call()
+        passes.append(t.results())
+    names = [r[0] for r in passes[0]]
+    assert all([r[0] for r in p_] == names for p_ in passes), "the call sequence of a step is deterministic"
+    us = [float(np.median([p_[i][2] for p_ in passes])) for i in range(len(names))]
+    ints = [r[1] for r in passes[0]]
+
+    # the stacks behind the chain launches, in call order (widths from the model itself)
+    SA, FP = list(model.SA_modules), list(model.FP_modules)
+    pk = lambda mlp: [(L.K, L.Cout) for L in fused.pack_conv_stack(mlp)]
+    head = pk(model.FC_layer)
+    mfma_peak = (MFMA_F32_PEAK_TFLOPS if precision == "fp32" else MFMA_BF16_PEAK_TFLOPS) * 1e12
+    rows_out, labels = [], {}
+    sa_lvl = {}
+    chain_i = lin_i = 0
+    chain_desc = []
+    for li in (1, 2):                                  # SA levels 2 and 3, scale 0 then scale 1: layers behind the first-layer table
+        for si, mlp in enumerate(SA[li].mlps):
+            st = pk(mlp)
+            chain_desc.append((f"SA level {li + 1} scale {si}: grouped rows x {st[0][1]}(table) -> " + " -> ".join(str(c) for _, c in st[1:]) + " + max pool",
+                               st[1:], st))
+    fp2 = pk(FP[1].mlp)
+    c1_fp2 = SA[0].mlps[0][-1].conv.out_channels + SA[0].mlps[1][-1].conv.out_channels      # skip features of the middle FP level
+    fp1 = pk(FP[0].mlp)
+    chain_desc.append((f"FP level 2: skip columns {c1_fp2} -> {fp2[0][1]} (interpolated table as accumulator start) -> {fp2[1][1]} -> {fp1[0][1]} (the last level's table)",
+                       [(c1_fp2, fp2[0][1])] + fp2[1:] + [(fp1[0][0], fp1[0][1])], fp2))
+    chain_desc.append((f"FP level 1 + head: interpolated {fp1[0][1]}-wide table -> " + " -> ".join(str(c) for _, c in fp1[1:] + head), fp1[1:] + head, fp1 + head))
+    for i, (nm, iv, t_us) in enumerate(zip(names, ints, us)):
+        row = {"entry": nm, "us": t_us, "us_per_step": t_us / kco}
+        if nm == "g4d_fps_gather_grid_f32":
+            b_, n_, m_ = iv[0], iv[1], iv[2]
+            row.update(what=f"FPS {n_} -> {m_} + gather + the clouds' cell grids, {b_} clouds", bound="latency", rounds=m_ - 1, us_per_round=t_us / (m_ - 1),
+                       algorithmic_bytes=b_ * (12 * n_ + 16 * m_), grid_role_bytes=b_ * 28 * n_)
+        elif nm == "g4d_fps_gather_pair_f32":
+            row.update(what=f"FPS {iv[1]} -> {iv[2]} -> {iv[3]} + gathers", bound="latency", rounds=iv[2] + iv[3] - 2, us_per_round=t_us / (iv[2] + iv[3] - 2))
+        elif nm == "g4d_sa_xyz_mlp3_pair_f32":
+            b_, p_ = iv[0], iv[2]
+            ex = 2.0 * b_ * p_ * (16 * (16 * 16 + 16 * 32) + 32 * (32 * 32 + 32 * 64))
+            row.update(what="SA level 1, both xyz-only scales: layer 1 on the VALU, layers 2-3 on the matrix pipe, max pool", bound="mfma", executed_flops=ex,
+                       algorithmic_flops=ex + 2.0 * b_ * p_ * (16 * 3 * 16 + 32 * 3 * 32))
+        elif nm == "g4d_linear_f32":
+            rows_, k_, cout_ = iv[0], iv[1], iv[3]
+            row.update(what=f"{rows_} rows x {k_} -> {cout_} (first-layer table / wide FP level)", bound="mfma", executed_flops=2.0 * rows_ * k_ * cout_,
+                       algorithmic_flops=2.0 * rows_ * k_ * cout_)
+        elif nm in ("g4d_mlp_chain_group_table_f32", "g4d_mlp_chain_interp_init_f32", "g4d_mlp_chain_table_cells_f32", "g4d_mlp_chain_table_f32", "g4d_mlp_chain_f32",
+                    "g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc) and precision == "fp32":
+            desc, layers, full = chain_desc[chain_i]
+            chain_i += 1
+            rows_ = iv[0]
+            row.update(what=desc, bound="mfma", executed_flops=2.0 * rows_ * sum(k * c for k, c in layers), algorithmic_flops=2.0 * rows_ * sum(k * c for k, c in full))
+        elif nm in ("g4d_three_nn_cells_sorted_f32", "g4d_three_nn_cells_f32"):
+            b_, n_, m_ = iv[0], iv[1], iv[2]
+            ev = float(b_) * n_ * m_
+            row.update(what=f"three_nn {n_} <- {m_} known points, {b_} clouds: brute-force scan over cell-ordered queries", bound="valu", evals=ev,
+                       lane_ops_per_eval=7, achieved=ev * 7 / (t_us * 1e-6), peak=VALU_LANE_OPS_PEAK, unit="lane-op/s", algorithmic_bytes=b_ * (12 * (n_ + m_) + 24 * n_))
+        elif nm == "g4d_lbs_one_f32":
+            b_, v_, j_, nb_ = iv[0], iv[1], iv[2], iv[3]
+            by = b_ * (12 * v_ + 64 * j_ + 12 * v_) + 4.0 * v_ * 3 * (nb_ + (j_ - 1) * 9) + 4.0 * v_ * j_
+            row.update(what=f"lbs() of {b_} frames (V = {v_}, J = {j_}): blend rows + weights once per vertex tile, vertices out", bound="hbm", algorithmic_bytes=by)
+        else:
+            row.update(what=nm.replace("g4d_", "").replace("_f32", ""), bound=None)
+        if row.get("bound") == "mfma":
+            row.update(achieved=row["executed_flops"] / (t_us * 1e-6) / 1e12, peak=mfma_peak / 1e12, unit="TFLOP/s")
+            row["frac"] = row["achieved"] / row["peak"]
+        elif row.get("bound") == "valu":
+            row["frac"] = row["achieved"] / row["peak"]
+        elif row.get("bound") in ("hbm", "latency") and "algorithmic_bytes" in row:
+            row.update(achieved=row["algorithmic_bytes"] / (t_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            row["frac"] = row["achieved"] / row["peak"]
+        rows_out.append(row)
+    total = sum(us)
+    mf = [r for r in rows_out if r.get("bound") == "mfma"]
+    roof = {}
+    kernel_of = {"SA level 3 scale 1": "sa_table_kernel<128, 64, 1, false>", "SA level 3 scale 0": "sa_table_kernel<64, 32, 2, true>", "SA level 2 scale 1": "sa_table_kernel<64, 32, 2, true>",
+                 "SA level 2 scale 0": "sa_table_kernel<32, 16, 2, true>", "SA level 1": "sa_xyz_pair_kernel", "FP level 1": "fp_table_head_kernel", "FP level 2": "mlp_chain_kernel<2, 16, 8, 8"}
+
+    def with_counters(r):
+        r = dict(r)
+        kn = next((v for k_, v in kernel_of.items() if r["what"].startswith(k_)), None)
+        tr, sq = (pmc_traffic(kn), pmc_sq(kn)) if kn else (None, None)
+        r.update(kernel=kn, traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch", traffic_source=None if tr is None else tr["source"],
+                 mfma_busy=None if sq is None else sq["mfma_busy"], mfma_busy_source=None if sq is None else sq["source"], avg_launch_us=r["us"],
+                 share_of_call=r["us"] / total)
+        return r
+
+    if mf:
+        dom = max(mf, key=lambda r: r["us"])
+        roof["roofline"] = with_counters(dom)
+        roof["roofline"]["note"] = ("the launch with the largest GPU time of a coalesced call; timed live with HIP events on the launching stream; `achieved` counts the MFMA flops "
+                                    "the launch executes (the feature part of its first layer runs once per source point in the table launch before it)")
+        ex = sum(r["executed_flops"] for r in mf)
+        roof["roofline_mfma_all"] = {"bound": "mfma", "launches": len(mf), "us": sum(r["us"] for r in mf), "executed_flops": ex,
+                                     "achieved": ex / (sum(r["us"] for r in mf) * 1e-6) / 1e12, "peak": mfma_peak / 1e12, "unit": "TFLOP/s",
+                                     "frac": ex / (sum(r["us"] for r in mf) * 1e-6) / mfma_peak, "share_of_call": sum(r["us"] for r in mf) / total}
+    fps = next((r for r in rows_out if r["entry"] == "g4d_fps_gather_grid_f32"), None)
+    if fps is not None:
+        tr = pmc_traffic("fps_bucket_grid_kernel")
+        roof["roofline_fps"] = dict(fps, kernel="fps_bucket_grid_kernel<FM, 8>", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
+                                    traffic_source=None if tr is None else tr["source"], share_of_call=fps["us"] / total,
+                                    traffic_over_algorithmic_incl_grid_role=None if tr is None else tr["bytes"] / (fps["algorithmic_bytes"] + fps["grid_role_bytes"]),
+                                    note="serial-dependency bound: dependent rounds, one workgroup per cloud; neither HBM nor MFMA limits it (frac is against HBM only "
+                                         "because the contract wants a number) -- the meaningful figure is us_per_round; it overlaps other calls' launches in the executor")
+    hb = [r for r in rows_out if r.get("bound") in ("valu", "hbm")]
+    if hb:
+        roof["roofline_hbm"] = [dict(r, share_of_call=r["us"] / total) for r in hb]
+    return rows_out, roof, total
 
 
 def cpu_model_name():
@@ -532,7 +541,9 @@ def main():
             lat = alone(one, 1)
             lat_call = alone(pipe, kco)                  # one coalesced call alone (includes its kco input copies)
             del one
-        roof = kernel_rooflines(model, pool[0], args.precision) if rank == 0 else None
+        table = roof = None
+        if rank == 0:
+            table, roof, call_us = launch_table(model, smpl, pose_pool, pool, kco, args.precision)
 
     if rank == 0:
         total_steps = args.steps * repeats
@@ -566,7 +577,11 @@ def main():
                                    ("torch.distributed.run" if world > 1 else "single process"),
                        "distance_contraction": __import__("garment4d_amd.numerics", fromlist=["x"]).get_distance_contraction(),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
-            "roofline": roof["fps"], "roofline_mfma": roof["mlp"],
+            "roofline": roof.get("roofline"), "roofline_mfma_all": roof.get("roofline_mfma_all"), "roofline_fps": roof.get("roofline_fps"),
+            "roofline_hbm": roof.get("roofline_hbm"),
+            "launches": {"clouds_per_call": B_CLOUDS * kco, "eager_one_stream_us": call_us, "note": "one coalesced call launched eagerly on one stream, HIP events around every "
+                         "C-ABI call (median of 3): us per call and per B=8 step", "table": [{k: (round(v, 3) if isinstance(v, float) and k in ("us", "us_per_step", "frac") else v)
+                                                                                              for k, v in r.items() if k in ("entry", "what", "us", "us_per_step", "bound", "frac")} for r in table]},
             # SURVEY 8(d) whole-path fractions, per GPU: frames/s x per-frame algorithmic cost / peak
             "whole_path": {"mfma_frac": per_gpu * 2.22e9 / (MFMA_F32_PEAK_TFLOPS * 1e12 if args.precision == "fp32" else 2.5e15),
                            "mfma_peak": "157.3 TFLOP/s fp32" if args.precision == "fp32" else "2.5 PFLOP/s bf16 dense",

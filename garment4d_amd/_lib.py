@@ -137,6 +137,29 @@ def lib():
 
 
 _TRACE = os.environ.get("G4D_TRACE_CALLS", "0") != "0"   # debugging: every C-ABI call with its integer / float arguments on stderr
+_TIMED = None   # measurement: a list collecting (name, integer args, start event, end event) of every call (timed_calls)
+
+
+class timed_calls:
+    """with _lib.timed_calls() as t: ...; t.results() -> [(entry point, integer arguments, microseconds)] of every C-ABI call made inside,
+    from HIP events recorded on the stream each call launched on (torch's current stream), i.e. the GPU time of the call's launches plus the
+    gap to the next event (2-5 us).  bench.py builds its per-launch table and the `roofline` objects from it, live."""
+
+    def __enter__(self):
+        global _TIMED
+        self._rec = []
+        _TIMED = self._rec
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMED
+        _TIMED = None
+        return False
+
+    def results(self):
+        import torch
+        torch.cuda.synchronize()
+        return [(name, ints, e0.elapsed_time(e1) * 1e3) for name, ints, e0, e1 in self._rec]
 
 
 def call(name, *args):
@@ -145,7 +168,15 @@ def call(name, *args):
     if _TRACE:
         import sys
         print("g4d call", name, *[a for a in args if isinstance(a, (int, float)) and abs(a) < (1 << 31)], file=sys.stderr)
-    rc = getattr(L, name)(*args)
+    if _TIMED is not None and args and name not in ("g4d_tuning_set", "g4d_launch_group_begin"):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(L, name)(*args)
+        e1.record()
+        _TIMED.append((name, tuple(a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < (1 << 31)), e0, e1))
+    else:
+        rc = getattr(L, name)(*args)
     if rc != 0:
         raise G4DError(f"{name} failed with status {rc}: {L.g4d_last_error().decode(errors='replace')}")
     return rc

@@ -49,9 +49,18 @@ __device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, 
 constexpr int kRing = 4;   // weight fragments requested ahead of their MFMAs (LDS: ~130 cycles; L2: see kRingG)
 constexpr int kRingG = 6;
 
-// C: table / hidden width (layers C -> C -> 2C), S samples per neighbourhood, MT row tiles of 16 per block, WLDS: weights in LDS
-template <int C, int S, int MT, bool WLDS>
-__global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
+// C: table / hidden width (layers C -> C -> 2C), S samples per neighbourhood, MT row tiles of 16 per block.
+// WM: where a wave's weight fragments come from
+//   1  both matrices resident in LDS (32- / 64-wide stacks: 12 / 48 KB);
+//   0  every wave streams its fragments from L2 through a register ring.  At 16 rows per wave a 1 KB fragment feeds 4 MFMAs = 128 cycles
+//      of matrix pipe: 8 waves per CU ask the vector-memory path for 64 bytes per cycle, all it has -- the 128-wide stack (192 KB of
+//      weights) ran at 0.70 of the matrix pipe this way, the same as the register-chain kernel with 32 rows per wave and half the waves;
+//   2  the four waves of a workgroup walk their blocks in lock step and SHARE every fragment: a k-step's fragments (8 or 16 KB) are copied
+//      L2 -> LDS once per workgroup (global_load_lds, each wave a quarter) into a double buffer, one k-step ahead, one barrier per k-step;
+//      the waves read them with ds_read_b128.  L2 traffic for weights drops 4x.
+template <int C, int S, int MT, int WM>
+__global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
+    constexpr bool WLDS = WM == 1;
     constexpr int T = C / 16, T3 = 2 * T;
     constexpr int R = 16 * MT;                       // rows per block
     constexpr int G = S > R ? S / R : 1;             // blocks per neighbourhood (running maximum across them)
@@ -63,6 +72,7 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_wx = smem, *s_ps = smem + 3 * C, *s_pf = s_ps + C, *s_sc2 = s_pf + C, *s_sh2 = s_sc2 + C, *s_sc3 = s_sh2 + C, *s_sh3 = s_sc3 + 2 * C;
     float *s_w2 = smem + NCONST, *s_w3 = s_w2 + NW2;
+    float *s_stage = smem + NCONST;                  // WM == 2: [2][T3 * 256] floats, a k-step's fragments (tile ct at ct * 256) x 2 buffers
     const int tid = threadIdx.x;
     for (int i = tid; i < 3 * C; i += 256) s_wx[i] = a.wx[i];
     for (int i = tid; i < C; i += 256) { s_ps[i] = a.ps[i]; s_pf[i] = a.pf[i]; s_sc2[i] = a.sc2[i]; s_sh2[i] = a.sh2[i]; }
@@ -91,6 +101,7 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
         const int unit = wg + (it / G) * nwaves;
         return min(unit * G + it % G, nblk - 1);
     };
+    auto live = [&](int it) { return WM != 2 || wg + (it / G) * nwaves < nunit; };   // WM == 2: is this iteration's unit real?
     struct Rows { f32x4 raw[T][MT]; float px[MT], py[MT], pz[MT], cx[MT], cy[MT], cz[MT]; };
     auto load_idx = [&](int blk, int (&v)[MT]) {
 #pragma unroll
@@ -120,11 +131,46 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
         if constexpr (WLDS) return *reinterpret_cast<const f32x4 *>(sw + ((ct * T + ks) * 64 + lane) * 4);
         else return *reinterpret_cast<const f32x4 *>(gw + (ct * T + ks) * 256 + lane16);
     };
-    constexpr int RD = WLDS ? kRing : kRingG;
+    constexpr int RD = WLDS ? kRing : (WM == 2 ? 1 : kRingG);
 
-    const int my_units = wg < nunit ? (nunit - wg + nwaves - 1) / nwaves : 0;
+    // WM == 2: the waves of a workgroup run the same number of iterations (barriers inside the loop); a wave whose unit lies past the end
+    // computes on clamped rows and stores nothing
+    const int units_first = WM == 2 ? blockIdx.x * 4 : wg;
+    const int my_units = units_first < nunit ? (nunit - units_first + nwaves - 1) / nwaves : 0;
     const int iters = my_units * G;
     if (iters == 0) return;
+    // one k-step's fragments into the stage buffer `step & 1`: steps 0 .. T-1 are layer 2's k-steps, T .. 2T-1 layer 3's; periodic per block
+    auto stage_issue = [&](int step) {
+        if constexpr (WM == 2) {
+            step = step % (2 * T);
+            float *dst = s_stage + (step & 1) * (T3 * 256);
+            if (step < T) {
+#pragma unroll
+                for (int j = 0; j < T / 4; ++j) {
+                    const int ct = wave + 4 * j;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W2 + (ct * T + step) * 256 + lane16),
+                                                     (__attribute__((address_space(3))) void *)(dst + ct * 256), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T3 / 4; ++j) {
+                    const int ct = wave + 4 * j;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W3 + (ct * T + step - T) * 256 + lane16),
+                                                     (__attribute__((address_space(3))) void *)(dst + ct * 256), 16, 0, 0);
+                }
+            }
+        }
+    };
+    // start of a k-step: this wave's share of the step's fragments has landed (vmcnt), so has everybody else's and nobody reads the other
+    // buffer any more (barrier); then the next step's copy goes out
+    auto stage_step = [&](int step) {
+        if constexpr (WM == 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            stage_issue(step + 1);
+        }
+    };
+    auto sfrag = [&](int step, int ct) -> f32x4 { return *reinterpret_cast<const f32x4 *>(s_stage + (step & 1) * (T3 * 256) + (ct * 64 + lane) * 4); };
+    stage_issue(0);
     int ivn[MT];
     Rows cur, nxt;
     load_idx(block_of(0), ivn);
@@ -133,12 +179,15 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
     float pm[T3];                                    // running maximum of the neighbourhood across its blocks (G > 1)
     for (int it = 0; it < iters; ++it) {
         const int blk = block_of(it);
-        if constexpr (!WLDS) asm volatile("" : "+v"(lane16));   // no hoisted fragment addresses
-        load_rows(block_of(it + 1), ivn, nxt);       // level 2 of the next block
-        load_idx(block_of(it + 2), ivn);             // level 1 of the one after
+        if constexpr (WM != 1) asm volatile("" : "+v"(lane16));   // no hoisted fragment addresses
+        if constexpr (WM != 2) {
+            load_rows(block_of(it + 1), ivn, nxt);   // level 2 of the next block
+            load_idx(block_of(it + 2), ivn);         // level 1 of the one after
+        }
         // ---- first layer: relu(affine(table row + Wx (x_j - q))), the arithmetic of mlp_chain.hip's table loader, one k-step at a time
         //      in front of that k-step's share of layer 2 (transposed: A = weights, B = activations -- lane (fi, fq) ends with channels
         //      16 ct + 4 fq + r of row fi).  Fragment (ks, ct): every accumulator sees k ascending, as in the chain kernel.
+        f32x4 sring[2];
         float gx[MT], gy[MT], gz[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { gx[mt] = cur.px[mt] - cur.cx[mt]; gy[mt] = cur.py[mt] - cur.cy[mt]; gz[mt] = cur.pz[mt] - cur.cz[mt]; }
@@ -150,11 +199,14 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
         {
             constexpr int F = T * T;
             f32x4 ring[RD];
+            if constexpr (WM != 2) {
 #pragma unroll
-            for (int f = 0; f < RD; ++f)
-                if (f < F) ring[f] = wfrag(a.W2, s_w2, f % T, f / T);
+                for (int f = 0; f < RD; ++f)
+                    if (f < F) ring[f] = wfrag(a.W2, s_w2, f % T, f / T);
+            }
 #pragma unroll
             for (int ks = 0; ks < T; ++ks) {
+                stage_step(ks);
                 const int k0 = ks * 16 + fq * 4;
                 const f32x4 wx = *reinterpret_cast<const f32x4 *>(s_wx + k0), wy = *reinterpret_cast<const f32x4 *>(s_wx + C + k0),
                             wz = *reinterpret_cast<const f32x4 *>(s_wx + 2 * C + k0);
@@ -170,8 +222,15 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
 #pragma unroll
                 for (int ct = 0; ct < T; ++ct) {
                     const int f = ks * T + ct;
-                    const f32x4 w = ring[f % RD];
-                    if (f + RD < F) ring[f % RD] = wfrag(a.W2, s_w2, (f + RD) % T, (f + RD) / T);
+                    f32x4 w;
+                    if constexpr (WM == 2) {   // two fragments of the step's buffer ahead of the MFMAs (the ring restarts at every k-step: the next buffer is not ready before its barrier)
+                        if (ct == 0) { sring[0] = sfrag(ks, 0); sring[1] = sfrag(ks, 1); }
+                        w = sring[ct & 1];
+                        if (ct + 2 < T) sring[ct & 1] = sfrag(ks, ct + 2);
+                    } else {
+                        w = ring[f % RD];
+                        if (f + RD < F) ring[f % RD] = wfrag(a.W2, s_w2, (f + RD) % T, (f + RD) / T);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -180,12 +239,14 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
                 }
             }
         }
-        cur = nxt;
+        if constexpr (WM != 2) cur = nxt;
         f32x4 ring3[RD];                             // layer 3's first fragments, requested before the seam
         constexpr int F3 = T * T3;
+        if constexpr (WM != 2) {
 #pragma unroll
-        for (int f = 0; f < RD; ++f)
-            if (f < F3) ring3[f] = wfrag(a.W3, s_w3, f % T3, f / T3);
+            for (int f = 0; f < RD; ++f)
+                if (f < F3) ring3[f] = wfrag(a.W3, s_w3, f % T3, f / T3);
+        }
 #pragma unroll
         for (int ct = 0; ct < T; ++ct) {
             const f32x4 sc = *reinterpret_cast<const f32x4 *>(s_sc2 + ct * 16 + fq * 4), sh = *reinterpret_cast<const f32x4 *>(s_sh2 + ct * 16 + fq * 4);
@@ -203,8 +264,25 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
 #pragma unroll
         for (int f = 0; f < F3; ++f) {
             const int ks = f / T3, ct = f % T3;
-            const f32x4 w = ring3[f % RD];
-            if (f + RD < F3) ring3[f % RD] = wfrag(a.W3, s_w3, (f + RD) % T3, (f + RD) / T3);
+            if (ct == 0) {
+                stage_step(T + ks);
+                if constexpr (WM == 2) {
+                    if (ks == 0) {   // the next block's rows: requested here, behind a k-step barrier -- every barrier drains this wave's loads (vmcnt(0)),
+                                     // so they get the 2k cycles of layer 3's first k-step instead of stalling the block's first one
+                        load_rows(block_of(it + 1), ivn, nxt);
+                        load_idx(block_of(it + 2), ivn);
+                    }
+                }
+            }
+            f32x4 w;
+            if constexpr (WM == 2) {
+                if (ct == 0) { sring[0] = sfrag(T + ks, 0); sring[1] = sfrag(T + ks, 1); }
+                w = sring[ct & 1];
+                if (ct + 2 < T3) sring[ct & 1] = sfrag(T + ks, ct + 2);
+            } else {
+                w = ring3[f % RD];
+                if (f + RD < F3) ring3[f % RD] = wfrag(a.W3, s_w3, (f + RD) % T3, (f + RD) / T3);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -230,7 +308,7 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
 #pragma unroll
                 for (int c4 = 0; c4 < T3 / 4; ++c4) {
                     const float m = fmaxf(pool4_rows_max_t(v[c4 * 4][mt], v[c4 * 4 + 1][mt], v[c4 * 4 + 2][mt], v[c4 * 4 + 3][mt]), 0.f);
-                    if (g < nq) a.out[(size_t)g * a.ldo + a.col0 + c4 * 64 + lane] = m;
+                    if (g < nq && live(it)) a.out[(size_t)g * a.ldo + a.col0 + c4 * 64 + lane] = m;
                 }
             }
         } else {
@@ -253,10 +331,11 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
                     float m;
                     if constexpr (G > 1) m = pool4_rows_max_t(pm[c4 * 4], pm[c4 * 4 + 1], pm[c4 * 4 + 2], pm[c4 * 4 + 3]);
                     else m = pool4_rows_max_t(x[c4 * 4], x[c4 * 4 + 1], x[c4 * 4 + 2], x[c4 * 4 + 3]);
-                    if (g < nq) a.out[(size_t)g * a.ldo + a.col0 + c4 * 64 + lane] = fmaxf(m, 0.f);
+                    if (g < nq && live(it)) a.out[(size_t)g * a.ldo + a.col0 + c4 * 64 + lane] = fmaxf(m, 0.f);
                 }
             }
         }
+        if constexpr (WM == 2) cur = nxt;
     }
 }
 
@@ -264,19 +343,20 @@ __global__ void __launch_bounds__(256) sa_table_kernel(const SaTabArgs a) {
 
 using namespace g4d;
 
-template <int C, int S, int MT, bool WLDS>
+template <int C, int S, int MT, int WM>
 static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
-    const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0));
+    constexpr bool WLDS = WM == 1;
+    const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * (C / 8) * 256 : 0));
     static unsigned long long attr = 0;
     if (lds > 64 * 1024) {
-        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sa_table_kernel<C, S, MT, WLDS>), lds, attr, "g4d_sa_table");
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sa_table_kernel<C, S, MT, WM>), lds, attr, "g4d_sa_table");
         if (rc) return rc;
     }
     static const int resident = [] {
-        const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0));
+        const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * (C / 8) * 256 : 0));
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sa_table_kernel<C, S, MT, WLDS>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sa_table_kernel<C, S, MT, WM>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return per_cu * 256;
         return per_cu * prop.multiProcessorCount;
     }();
@@ -284,7 +364,7 @@ static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
     const long long nunit = ((a.rows + R - 1) / R + G - 1) / G;
     const long long want = (nunit + 3) / 4;
     const unsigned grid = (unsigned)(want < resident ? want : resident);
-    hipLaunchKernelGGL((sa_table_kernel<C, S, MT, WLDS>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sa_table_kernel<C, S, MT, WM>), dim3(grid), dim3(256), lds, st, a);
     return check_launch("g4d_sa_table");
 }
 
@@ -305,13 +385,14 @@ int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, con
     a.W2 = W[0]; a.sc2 = scale[0]; a.sh2 = shift[0];
     a.W3 = W[1]; a.sc3 = scale[1]; a.sh3 = shift[1];
     a.out = out; a.ldo = ldo; a.col0 = col0;
-    if (Kt == 32 && S == 16) return sa_table_launch<32, 16, 2, true>(a, st);
-    if (Kt == 32 && S == 32) return sa_table_launch<32, 32, 2, true>(a, st);
-    if (Kt == 64 && S == 32) return sa_table_launch<64, 32, 2, true>(a, st);
-    if (Kt == 64 && S == 64) return sa_table_launch<64, 64, 2, true>(a, st);
-    if (Kt == 64 && S == 16) return sa_table_launch<64, 16, 1, true>(a, st);
+    if (Kt == 32 && S == 16) return sa_table_launch<32, 16, 2, 1>(a, st);
+    if (Kt == 32 && S == 32) return sa_table_launch<32, 32, 2, 1>(a, st);
+    if (Kt == 64 && S == 32) return sa_table_launch<64, 32, 2, 1>(a, st);
+    if (Kt == 64 && S == 64) return sa_table_launch<64, 64, 2, 1>(a, st);
+    if (Kt == 64 && S == 16) return sa_table_launch<64, 16, 1, 1>(a, st);
     const int wide = (int)tuning("sa_table_128", 1);   // A/B switch: the 128-wide stack (weights streamed from L2: 192 KB do not fit LDS)
-    if (wide && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, false>(a, st);
-    if (wide && Kt == 128 && S == 32) return sa_table_launch<128, 32, 1, false>(a, st);
+    if (wide == 2 && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, 0>(a, st);   // (A/B: every wave streaming its own fragments)
+    if (wide && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, 2>(a, st);
+    if (wide && Kt == 128 && S == 32) return sa_table_launch<128, 32, 1, 2>(a, st);
     return -1;
 }
