@@ -815,6 +815,11 @@ extern "C" int g4d_mlp_chain_interp_init_f32(long long rows, int n, int m, int C
                                              const int *relu, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld,
                                              g4d_stream_t stream) {
     G4D_REQUIRE(table && skip && dist2 && nn_idx, "g4d_mlp_chain_interp_init_f32: null pointer");
+    if (W && scale && shift && Kpad && Cout && relu && out) {   // large launches of the middle FP level's stack: fp_init.hip (bit-identical)
+        const int rc = fp_init_try(rows, n, m, C1, skip, table, tab_ld, dist2, nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, out, ldo, col0, tap_layer,
+                                   tap_out, tap_ld, reinterpret_cast<hipStream_t>(stream));
+        if (rc != -1) return rc;
+    }
     return chain_f32_impl(LOAD_INTERP, rows, C1, nullptr, 0, 0, 0, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, n, m, 0, C1, nullptr, skip, dist2,
                           nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, 0, out, ldo, col0, tap_layer, tap_out, tap_ld, nullptr, nullptr,
                           nullptr, 0, table, tab_ld, nullptr, stream);

@@ -74,6 +74,11 @@ int fp_table_try(long long rows, int n, int m, int C2, const float *table, const
                  const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out, int ldo,
                  int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
 
+// fp_init.hip: persistent form of g4d_mlp_chain_interp_init_f32 for the skip 96 -> 256 -> 128 -> 128 stack, weights shared through LDS; -1 = not its kind
+int fp_init_try(long long rows, int n, int m, int C1, const float *skip, const float *table, int tab_ld, const float *dist2, const int *nn_idx, int nlayers,
+                const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out,
+                int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
+
 // sa_table.hip: persistent, software-pipelined form of g4d_mlp_chain_group_table_f32 for large launches (same arguments); -1 = not its kind
 int sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld, int Kt,
                  const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def tuning(**kv):
     """g4d_tuning_set for the duration of the block; restores the defaults of this file's keys afterwards."""
     defaults = {"sa_table_persistent": 1, "sa_table_min_rows": 262144, "sa_table_128": 1, "fp_table_persistent": 1, "fp_table_min_rows": 262144,
-                "gemm_tile": 1, "gemm_tile_min_rows": 32768}
+                "gemm_tile": 1, "gemm_tile_min_rows": 32768, "fp_init_persistent": 1, "fp_init_min_rows": 131072}
     try:
         for k, v in kv.items():
             _lib.call("g4d_tuning_set", k.encode(), int(v))
@@ -131,3 +131,27 @@ def test_copy_segments():
         _lib.call("g4d_copy_segments_f32", 5, 0, 0, 0, _lib.stream_ptr())
     with pytest.raises(_lib.G4DError):
         _lib.call("g4d_tuning_set", b"no_such_key", 1)
+
+
+@pytest.mark.parametrize("B,n,m,also", [(3, 1024, 256, True), (2, 1000, 100, True), (5, 333, 64, False)])
+def test_fp_init_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, also):
+    """Middle FP level of the encoder ([256 + 96 -> 256 -> 128] with skip features, + the next level's 128 -> 128 table as a third layer):
+    csrc/fp_init.hip against the register-chain kernel; n = 1000 / 333: tiles straddle clouds, the last tile is partial."""
+    torch.manual_seed(n + m)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 256, device="cuda")
+    skip = torch.randn(B, n, 96, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[352, 256, 128]))
+    nxt = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    raw = fused.fp_table_layer(nxt, 0, 128, None) if also else None
+    if not also:
+        pytest.skip("the kernel covers the three-layer form (with the next level's table) only")
+    outs = {}
+    with torch.no_grad():
+        for on in (0, 1):
+            with tuning(fp_init_persistent=on, fp_init_min_rows=0):
+                outs[on] = fused.fp_forward(fp, unknown, known, skip, kf, also_table=raw)
+    assert isinstance(outs[1], tuple) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want = fp(unknown, known, fused.to_channel_major(skip), fused.to_channel_major(kf))
+    np.testing.assert_allclose(fused.to_channel_major(outs[1][0]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
