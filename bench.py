@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--coalesce", type=int, default=30, help="B = 8 steps gathered into one call of the executor (garment4d_amd/pipeline.py): 30 = the "
                                                               "reference's own fold of (8 clips, 30 frames) into one batch, modules/mesh_encoder.py:133")
-    ap.add_argument("--streams", type=int, default=2, help="calls in flight per GPU, each a captured hipGraph on its own stream (profiles/r04_coalesce_by_streams.txt)")
+    ap.add_argument("--streams", type=int, default=3, help="calls in flight per GPU, each a captured hipGraph on its own stream (profiles/r04_coalesce_by_streams.txt)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per sample the CPU oracle is timed on with all cores")
@@ -128,7 +128,7 @@ def pmc_sq(kernel_substr):
     return None
 
 
-VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # fp32 VALU lane-operations per second (un-packed): 39.3e12
+VALU_LANE_OPS_PEAK = 2 * 256 * 4 * 16 * 2.4e9   # fp32 VALU lane-operations per second with packed instructions (v_pk_fma_f32: two per lane and cycle): 78.6e12
 
 
 def launch_table(model, smpl, pose_pool, pool, kco, precision):
@@ -138,7 +138,7 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     Per launch: microseconds (median of 3 passes), the same per B = 8 step, and -- where SURVEY 8(d) defines one -- the launch's algorithmic
     work against the peak that bounds it:  mfma = the MFMA flops the launch executes / 157.3 TFLOP/s fp32 (2.5 PFLOP/s with bf16 operands);
     latency = the sampling chain (dependent rounds; HBM bytes reported for completeness); valu = distance evaluations of the brute-force
-    search x 7 lane-operations each / 39.3e12 lane-operations per second; hbm = bytes moved / 8 TB/s."""
+    search x 7 lane-operations each / 78.6e12 packed-fp32 lane-operations per second; hbm = bytes moved / 8 TB/s."""
     from garment4d_amd import _lib, fused, lbs as G
     B = B_CLOUDS * kco
     n = pool.shape[0]
