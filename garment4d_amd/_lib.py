@@ -131,6 +131,8 @@ def lib():
         L.g4d_get_distance_contraction.restype = _I
         L.g4d_set_distance_contraction.argtypes = [_I]
         L.g4d_set_distance_contraction.restype = _I
+        L.g4d_set_distance_contraction_thread.argtypes = [_I]
+        L.g4d_set_distance_contraction_thread.restype = _I
         L.g4d_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib

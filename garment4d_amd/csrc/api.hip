@@ -25,7 +25,11 @@ static int parse_contract(const char *e) {
     return G4D_CONTRACT_NVCC;
 }
 
+// per host thread override (-1: none): what a launcher called on this thread uses; the process-wide mode is only the default
+static thread_local int t_contract = -1;
+
 int distance_contraction() {
+    if (t_contract >= 0) return t_contract;
     int m = __atomic_load_n(&g_contract, __ATOMIC_RELAXED);
     if (m < 0) {
         m = parse_contract(getenv("G4D_DIST_CONTRACT"));
@@ -78,8 +82,21 @@ extern "C" int g4d_version(void) { return 200; /* 0.2.0: round 2 (g4d_ball_query
 extern "C" const char *g4d_last_error(void) { return g4d::g_err; }
 
 extern "C" int g4d_get_distance_contraction(void) { return g4d::distance_contraction(); }
+extern "C" int g4d_set_distance_contraction_thread(int mode) {
+    const int prev = g4d::t_contract;
+    if (mode < -1 || mode > G4D_CONTRACT_CHAIN) {
+        g4d::set_error("g4d_set_distance_contraction_thread: mode %d is not -1 (no override) or one of G4D_CONTRACT_OFF/NVCC/CHAIN", mode);
+        return -2;
+    }
+    g4d::t_contract = mode;
+    return prev;
+}
+
 extern "C" int g4d_set_distance_contraction(int mode) {
-    const int prev = g4d::distance_contraction();
+    const int saved = g4d::t_contract;
+    g4d::t_contract = -1;
+    const int prev = g4d::distance_contraction();   // the process-wide mode, not this thread's override
+    g4d::t_contract = saved;
     if (mode < G4D_CONTRACT_OFF || mode > G4D_CONTRACT_CHAIN) {
         g4d::set_error("g4d_set_distance_contraction: mode %d is not one of G4D_CONTRACT_OFF/NVCC/CHAIN", mode);
         return -1;

@@ -46,6 +46,7 @@ __device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, 
     return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
 }
 
+constexpr int kStageK = 2;   // WM == 2: k-steps per staged chunk (one barrier per chunk)
 constexpr int kRing = 4;   // weight fragments requested ahead of their MFMAs (LDS: ~130 cycles; L2: see kRingG)
 constexpr int kRingG = 6;
 
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_wx = smem, *s_ps = smem + 3 * C, *s_pf = s_ps + C, *s_sc2 = s_pf + C, *s_sh2 = s_sc2 + C, *s_sc3 = s_sh2 + C, *s_sh3 = s_sc3 + 2 * C;
     float *s_w2 = smem + NCONST, *s_w3 = s_w2 + NW2;
-    float *s_stage = smem + NCONST;                  // WM == 2: [2][T3 * 256] floats, a k-step's fragments (tile ct at ct * 256) x 2 buffers
+    float *s_stage = smem + NCONST;                  // WM == 2: [2][kStageK * T3 * 256] floats: two buffers of one chunk's fragments
     const int tid = threadIdx.x;
     for (int i = tid; i < 3 * C; i += 256) s_wx[i] = a.wx[i];
     for (int i = tid; i < C; i += 256) { s_ps[i] = a.ps[i]; s_pf[i] = a.pf[i]; s_sc2[i] = a.sc2[i]; s_sh2[i] = a.sh2[i]; }
@@ -139,37 +140,46 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
     const int my_units = units_first < nunit ? (nunit - units_first + nwaves - 1) / nwaves : 0;
     const int iters = my_units * G;
     if (iters == 0) return;
-    // one k-step's fragments into the stage buffer `step & 1`: steps 0 .. T-1 are layer 2's k-steps, T .. 2T-1 layer 3's; periodic per block
-    auto stage_issue = [&](int step) {
+    // kStageK k-steps' fragments (a chunk) into the stage buffer `chunk & 1`: chunks 0 .. T/kStageK-1 are layer 2's, the rest layer 3's; periodic
+    // per block (an even number of chunks).  Fragment (kk, ct) of a chunk sits at slot kk * (tiles of the layer) + ct.
+    auto stage_issue = [&](int chunk) {
         if constexpr (WM == 2) {
-            step = step % (2 * T);
-            float *dst = s_stage + (step & 1) * (T3 * 256);
-            if (step < T) {
+            constexpr int NC2 = T / kStageK, NCH = 2 * NC2;
+            chunk = chunk % NCH;
+            float *dst = s_stage + (chunk & 1) * (kStageK * T3 * 256);
+            unsigned l16 = lane16;
+            asm volatile("" : "+v"(l16));   // opaque here: otherwise the copy-source addresses of every chunk are formed at the top of the block and kept
+            if (chunk < NC2) {
 #pragma unroll
-                for (int j = 0; j < T / 4; ++j) {
-                    const int ct = wave + 4 * j;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W2 + (ct * T + step) * 256 + lane16),
-                                                     (__attribute__((address_space(3))) void *)(dst + ct * 256), 16, 0, 0);
+                for (int j = 0; j < kStageK * T / 4; ++j) {
+                    const int slot = wave + 4 * j, kk = slot / T, ct = slot % T;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W2 + (ct * T + chunk * kStageK + kk) * 256 + l16),
+                                                     (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < T3 / 4; ++j) {
-                    const int ct = wave + 4 * j;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W3 + (ct * T + step - T) * 256 + lane16),
-                                                     (__attribute__((address_space(3))) void *)(dst + ct * 256), 16, 0, 0);
+                for (int j = 0; j < kStageK * T3 / 4; ++j) {
+                    const int slot = wave + 4 * j, kk = slot / T3, ct = slot % T3;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W3 + (ct * T + (chunk - NC2) * kStageK + kk) * 256 + l16),
+                                                     (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, 0, 0);
                 }
             }
         }
     };
-    // start of a k-step: this wave's share of the step's fragments has landed (vmcnt), so has everybody else's and nobody reads the other
-    // buffer any more (barrier); then the next step's copy goes out
-    auto stage_step = [&](int step) {
+    // start of a chunk (k-step gks of the block, 0 .. 2T-1; acts on the first k-step of each chunk): this wave's share of the chunk's
+    // fragments has landed (vmcnt), so has everybody else's and nobody reads the other buffer any more (barrier); then the next chunk's copy
+    // goes out.  (One k-step per barrier: 805 us for the 128-wide stack; a 1k-cycle k-step barely covers the copy's L2 round trip.)
+    auto stage_step = [&](int gks) {
         if constexpr (WM == 2) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            stage_issue(step + 1);
+            if (gks % kStageK == 0) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                stage_issue(gks / kStageK + 1);
+            }
         }
     };
-    auto sfrag = [&](int step, int ct) -> f32x4 { return *reinterpret_cast<const f32x4 *>(s_stage + (step & 1) * (T3 * 256) + (ct * 64 + lane) * 4); };
+    auto sfrag = [&](int gks, int nt, int ct) -> f32x4 {
+        return *reinterpret_cast<const f32x4 *>(s_stage + ((gks / kStageK) & 1) * (kStageK * T3 * 256) + (((gks % kStageK) * nt + ct) * 64 + lane) * 4);
+    };
     stage_issue(0);
     int ivn[MT];
     Rows cur, nxt;
@@ -224,9 +234,9 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
                     const int f = ks * T + ct;
                     f32x4 w;
                     if constexpr (WM == 2) {   // two fragments of the step's buffer ahead of the MFMAs (the ring restarts at every k-step: the next buffer is not ready before its barrier)
-                        if (ct == 0) { sring[0] = sfrag(ks, 0); sring[1] = sfrag(ks, 1); }
+                        if (ct == 0) { sring[0] = sfrag(ks, T, 0); sring[1] = sfrag(ks, T, 1); }
                         w = sring[ct & 1];
-                        if (ct + 2 < T) sring[ct & 1] = sfrag(ks, ct + 2);
+                        if (ct + 2 < T) sring[ct & 1] = sfrag(ks, T, ct + 2);
                     } else {
                         w = ring[f % RD];
                         if (f + RD < F) ring[f % RD] = wfrag(a.W2, s_w2, (f + RD) % T, (f + RD) / T);
@@ -276,9 +286,9 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
             }
             f32x4 w;
             if constexpr (WM == 2) {
-                if (ct == 0) { sring[0] = sfrag(T + ks, 0); sring[1] = sfrag(T + ks, 1); }
+                if (ct == 0) { sring[0] = sfrag(T + ks, T3, 0); sring[1] = sfrag(T + ks, T3, 1); }
                 w = sring[ct & 1];
-                if (ct + 2 < T3) sring[ct & 1] = sfrag(T + ks, ct + 2);
+                if (ct + 2 < T3) sring[ct & 1] = sfrag(T + ks, T3, ct + 2);
             } else {
                 w = ring3[f % RD];
                 if (f + RD < F3) ring3[f % RD] = wfrag(a.W3, s_w3, (f + RD) % T3, (f + RD) / T3);
@@ -346,14 +356,14 @@ using namespace g4d;
 template <int C, int S, int MT, int WM>
 static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
     constexpr bool WLDS = WM == 1;
-    const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * (C / 8) * 256 : 0));
+    const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * kStageK * (C / 8) * 256 : 0));
     static unsigned long long attr = 0;
     if (lds > 64 * 1024) {
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(sa_table_kernel<C, S, MT, WM>), lds, attr, "g4d_sa_table");
         if (rc) return rc;
     }
     static const int resident = [] {
-        const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * (C / 8) * 256 : 0));
+        const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * kStageK * (C / 8) * 256 : 0));
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sa_table_kernel<C, S, MT, WM>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;

@@ -449,7 +449,9 @@ def _fps_needs_no_scratch(N, npoint):
     pick list on chip and take temp = NULL; everything else (N < 64, N > 32768) runs the generic kernel, which needs the reference's
     (B, N) scratch initialised to 1e10."""
     if 8192 < N <= 32768 and npoint <= N:      # csrc/fps_big.hip (or the register-resident kernel below 12800 points)
-        return True
+        # ... unless the A/B switches of fps_impl (G4D_FPS_BIG=0, G4D_FPS_W) keep these clouds off fps_big.hip: then the rule below decides
+        if os.environ.get("G4D_FPS_BIG", "1") != "0" and "G4D_FPS_W" not in os.environ:
+            return True
     return N >= 64 and N * 12 + npoint * 4 + 512 <= 158 * 1024 and N <= 12800
 
 
@@ -721,7 +723,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
         table, toffs = sa_level_table(sa, packed, feats_pm, tab_scales) if tab_scales else (None, [])
         # the scales of a level are independent of each other: when all of them run on the table-loader chain kernel they are one
         # launch group (one kernel launch where a merged kernel exists, csrc/mlp_chain.hip)
-        grouped = len(packed) > 1 and len(tab_scales) == len(packed)
+        grouped = 1 < len(packed) <= 4 and len(tab_scales) == len(packed)   # (a launch group holds at most 4 recorded stacks; all on the current stream)
         with (launch_group() if grouped else contextlib.nullcontext()):
             for k, (grouper, layers, idx) in enumerate(zip(sa.groupers, packed, idxs)):
                 S = grouper.nsample

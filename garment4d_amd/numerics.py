@@ -8,11 +8,11 @@ distance contraction -- how the squared distance inside FPS / ball query / three
 Index outputs (FPS picks, ball membership, 3-NN order) can differ between modes wherever two candidates are within an ulp;
 checkpoints trained on the CUDA build expect "nvcc".  Process-wide; also settable with G4D_DIST_CONTRACT before first use.
 
-NOT thread-safe: the mode is ONE global of the library (g_contract, csrc/api.hip), read each time a kernel is launched.  Set it once at
-start-up.  `distance_contraction(...)` below is a convenience for single-threaded tests: two host threads (or two streams driven from
-different threads) that switch modes race, and a launch enqueued by another thread inside the `with` block takes the temporary mode.
-(`fused.precision` is different: a context variable, per thread.)  The default moved from "off" (round 1) to "nvcc" (round 2): indices
-can differ from a round-1 library wherever two candidates are within an ulp unless G4D_DIST_CONTRACT=off.
+Two levels (round 4): `set_distance_contraction` sets the PROCESS-WIDE default (one global of the library, csrc/api.hip; set it once at
+start-up), `distance_contraction(...)` below overrides it for the CALLING HOST THREAD only (a thread-local of the library, read each time
+a kernel is launched from that thread) -- two host threads driving the library on different streams with different modes do not
+interfere, like `fused.precision`.  The default moved from "off" (round 1) to "nvcc" (round 2): indices can differ from a round-1 library
+wherever two candidates are within an ulp unless G4D_DIST_CONTRACT=off.
 """
 import contextlib
 
@@ -37,9 +37,12 @@ def set_distance_contraction(mode) -> str:
 
 @contextlib.contextmanager
 def distance_contraction(mode):
-    """Temporarily switch the PROCESS-WIDE mode (single-threaded use only, see the module docstring)."""
-    prev = set_distance_contraction(mode)
+    """Use `mode` for every launch made by the CALLING THREAD inside the block (other threads keep theirs); nests."""
+    m = MODES[mode] if isinstance(mode, str) else int(mode)
+    prev = _lib.lib().g4d_set_distance_contraction_thread(m)
+    if prev < -1:
+        raise _lib.G4DError(_lib.lib().g4d_last_error().decode(errors="replace"))
     try:
         yield
     finally:
-        set_distance_contraction(prev)
+        _lib.lib().g4d_set_distance_contraction_thread(prev)

@@ -12,6 +12,8 @@ RuntimeError instead of the reference's exit(-1).
 Install under the reference's name with `garment4d_amd.install_as_pointnet2_cuda()` or by putting the repo
 root (which holds a `pointnet2_cuda.py` shim) on PYTHONPATH.
 """
+import collections
+
 import torch
 
 from . import _lib
@@ -43,14 +45,23 @@ _NN_GRID_MIN_M = 4096  # same threshold as fused.THREE_NN_GRID_MIN_M
 # The reference's boundary never allocates: the cell-grid searches need a scratch the nine-name signature has no slot
 # for, so it is a cached workspace per (device, stream) -- grown, never shrunk, reused by every later call on that stream (kernels of one
 # stream run in order, so consecutive calls may share it; two streams never do).  No allocator call on the steady-state path.
-_workspaces = {}
+# Bounded: the least recently used entry goes when more than _WS_MAX streams have been seen (programs that create short-lived streams),
+# and nothing is cached while a hipGraph is being captured (a tensor allocated then belongs to the graph's private pool: sharing it with
+# eager calls or other graphs would be an unsynchronised shared scratch) -- a capture gets a plain allocation, which the graph keeps alive.
+_workspaces = collections.OrderedDict()
+_WS_MAX = 32
 
 
 def _workspace(nbytes, device):
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _workspaces[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    _workspaces.move_to_end(key)
+    while len(_workspaces) > _WS_MAX:
+        _workspaces.popitem(last=False)
     return ws
 
 

@@ -54,6 +54,10 @@ const char *g4d_last_error(void);
 #define G4D_CONTRACT_CHAIN 2
 int g4d_get_distance_contraction(void);
 int g4d_set_distance_contraction(int mode);
+/* Override for the CALLING host thread only (-1 removes it): every launcher called on this thread uses it instead of the process-wide mode.
+ * Two host threads driving the library on different streams with different modes do not interfere.  Returns the previous override
+ * (-1 = none), -2 on a bad mode.  g4d_get_distance_contraction() reports what the calling thread's launches would use. */
+int g4d_set_distance_contraction_thread(int mode);
 
 /* ---- the reference's nine kernels ------------------------------------------------------- */
 

@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_signatures_cover_header():
     from garment4d_amd import _lib
-    declared = set(declared_symbols()) - {"g4d_version", "g4d_last_error", "g4d_get_distance_contraction", "g4d_set_distance_contraction"}
+    declared = set(declared_symbols()) - {"g4d_version", "g4d_last_error", "g4d_get_distance_contraction", "g4d_set_distance_contraction",
+                                          "g4d_set_distance_contraction_thread"}
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
 
 
@@ -124,6 +125,38 @@ def test_distance_contraction_switch_without_a_gpu():
             numerics.set_distance_contraction(3)
     finally:
         numerics.set_distance_contraction(start)
+
+
+def test_distance_contraction_override_is_per_host_thread():
+    """the contraction mode was one process global.  `numerics.distance_contraction(...)` now overrides it for the calling
+    host thread only (a thread-local of the library): a second thread inside its own block, or outside any block, is not affected."""
+    import threading
+    from garment4d_amd import numerics
+    start = numerics.get_distance_contraction()
+    seen = {}
+    gate1, gate2 = threading.Event(), threading.Event()
+
+    def other():
+        seen["before"] = numerics.get_distance_contraction()
+        with numerics.distance_contraction("chain"):
+            seen["inside"] = numerics.get_distance_contraction()
+            gate1.set()
+            gate2.wait(10)
+            seen["inside_after_main_changed"] = numerics.get_distance_contraction()
+        seen["after"] = numerics.get_distance_contraction()
+
+    t = threading.Thread(target=other)
+    with numerics.distance_contraction("off"):
+        t.start()
+        assert gate1.wait(10)
+        assert numerics.get_distance_contraction() == "off"          # the other thread's "chain" is its own
+        with numerics.distance_contraction("nvcc"):                   # nests
+            assert numerics.get_distance_contraction() == "nvcc"
+        assert numerics.get_distance_contraction() == "off"
+        gate2.set()
+        t.join(10)
+    assert numerics.get_distance_contraction() == start
+    assert seen == {"before": start, "inside": "chain", "inside_after_main_changed": "chain", "after": start}
 
 
 def test_mlp_precision_is_per_thread_not_a_process_global():
