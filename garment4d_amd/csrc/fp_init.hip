@@ -11,7 +11,10 @@
 // chunk ahead, one barrier per chunk), as in sa_table.hip; per-layer constants sit in LDS; (index, distance) of tile t + 2, the
 // interpolation weights / offsets and skip rows of tile t + 1 are prepared while tile t computes, and tile t + 1's starting accumulators
 // (the interpolated table) are built during tile t's middle layer, one channel tile per k-step.  Arithmetic and k order are the chain
-// kernel's: bit-identical results.  Measured: 432 us (one k-step per barrier: 449) -- a small gain only; what still bounds it is open.
+// kernel's: bit-identical results.  Measured: 432 us (one k-step per barrier: 449) -- a small gain only.  What still bounds it is open; ruled
+// out by A/B builds on the same box: stores in front of the chunk barriers (issued behind them instead: 444 us), the weight traffic itself
+// (8 waves per workgroup sharing a copy: 484 us -- one lock-stepped workgroup per CU has no partner to interleave with), L2 locality of the
+// table gathers (XCD-contiguous tile ranges: 450 us).
 #include <cstdlib>
 
 #include "mlp_common.h"

@@ -18,7 +18,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline", "latency_ms_single_stream", "repeats", "whole_path", "roofline_mfma"):
+              "config", "roofline", "cpu_baseline", "latency_ms_single_stream", "latency_frames_per_s", "latency_ms_one_call", "repeats", "whole_path",
+              "roofline_mfma_all", "roofline_fps", "roofline_hbm", "launches"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["unit"] == "frames/s" and d["value"] > 1000 and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
@@ -26,8 +27,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "latency" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert d["roofline_mfma"]["bound"] == "mfma" and 0.0 < d["roofline_mfma"]["frac"] < 1.0
+    # the dominant launch of a coalesced call is a shared-MLP launch: bound by the fp32 matrix pipe, timed live
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["executed_flops"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 1e-6
+    f = d["roofline_fps"]
+    assert f["bound"] == "latency" and f["peak"] == 8000.0 and f["rounds"] == 1023 and 0.2 < f["us_per_round"] < 2.0
+    assert d["roofline_mfma_all"]["bound"] == "mfma" and 0.0 < d["roofline_mfma_all"]["frac"] < 1.0
+    assert {h["bound"] for h in d["roofline_hbm"]} == {"valu", "hbm"}
+    tab = d["launches"]["table"]
+    assert len(tab) >= 15 and abs(sum(t["us"] for t in tab) - d["launches"]["eager_one_stream_us"]) < 1.0
+    cfg = d["config"]
+    assert cfg["coalesce"] * cfg["frames_per_step"] == cfg["clouds_per_call"] and cfg["calls_in_flight"] >= 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
