@@ -515,6 +515,11 @@ extern "C" int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float 
                                   int nlayers, const unsigned short *const *W, const float *const *scale, const float *const *shift,
                                   const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
                                   int tap_layer, float *tap_out, int tap_ld, g4d_stream_t stream) {
+    if (mode == LOAD_INTERP && known_feats && dist2 && nn_idx && W && scale && shift && Kpad && Cout && relu && out) {   // large launches of config 3's last level: fp_head_bf16.hip (bit-identical)
+        const int rc = fp_head_bf16_try(rows, n, m, C2, C1, known_feats, dist2, nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer,
+                                        tap_out, tap_ld, reinterpret_cast<hipStream_t>(stream));
+        if (rc != -1) return rc;
+    }
     return chain_bf16_impl("g4d_mlp_chain_bf16", 1, mode, rows, K0, X, ldx, N, P, S, C, use_xyz, xyz, new_xyz, feats, idx, n, m, C2, C1, known_feats, skip,
                            dist2, nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer, tap_out, tap_ld, stream);
 }

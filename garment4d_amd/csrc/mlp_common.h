@@ -79,6 +79,11 @@ int fp_init_try(long long rows, int n, int m, int C1, const float *skip, const f
                 const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, float *out,
                 int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
 
+// fp_head_bf16.hip: persistent form of g4d_mlp_chain_bf16 (interpolating mode) for the 128 -> 128 -> 64 -> 32 -> <= 16 stack of config 3; -1 = not its kind
+int fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const float *known_feats, const float *dist2, const int *nn_idx, int nlayers,
+                     const unsigned short *const *W, const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
+                     const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
+
 // sa_table.hip: persistent, software-pipelined form of g4d_mlp_chain_group_table_f32 for large launches (same arguments); -1 = not its kind
 int sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld, int Kt,
                  const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,

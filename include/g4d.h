@@ -306,7 +306,7 @@ int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const float *know
 int g4d_transpose_f32(int b, int r, int c, const float *in, float *out, g4d_stream_t stream);
 
 /* Run-time tuning switch of the large-launch kernels: keys "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "fp_table_persistent",
- * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "gemm_tile", "gemm_tile_min_rows" (each also an environment variable G4D_<KEY IN UPPER CASE>, read on first use).
+ * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "gemm_tile", "gemm_tile_min_rows" (each also an environment variable G4D_<KEY IN UPPER CASE>, read on first use).
  * Process-wide; for A/B measurements and tests -- every setting computes the same bits. */
 int g4d_tuning_set(const char *key, long long value);
 

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def tuning(**kv):
     """g4d_tuning_set for the duration of the block; restores the defaults of this file's keys afterwards."""
     defaults = {"sa_table_persistent": 1, "sa_table_min_rows": 262144, "sa_table_128": 1, "fp_table_persistent": 1, "fp_table_min_rows": 262144,
-                "gemm_tile": 1, "gemm_tile_min_rows": 32768, "fp_init_persistent": 1, "fp_init_min_rows": 131072}
+                "gemm_tile": 1, "gemm_tile_min_rows": 32768, "fp_init_persistent": 1, "fp_init_min_rows": 131072, "fp_head_bf16_persistent": 1, "fp_head_bf16_min_rows": 262144}
     try:
         for k, v in kv.items():
             _lib.call("g4d_tuning_set", k.encode(), int(v))
@@ -155,3 +155,25 @@ def test_fp_init_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, also):
     assert isinstance(outs[1], tuple) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     want = fp(unknown, known, fused.to_channel_major(skip), fused.to_channel_major(kf))
     np.testing.assert_allclose(fused.to_channel_major(outs[1][0]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 8192, 1024), (3, 5000, 300), (1, 4100, 257)])
+def test_fp_head_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, n, m):
+    """Config 3's last FP level + head (bf16 operands: interpolated 128 -> 128 -> 64 -> 32 -> 7): csrc/fp_head_bf16.hip against the bf16
+    register-chain kernel, bit for bit; n = 5000 / 4100: 16-row tiles straddle clouds, the last tile is partial."""
+    torch.manual_seed(n)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 128, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    head = _seed_bn(torch.nn.Sequential(pt_utils.Conv1d(64, 32, bn=True), torch.nn.Dropout(), pt_utils.Conv1d(32, 7, activation=None)))
+    outs = {}
+    with torch.no_grad(), fused.precision("bf16"):
+        for on in (0, 1):
+            with tuning(fp_head_bf16_persistent=on, fp_head_bf16_min_rows=0):
+                outs[on] = fused.fp_forward(fp, unknown, known, None, kf, head=head)
+    assert torch.equal(outs[0][0], outs[1][0]), "FP features differ"
+    assert torch.equal(outs[0][1], outs[1][1]), "head outputs differ"
+    feats = fp(unknown, known, None, fused.to_channel_major(kf))          # fp32 module: the bf16 result is close, not equal
+    scale = float(feats.abs().max())
+    assert float((fused.to_channel_major(outs[1][0]) - feats).abs().max()) <= 3e-2 * scale
