@@ -49,6 +49,7 @@ SIGNATURES = {
     "g4d_pool_rows_f32": [_I, _I, _I, _vp, _I, _vp, _I, _I, _I, _vp],
     "g4d_transpose_f32": [_I, _I, _I, _vp, _vp, _vp],
     "g4d_copy_segments_f32": [_I, _vp, _vp, _vp, _vp],
+    "g4d_linear_interp_add_f32": [_LL, _I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_tuning_set": [ctypes.c_char_p, _LL],
     "g4d_interp_concat_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_spmm_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp],

@@ -147,7 +147,7 @@ bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc) {
     static const int enabled = [] { const char *e = getenv("G4D_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     static const long long min_rows = [] { const char *e = getenv("G4D_GEMM_STREAM_MIN_ROWS"); return e ? atoll(e) : 65536ll; }();
     const int cpad = (a.Cout + 63) / 64 * 64;   // the packed weight / scale / shift are padded to 64 channels
-    if (!enabled || a.pool != 0 || a.rows < min_rows || cpad % GN != 0 || a.Kpad > 128) return false;
+    if (!enabled || a.pool != 0 || a.rows < min_rows || cpad % GN != 0 || a.Kpad > 128 || a.tab) return false;   // (tab: the interpolate-add epilogue lives in mlp.hip / gemm_tile.hip)
     static unsigned long long attr = 0;
     const int lds = (GM + GN) * GLD * (int)sizeof(float);
     static unsigned long long attr2 = 0;

@@ -96,6 +96,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
         __syncthreads();
     }
     // epilogue.  C/D layout of the 16x16 MFMA: column (channel) = lane & 15, rows = (lane >> 4) * 4 + reg
+    if (a.tab) {   // + three_interpolate(tab) of the row (g4d_linear_interp_add_f32): as linear_kernel, added to the finished contraction
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const InterpRow c = interp_row(a, min(row0 + wr * 64 + i * 16 + fq * 4 + r, a.rows - 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = acc[i][j][r] + interp_at(a, c, min(n0 + wc * 64 + j * 16 + fi, a.Cout - 1));
+            }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ch = n0 + wc * 64 + j * 16 + fi;
@@ -120,7 +130,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
 bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
     const int enabled = (int)tuning("gemm_tile", 1);
     const long long min_rows = tuning("gemm_tile_min_rows", 32768);
-    if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < 256 || a.Cout < 256 || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
+    if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < (a.tab ? 128 : 256) || a.Cout < 256 || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
     const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
     static unsigned long long attr = 0;
     *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_tile_kernel), lds, attr, "g4d_linear_f32(tile)");

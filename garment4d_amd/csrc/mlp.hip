@@ -111,6 +111,18 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinearArgs a) {
 
     // epilogue.  C/D layout of 16x16 MFMA: column (channel) = lane & 15, rows = (lane >> 4) * 4 + reg.
     const int ch = n0 + wave * 16 + fi;
+    if constexpr (MODE == LOAD_DIRECT) {
+        if (a.tab) {   // wave-uniform: + three_interpolate(tab) of the row (g4d_linear_interp_add_f32), added to the finished contraction
+            const int chc = min(ch, a.Cout - 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const InterpRow c = interp_row(a, min(row0 + mt * 16 + fq * 4 + r, a.rows - 1));
+                    acc[mt][r] = acc[mt][r] + interp_at(a, c, chc);
+                }
+        }
+    }
     const float sc = a.scale[ch], sh = a.shift[ch];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -248,6 +260,20 @@ extern "C" int g4d_linear_f32(long long rows, int K, int Kpad, int Cout, const f
     LinearArgs a = {};
     a.rows = (int)rows; a.K = K; a.Kpad = Kpad; a.Cout = Cout; a.W = W; a.scale = scale; a.shift = shift; a.relu = relu;
     a.out = out; a.ldo = ldo; a.col0 = col0; a.pool = pool; a.S = pool ? s_pool : 1; a.X = X; a.ldx = ldx;
+    return launch_linear(LOAD_DIRECT, a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int g4d_linear_interp_add_f32(long long rows, int n, int m, int K, int Kpad, int Cout, const float *X, int ldx, const float *W, const float *table,
+                                         int tab_ld, const float *dist2, const int *nn_idx, const float *scale, const float *shift, int relu, float *out, int ldo,
+                                         int col0, g4d_stream_t stream) {
+    if (int rc = check_common("g4d_linear_interp_add_f32", rows, K, Kpad, Cout, W, scale, shift, out, ldo, col0, 0, 1)) return rc;
+    if (rows == 0) return G4D_OK;
+    G4D_REQUIRE(X && ldx >= K && table && dist2 && nn_idx && n > 0 && m > 0 && rows % n == 0 && tab_ld >= Cout,
+                "g4d_linear_interp_add_f32: needs X, a table at least as wide as the output, the 3-NN results and whole clouds");
+    LinearArgs a = {};
+    a.rows = (int)rows; a.K = K; a.Kpad = Kpad; a.Cout = Cout; a.W = W; a.scale = scale; a.shift = shift; a.relu = relu;
+    a.out = out; a.ldo = ldo; a.col0 = col0; a.pool = 0; a.S = 1; a.X = X; a.ldx = ldx;
+    a.tab = table; a.tab_ld = tab_ld; a.dist2 = dist2; a.nn_idx = nn_idx; a.n = n; a.m = m;
     return launch_linear(LOAD_DIRECT, a, reinterpret_cast<hipStream_t>(stream));
 }
 

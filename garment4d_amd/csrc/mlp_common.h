@@ -63,6 +63,25 @@ __device__ __forceinline__ int out_row(const LinearArgs &a, int row) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// DIRECT launches with `tab` set (g4d_linear_interp_add_f32): the GEMM result of a row gets three_interpolate(tab) of that row added before the
+// affine -- the known-feature part of a feature-propagation level's first layer, pre-contracted over the m known rows (conv(sum_i w_i f_i) =
+// sum_i w_i conv(f_i); pointnet2_modules.py:139-149).  Weights as make_ctx<LOAD_INTERP> computes them; offsets in floats into `tab`.
+struct InterpRow { float w0, w1, w2; size_t k0, k1, k2; };
+__device__ __forceinline__ InterpRow interp_row(const LinearArgs &a, int row) {
+    InterpRow c;
+    const int b = row / a.n;
+    const int *ix = a.nn_idx + (size_t)row * 3;
+    const float *d2 = a.dist2 + (size_t)row * 3;
+    const float r0 = 1.0f / (__fsqrt_rn(d2[0]) + 1e-8f), r1 = 1.0f / (__fsqrt_rn(d2[1]) + 1e-8f), r2 = 1.0f / (__fsqrt_rn(d2[2]) + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    c.w0 = r0 / norm; c.w1 = r1 / norm; c.w2 = r2 / norm;
+    c.k0 = ((size_t)b * a.m + ix[0]) * a.tab_ld; c.k1 = ((size_t)b * a.m + ix[1]) * a.tab_ld; c.k2 = ((size_t)b * a.m + ix[2]) * a.tab_ld;
+    return c;
+}
+__device__ __forceinline__ float interp_at(const LinearArgs &a, const InterpRow &c, int ch) {
+    return c.w0 * a.tab[c.k0 + ch] + c.w1 * a.tab[c.k1 + ch] + c.w2 * a.tab[c.k2 + ch];
+}
+
 // gemm_stream.hip: persistent row-streaming GEMM for tall DIRECT launches; returns false when the launch is not its kind
 bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc);
 // gemm_tile.hip: 128 x 128-tile GEMM for tall DIRECT launches with a deep contraction; same contract

@@ -814,6 +814,7 @@ def three_nn_multi(pairs):
 FP_WIDE_FUSED = os.environ.get("G4D_FP_WIDE_FUSED", "0") != "0"   # wide FP level: interpolation inside the first layer's loader (one launch fewer; A/B switch)
 FP_CELLS = os.environ.get("G4D_FP_CELLS", "1") != "0"   # last FP level: rows walked in the cell order of the unknown cloud's ball grid
 FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
+FP_WIDE_TABLE = os.environ.get("G4D_FP_WIDE_TABLE", "1") != "0"   # wide FP levels with skip features: known-feature columns pre-contracted, interpolation added in the GEMM's epilogue
 
 
 def fp_table_layer(fp, C1, C2, head):
@@ -941,11 +942,34 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
             return out, logits
     if USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
+    elif (layers[0].Cout > 64 and FP_WIDE_TABLE and C1 > 0 and C1 % 4 == 0 and m < n and current_precision() == "fp32"):
+        # wide FP level (FP level 3 of the encoder: [384 + 192 -> 512 -> 256] over 256 points per cloud).  Split first layer:
+        #   W [interp(f) ; s] = interp(Wa f) + Wb s
+        # -- the known-feature columns are contracted over the m KNOWN rows (a quarter of the n rows: half of the level's flops gone), the skip
+        # columns run as a plain GEMM on the skip features themselves and the interpolated table is added in that GEMM's epilogue
+        # (g4d_linear_interp_add_f32); no interpolated + concatenated matrix is written.  Round 2 measured this at 8 clouds (one more launch on
+        # 2048 rows: 45.3 -> 47.1 us alone) and dropped it; at the executor's 240 clouds per call the level is flop-bound and it wins
+        # (471 -> ~200 us).  Taken at EVERY batch size: a cloud's result must not depend on how many clouds share the call.
+        hit = getattr(fp, "_g4d_fp_split", None)
+        if hit is None or hit[0] != id(layers[0]):
+            L0 = layers[0]
+            with torch.no_grad():
+                W0 = L0.W[:L0.Cout, :L0.K]
+                ones, zeros = torch.ones(L0.Cout, device=W0.device), torch.zeros(L0.Cout, device=W0.device)
+                La = PackedLayer(W0[:, :C2].contiguous(), ones, zeros, relu=False)
+                Lb = PackedLayer(W0[:, C2:C2 + C1].contiguous(), L0.scale[:L0.Cout], L0.shift[:L0.Cout], relu=bool(L0.relu))
+            hit = (id(L0), La, Lb, L0)
+            fp._g4d_fp_split = hit
+        _, La, Lb, _ = hit
+        table = linear(known_feats_pm.view(B * m, C2), La)
+        h = out.view(B * n, -1) if len(layers) == 1 else torch.empty((B * n, Lb.Cout), dtype=torch.float32, device=unknown.device)
+        _lib.call("g4d_linear_interp_add_f32", B * n, n, m, C1, Lb.Kpad, Lb.Cout, _chk(unknow_feats_pm).data_ptr(), C1, Lb.W.data_ptr(), table.data_ptr(),
+                  table.shape[-1], dist2.data_ptr(), nn_idx.data_ptr(), Lb.scale.data_ptr(), Lb.shift.data_ptr(), Lb.relu, h.data_ptr(), h.shape[-1], 0, stream)
+        for i, L in enumerate(layers[1:], 1):
+            h = linear(h, L, out=out.view(B * n, -1) if i == len(layers) - 1 else None)
     elif layers[0].Cout > 64 and not FP_WIDE_FUSED:
-        # wide FP level: every 64-channel tile of the first layer would redo the interpolation -> materialise the
-        # interpolated + concatenated rows once (a few MB), then plain DIRECT layers.  (Splitting the first layer here too -- table over
-        # the known rows, its interpolation added in the LDS-tiled kernel's epilogue, skip columns only on the matrix pipe: 35 % fewer
-        # flops but one more launch on 2048 rows -- measured 45.3 -> 47.1 us alone, 27.0 -> 27.3 us per step with 16 in flight: not kept.)
+        # wide FP level without skip features / other precisions: every 64-channel tile of the first layer would redo the interpolation ->
+        # materialise the interpolated + concatenated rows once (a few MB), then plain DIRECT layers.
         x = torch.empty((B * n, C2 + C1), dtype=torch.float32, device=unknown.device)
         _lib.call("g4d_interp_concat_f32", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm), dist2.data_ptr(),
                   nn_idx.data_ptr(), x.data_ptr(), stream)

@@ -305,6 +305,16 @@ int g4d_interp_concat_f32(int b, int n, int m, int c2, int c1, const float *know
 /* batched matrix transpose (b, r, c) -> (b, c, r): channel-major <-> point-major at the API boundary. */
 int g4d_transpose_f32(int b, int r, int c, const float *in, float *out, g4d_stream_t stream);
 
+/* Wide feature-propagation level, first layer with its known-feature part pre-contracted (pointnet2_modules.py:127-156):
+ *   out = act((X . W^T + three_interpolate(table)) * scale + shift)
+ * X (rows, ldx >= K): the skip features; W (CoutPad64, Kpad) row-major: the skip columns of the layer's weight; table (B*m rows, stride tab_ld >=
+ * Cout): the known features times the remaining columns (one small g4d_linear_f32 over the m known rows instead of the n interpolated ones);
+ * dist2 / nn_idx (rows, 3) as g4d_three_nn_f32 returns them; rows = B*n.  The interpolation is added to the finished contraction, then the
+ * affine and the ReLU.  Same kernels, k order and tiling as g4d_linear_f32. */
+int g4d_linear_interp_add_f32(long long rows, int n, int m, int K, int Kpad, int Cout, const float *X, int ldx, const float *W, const float *table,
+                              int tab_ld, const float *dist2, const int *nn_idx, const float *scale, const float *shift, int relu, float *out, int ldo,
+                              int col0, g4d_stream_t stream);
+
 /* Run-time tuning switch of the large-launch kernels: keys "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "fp_table_persistent",
  * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "gemm_tile", "gemm_tile_min_rows" (each also an environment variable G4D_<KEY IN UPPER CASE>, read on first use).
  * Process-wide; for A/B measurements and tests -- every setting computes the same bits. */

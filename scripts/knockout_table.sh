@@ -1,8 +1,8 @@
 #!/bin/bash
-# What each launch (group) of the cfg2 step costs the 16-stream mix: bench.py with those C-ABI calls skipped (scripts/exp_knockout.py,
+# What each launch (group) of the cfg2 step costs the bench's mix (round 4: 30 steps per call, 3 calls in flight): bench.py with those C-ABI calls skipped (scripts/exp_knockout.py,
 # diagnostic -- not a throughput number); the drop in us/step against `base` is the marginal cost.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-run() { name=$1; k=$2; KNOCK="$k" python scripts/exp_knockout.py --steps 160 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s %8.1f us/step  %6.0f frames/s' % ('$name', d['ms_per_step']*1e3, d['value']))"; }
+run() { name=$1; k=$2; KNOCK="$k" python scripts/exp_knockout.py --steps 120 --min-seconds 1.5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s %8.1f us/step  %6.0f frames/s' % ('$name', d['ms_per_step']*1e3, d['value']))"; }
 L=g4d_linear_f32; G=g4d_mlp_chain_group_table_f32
 run "base (nothing skipped)" ""
 run "without SA1 MLP pair" g4d_sa_xyz_mlp3_pair_f32

@@ -177,3 +177,29 @@ def test_fp_head_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, n, m):
     feats = fp(unknown, known, None, fused.to_channel_major(kf))          # fp32 module: the bf16 result is close, not equal
     scale = float(feats.abs().max())
     assert float((fused.to_channel_major(outs[1][0]) - feats).abs().max()) <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(3, 256, 64, 384, 192, [576, 512, 256]), (2, 1000, 100, 128, 64, [192, 256, 128]), (1, 333, 40, 96, 100, [196, 384])])
+def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, monkeypatch):
+    """Wide FP levels with skip features (FP level 3 of the encoder): W [interp(f) ; s] = interp(Wa f) + Wb s -- table over the known rows, skip
+    columns as a GEMM with the interpolated table added in its epilogue (g4d_linear_interp_add_f32).  Against the materialised route and the
+    op-by-op module at 1e-5; the 128 x 128-tile kernel and the 64 x 64 one must agree bit for bit on it."""
+    torch.manual_seed(n + C1)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, C2, device="cuda")
+    skip = torch.randn(B, n, C1, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=list(mlp)))
+    outs = {}
+    with torch.no_grad():
+        for on in (False, True):
+            monkeypatch.setattr(fused, "FP_WIDE_TABLE", on)
+            outs[on] = fused.fp_forward(fp, unknown, known, skip, kf)
+        with tuning(gemm_tile=1, gemm_tile_min_rows=0):
+            tiled = fused.fp_forward(fp, unknown, known, skip, kf)
+        with tuning(gemm_tile=0):
+            small = fused.fp_forward(fp, unknown, known, skip, kf)
+    assert torch.equal(tiled, small)
+    want = fp(unknown, known, fused.to_channel_major(skip), fused.to_channel_major(kf))
+    np.testing.assert_allclose(outs[True].cpu().numpy(), outs[False].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
