@@ -14,9 +14,28 @@ def _sub(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def calc_segmentation_results(x, sem_logits, n, target, feature_pm):
-    """mesh_encoder.py:109-125.  x (F,N,3), sem_logits (F,N,classes), feature_pm (F,N,C) -> (F,n,3), (F,n,C)."""
-    labels = np.argmax(sem_logits, axis=2)
+def admissible_labels(sem_logits, labels, tol=4e-5):
+    """The class decision is an arg-max over fp32 logits that two correct implementations only agree on to ~1e-5: a point whose two best
+    logits are closer than that may be labelled either way (the reference's own label there depends on the GEMM's summation order).
+    `labels` (F,N): decisions taken by the implementation under test.  Each one that differs from this oracle's arg-max is CHECKED: the
+    oracle's logit of the chosen class must lie within tol * (1 + |best logit|) of the best one, otherwise AssertionError.  Returns
+    (labels to use downstream, number of such near-tie flips)."""
+    own = np.argmax(sem_logits, axis=2)
+    labels = np.asarray(labels)
+    diff = labels != own
+    if diff.any():
+        best = np.take_along_axis(sem_logits, own[..., None], 2)[..., 0][diff]
+        chosen = np.take_along_axis(sem_logits, labels[..., None], 2)[..., 0][diff]
+        gap = (best - chosen) / (1.0 + np.abs(best))
+        assert (gap <= tol).all(), f"class decision differs where the logits are NOT tied: largest gap {gap.max():.3g} (tolerance {tol})"
+    return np.where(diff, labels, own), int(diff.sum())
+
+
+def calc_segmentation_results(x, sem_logits, n, target, feature_pm, labels=None):
+    """mesh_encoder.py:109-125.  x (F,N,3), sem_logits (F,N,classes), feature_pm (F,N,C) -> (F,n,3), (F,n,C).
+    labels: decisions already checked by admissible_labels() (None = the oracle's own arg-max)."""
+    if labels is None:
+        labels = np.argmax(sem_logits, axis=2)
     gv = np.zeros((x.shape[0], n, 3), F32)
     gf = np.zeros((x.shape[0], n, feature_pm.shape[-1]), F32)
     for i in range(x.shape[0]):
@@ -39,12 +58,17 @@ def conv_bn_head(x, sd, eps=1e-5):
     return h
 
 
-def garment_encoder_forward(sd, x, nbatch, T, target, pca):
-    """x (nbatch*T, N, 3); sd keys relative to PCA_garment_encoder.  Returns dict (features channel-major like the reference)."""
+def garment_encoder_forward(sd, x, nbatch, T, target, pca, decisions=None):
+    """x (nbatch*T, N, 3); sd keys relative to PCA_garment_encoder.  Returns dict (features channel-major like the reference).
+    decisions (F,N) int or None: the class labels of the implementation under test, used downstream where (and only where)
+    admissible_labels() finds them to be near-ties of this oracle's logits; out["decision_flips"] counts them."""
     N = x.shape[1]
     sem_logits, l_f, l_xyz = MO.encoder_forward(x, _sub(sd, "pointnet."))
-    out = {"sem_logits": sem_logits, "feature_list": l_f, "xyz_list": l_xyz}
-    gv, gf = calc_segmentation_results(l_xyz[0], sem_logits, N // 4, target, np.transpose(l_f[0], (0, 2, 1)))
+    out = {"sem_logits": sem_logits, "feature_list": l_f, "xyz_list": l_xyz, "decision_flips": 0}
+    labels = None
+    if decisions is not None:
+        labels, out["decision_flips"] = admissible_labels(sem_logits, decisions)
+    gv, gf = calc_segmentation_results(l_xyz[0], sem_logits, N // 4, target, np.transpose(l_f[0], (0, 2, 1)), labels)
     lx, lf = [gv], [np.ascontiguousarray(np.transpose(gf, (0, 2, 1)))]
     for i, (npoint, radii, ns) in enumerate([(512, [0.05, 0.1], [16, 32]), (64, [0.2, 0.4], [32, 64])]):
         nx, nf = MO.sa_module(lx[-1], lf[-1], npoint, radii, ns, _sub(sd, f"GarmentEncoder.{i}."))
@@ -73,13 +97,13 @@ def compute_vnorms(verts, faces):
     return vn.astype(F32)
 
 
-def full_forward(sd, x, batch, body, garment_name, pca, template_faces, lbs_k, iteration=3, return_ball_idx=False):
+def full_forward(sd, x, batch, body, garment_name, pca, template_faces, lbs_k, iteration=3, return_ball_idx=False, decisions=None):
     """PCALBSGarmentUseSegEncoderSeg.forward.  x (nbatch,T,N,3); batch: numpy arrays under the reference's keys;
-    body = dict(parents, faces)."""
+    body = dict(parents, faces).  decisions: see garment_encoder_forward."""
     from . import gcn_oracle as GO
     label = {"Body": 1, "Skirt": 2, "Dress": 3, "Jumpsuit": 4, "Top": 5, "Trousers": 6, "Tshirt": 7}[garment_name] - 1
     nbatch, T, N = x.shape[:3]
-    enc = garment_encoder_forward(_sub(sd, "PCA_garment_encoder."), x.reshape(nbatch * T, N, 3), nbatch, T, label, pca)
+    enc = garment_encoder_forward(_sub(sd, "PCA_garment_encoder."), x.reshape(nbatch * T, N, 3), nbatch, T, label, pca, decisions)
     nv = enc["tpose_garment"].shape[1]
     adj_old = GO.adjacency_old_from_faces(template_faces, nv)
     adj = GO.adjacency_from_faces(template_faces, nv)

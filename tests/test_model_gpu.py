@@ -105,7 +105,13 @@ def test_full_forward_vs_oracle(garment, lbs_k, size):
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     with torch.no_grad():
         out = m(dev(scene["x"]), _body_model(scene["body"]), {k: dev(v) for k, v in scene["batch"].items()})
-    want = MOr.full_forward(sd, scene["x"], scene["batch"], scene["body"], garment, scene["pca"], scene["template"][1], lbs_k, return_ball_idx=True)
+    # The class decision is an arg-max over logits that agree to 1e-5 only: the oracle takes the product's label at a point where ITS
+    # OWN two best logits are tied within that tolerance (checked per point, AssertionError otherwise), so that everything downstream of
+    # the segmentation is compared on the same garment points.  245760 points per clip: a handful of such near-ties at most.
+    decisions = out["sem_logits"].argmax(2).cpu().numpy()
+    want = MOr.full_forward(sd, scene["x"], scene["batch"], scene["body"], garment, scene["pca"], scene["template"][1], lbs_k, return_ball_idx=True,
+                            decisions=decisions)
+    assert want["decision_flips"] <= 4, want["decision_flips"]
 
     def close(a, b, tol=1e-5):   # north_star: 1e-5 fp32, elementwise
         np.testing.assert_allclose(a.cpu().numpy() if torch.is_tensor(a) else a, b, rtol=tol, atol=tol)

@@ -157,3 +157,20 @@ def test_gcn(golden_gcn):
     np.testing.assert_allclose(gcn_oracle.graph_convolution(g["x"], g["W"], g["b"], adj, ismlp=True), g["y_mlp"], **TOL)
     np.testing.assert_allclose(gcn_oracle.graph_convolution(g["x"][0], g["W"], g["b"], adj), g["y2d"], **TOL)
     np.testing.assert_allclose(gcn_oracle.graph_convolution(g["x"], g["W_nb"], None, adj), g["y_nb"], **TOL)
+
+
+def test_admissible_labels_accepts_near_ties_only():
+    """The model oracle lets the implementation under test decide the class of a point only where its own two best logits are tied
+    within the fp32 tolerance (tests/test_model_gpu.py uses this so that a near-tie does not derail everything downstream)."""
+    from oracle import model_oracle as MOr
+    logits = np.full((1, 4, 3), -9.0, np.float32)
+    logits[0, :, 0] = [2.0, 2.0, 2.0, -5.0]
+    logits[0, :, 1] = [2.0 - 1e-6, 1.0, 2.0 + 1e-6, -6.0]
+    own = np.argmax(logits, 2)
+    assert own.tolist() == [[0, 0, 1, 0]]
+    lab, flips = MOr.admissible_labels(logits, np.array([[1, 0, 0, 0]]))     # two near-ties taken the other way
+    assert lab.tolist() == [[1, 0, 0, 0]] and flips == 2
+    lab, flips = MOr.admissible_labels(logits, own)
+    assert flips == 0 and np.array_equal(lab, own)
+    with pytest.raises(AssertionError):
+        MOr.admissible_labels(logits, np.array([[0, 1, 1, 0]]))              # point 1: a full unit apart
