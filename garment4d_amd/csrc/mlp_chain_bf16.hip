@@ -520,6 +520,11 @@ extern "C" int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float 
                                         tap_out, tap_ld, reinterpret_cast<hipStream_t>(stream));
         if (rc != -1) return rc;
     }
+    if (mode == LOAD_GROUP && W && scale && shift && Kpad && Cout && relu && out) {   // large launches of config 3's SA levels: sa_group_bf16.hip (bit-identical)
+        const int rc = sa_group_bf16_try(rows, N, P, S, C, use_xyz, xyz, new_xyz, feats, idx, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0,
+                                         tap_out, reinterpret_cast<hipStream_t>(stream));
+        if (rc != -1) return rc;
+    }
     return chain_bf16_impl("g4d_mlp_chain_bf16", 1, mode, rows, K0, X, ldx, N, P, S, C, use_xyz, xyz, new_xyz, feats, idx, n, m, C2, C1, known_feats, skip,
                            dist2, nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer, tap_out, tap_ld, stream);
 }

@@ -103,6 +103,11 @@ int fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const float *
                      const unsigned short *const *W, const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
                      const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
 
+// sa_group_bf16.hip: persistent form of g4d_mlp_chain_bf16 (grouping mode) for the encoder's three-layer SA stacks
+int sa_group_bf16_try(long long rows, int N, int P, int S, int C, int use_xyz, const float *xyz, const float *new_xyz, const float *feats,
+                      const int *idx, int nlayers, const unsigned short *const *W, const float *const *scale, const float *const *shift,
+                      const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, float *tap_out, hipStream_t st);
+
 // sa_table.hip: persistent, software-pipelined form of g4d_mlp_chain_group_table_f32 for large launches (same arguments); -1 = not its kind
 int sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld, int Kt,
                  const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 def tuning(**kv):
     """g4d_tuning_set for the duration of the block; restores the defaults of this file's keys afterwards."""
     defaults = {"sa_table_persistent": 1, "sa_table_min_rows": 262144, "sa_table_128": 1, "fp_table_persistent": 1, "fp_table_min_rows": 262144,
-                "gemm_tile": 1, "gemm_tile_min_rows": 32768, "fp_init_persistent": 1, "fp_init_min_rows": 131072, "fp_head_bf16_persistent": 1, "fp_head_bf16_min_rows": 262144}
+                "gemm_tile": 1, "gemm_tile_min_rows": 32768, "fp_init_persistent": 1, "fp_init_min_rows": 131072, "fp_head_bf16_persistent": 1, "fp_head_bf16_min_rows": 262144,
+                "sa_group_bf16_persistent": 1, "sa_group_bf16_min_rows": 262144}
     try:
         for k, v in kv.items():
             _lib.call("g4d_tuning_set", k.encode(), int(v))
@@ -177,6 +178,29 @@ def test_fp_head_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, n, m):
     feats = fp(unknown, known, None, fused.to_channel_major(kf))          # fp32 module: the bf16 result is close, not equal
     scale = float(feats.abs().max())
     assert float((fused.to_channel_major(outs[1][0]) - feats).abs().max()) <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("B,N,P,C,mlps,nsamples", [
+    (3, 2000, 255, 0, [[0, 16, 16, 32], [0, 32, 32, 64]], [16, 32]),           # SA level 1 (coordinates only); 255 centroids: an odd number of neighbourhoods
+    (3, 1024, 253, 96, [[96, 32, 32, 64], [96, 64, 64, 128]], [16, 32]),       # SA level 2: 99 columns = three whole k-steps of features + one holding the last three
+    (5, 256, 61, 192, [[192, 64, 64, 128], [192, 128, 128, 256]], [32, 64]),   # SA level 3: 195 columns; 64 samples = four tiles with a running maximum; 8-wave workgroups
+    (1, 100, 3, 192, [[192, 128, 128, 256]], [64]),                            # fewer neighbourhoods than waves of ONE workgroup
+])
+def test_sa_group_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, mlps, nsamples):
+    """Config 3's SA levels (bf16 operands, rows gathered whole): csrc/sa_group_bf16.hip against the bf16 register-chain kernel, bit for bit."""
+    torch.manual_seed(B * 10 + C)
+    xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=N)).cuda()
+    fpm = torch.randn(B, N, C, device="cuda") if C else None
+    sa = _seed_bn(PM.PointnetSAModuleMSG(npoint=P, radii=[0.2 + 0.1 * i for i in range(len(mlps))], nsamples=nsamples, mlps=[list(m) for m in mlps]))
+    outs = {}
+    with torch.no_grad(), fused.precision("bf16"):
+        for on in (0, 1):
+            with tuning(sa_group_bf16_persistent=on, sa_group_bf16_min_rows=0):
+                outs[on] = fused.sa_forward(sa, xyz, fpm)[1]
+    assert torch.equal(outs[0], outs[1])
+    want = sa(xyz, fused.to_channel_major(fpm) if C else None)[1]               # fp32 module: the bf16 result is close, not equal
+    scale = float(want.abs().max())
+    assert float((fused.to_channel_major(outs[1]) - want).abs().max()) <= 3e-2 * scale
 
 
 @pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(3, 256, 64, 384, 192, [576, 512, 256]), (2, 1000, 100, 128, 64, [192, 256, 128]), (1, 333, 40, 96, 100, [196, 384])])
