@@ -185,6 +185,15 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     chain_desc.append((f"FP level 2: skip columns {c1_fp2} -> {fp2[0][1]} (interpolated table as accumulator start) -> {fp2[1][1]} -> {fp1[0][1]} (the last level's table)",
                        [(c1_fp2, fp2[0][1])] + fp2[1:] + [(fp1[0][0], fp1[0][1])], fp2))
     chain_desc.append((f"FP level 1 + head: interpolated {fp1[0][1]}-wide table -> " + " -> ".join(str(c) for _, c in fp1[1:] + head), fp1[1:] + head, fp1 + head))
+    if precision != "fp32":   # bf16 operands: no pre-contracted tables -- every stack runs whole, one launch per scale / level, in this order
+        chain_desc = []
+        for li in (0, 1, 2):
+            for si, mlp in enumerate(SA[li].mlps):
+                st = pk(mlp)
+                chain_desc.append((f"SA level {li + 1} scale {si}: grouped rows x " + " -> ".join(str(c) for c in [st[0][0]] + [c for _, c in st]) + " + max pool", st, st))
+        for li, extra in ((2, []), (1, []), (0, head)):
+            st = pk(FP[li].mlp) + extra
+            chain_desc.append((f"FP level {li + 1}" + (" + head" if extra else "") + ": interpolated + skip columns " + " -> ".join(str(c) for c in [st[0][0]] + [c for _, c in st]), st, st))
     for i, (nm, iv, t_us) in enumerate(zip(names, ints, us)):
         row = {"entry": nm, "us": t_us, "us_per_step": t_us / kco}
         if nm == "g4d_fps_gather_grid_f32":
@@ -203,10 +212,10 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             row.update(what=f"{rows_} rows x {k_} -> {cout_} (first-layer table / wide FP level)", bound="mfma", executed_flops=2.0 * rows_ * k_ * cout_,
                        algorithmic_flops=2.0 * rows_ * k_ * cout_)
         elif nm in ("g4d_mlp_chain_group_table_f32", "g4d_mlp_chain_interp_init_f32", "g4d_mlp_chain_table_cells_f32", "g4d_mlp_chain_table_f32", "g4d_mlp_chain_f32",
-                    "g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc) and precision == "fp32":
+                    "g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc):
             desc, layers, full = chain_desc[chain_i]
             chain_i += 1
-            rows_ = iv[0]
+            rows_ = iv[1] if nm in ("g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16", "g4d_mlp_chain_f32") else iv[0]   # (these take the loader mode first)
             row.update(what=desc, bound="mfma", executed_flops=2.0 * rows_ * sum(k * c for k, c in layers), algorithmic_flops=2.0 * rows_ * sum(k * c for k, c in full))
         elif nm in ("g4d_three_nn_cells_sorted_f32", "g4d_three_nn_cells_f32"):
             b_, n_, m_ = iv[0], iv[1], iv[2]
@@ -231,8 +240,13 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     total = sum(us)
     mf = [r for r in rows_out if r.get("bound") == "mfma"]
     roof = {}
-    kernel_of = {"SA level 3 scale 1": "sa_table_kernel<128, 64, 1, false>", "SA level 3 scale 0": "sa_table_kernel<64, 32, 2, true>", "SA level 2 scale 1": "sa_table_kernel<64, 32, 2, true>",
-                 "SA level 2 scale 0": "sa_table_kernel<32, 16, 2, true>", "SA level 1": "sa_xyz_pair_kernel", "FP level 1": "fp_table_head_kernel", "FP level 2": "mlp_chain_kernel<2, 16, 8, 8"}
+    if precision == "fp32":
+        kernel_of = {"SA level 3 scale 1": "sa_table_kernel<128, 64, 1, 2>", "SA level 3 scale 0": "sa_table_kernel<64, 32, 2, 1>", "SA level 2 scale 1": "sa_table_kernel<64, 32, 2, 1>",
+                     "SA level 2 scale 0": "sa_table_kernel<32, 16, 2, 1>", "SA level 1": "sa_xyz_pair_kernel", "FP level 1": "fp_table_head_kernel", "FP level 2": "fp_init_kernel"}
+    else:
+        kernel_of = {"SA level 3 scale 1": "sa_group_bf16_kernel<8, 64, 192, 8>", "SA level 3 scale 0": "sa_group_bf16_kernel<4, 32, 192, 4>", "SA level 2 scale 1": "sa_group_bf16_kernel<4, 32, 96, 4>",
+                     "SA level 2 scale 0": "sa_group_bf16_kernel<2, 16, 96, 4>", "SA level 1 scale 1": "sa_group_bf16_kernel<2, 32, 0, 4>", "SA level 1 scale 0": "sa_group_bf16_kernel<1, 16, 0, 4>",
+                     "FP level 1": "fp_head_bf16_kernel", "FP level 2": "mlp_chain_bf16_kernel<1, 2, 16, 8", "FP level 3": "mlp_stack_bf16_kernel<2>"}
 
     def with_counters(r):
         r = dict(r)

@@ -30,6 +30,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- $STEP 240 4 > $OUT/pmc_$C.log 2>&1
 done
 python $ROOT/scripts/pmc_to_profile.py $OUT/${R}_pmc_hbm_traffic.csv $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv')
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmcb_$C -o p -- $STEP 240 4 bf16 > $OUT/pmcb_$C.log 2>&1
+done
+python $ROOT/scripts/pmc_to_profile.py $OUT/${R}_pmc_hbm_traffic_bf16.csv $(find $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE -name '*counter_collection.csv')
 # 4. SQ counters (matrix-pipe busy, issue stalls, LDS conflicts, instruction mix) at 240 clouds per call, fp32 and bf16
 PMC_CMD="$STEP 240 4" bash $ROOT/scripts/make_pmc_sq.sh $R > $OUT/pmc_sq.log 2>&1
 PMC_SUFFIX=_bf16 PMC_CMD="$STEP 240 4 bf16" bash $ROOT/scripts/make_pmc_sq.sh $R > $OUT/pmc_sq_bf16.log 2>&1
@@ -53,7 +57,10 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('k=%3d clouds/call=%4d calls in flight=%2d clouds in flight=%4d : %7.0f frames/s (%6.1f us/step) | %7.3f ms' % ($1, 8*$1, $2, 8*$1*$2, d['value'], d['ms_per_step']*1e3, d['latency_ms_one_call']))"
   done
 } > $OUT/${R}_coalesce_by_streams.txt
+# 8. which launches of a call run concurrently with which (recorded C-ABI calls replayed alone and in pairs on two streams); per-launch times in bf16
+timeout 600 python scripts/exp_overlap.py 240 2>/dev/null > $OUT/${R}_overlap_pairs_240clouds.txt
+PAIRS="fps_gather_grid:mlp_chain_bf16,fps_gather_grid:three_nn" timeout 600 python scripts/exp_overlap.py 240 bf16 2>/dev/null > $OUT/${R}_launches_240clouds_bf16.txt
 python scripts/time_gemm.py 2>&1 | grep -v amdgpu > $OUT/${R}_gemm_shapes.txt
 python scripts/exp_clock.py 2>&1 | grep -v amdgpu > $OUT/${R}_clock_and_power_by_regime.txt
-rm -rf $OUT/bench $OUT/e240 $OUT/e240b $OUT/e8 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/cfg4 $OUT/cfg5
+rm -rf $OUT/bench $OUT/e240 $OUT/e240b $OUT/e8 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE $OUT/cfg4 $OUT/cfg5
 ls -la $OUT
