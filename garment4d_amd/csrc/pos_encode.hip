@@ -78,14 +78,15 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
         float ex[4][E == 3 ? 1 : (E ? E : 1)];
         f32x4 t[4][2];
     };
+    // (a chunk past the wave's last one is clamped onto the launch's last chunk -- loaded again, never used: a conditional load makes the
+    //  compiler wait for the whole prefetch where the branches join, i.e. at once, and the gathers of a wave then overlap nothing)
     auto load_idx = [&](int chunk, int (&iv)[4]) {
-        const int row0 = chunk << 6;
+        const int row0 = min(chunk, nchunks - 1) << 6;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) iv[mt] = chunk < nchunks ? a.idx[row0 + min(mt * 16 + fi, rows - 1 - row0)] : 0;
+        for (int mt = 0; mt < 4; ++mt) iv[mt] = a.idx[row0 + min(mt * 16 + fi, rows - 1 - row0)];
     };
     auto load_rows = [&](int chunk, const int (&iv)[4], Raw &rw) {
-        if (chunk >= nchunks) return;
-        const int row0 = __builtin_amdgcn_readfirstlane(chunk << 6);
+        const int row0 = __builtin_amdgcn_readfirstlane(min(chunk, nchunks - 1) << 6);
         const int q0 = row0 >> a.logS;                // first query of the chunk (uniform)
         const int f0 = q0 / a.p;                      // its frame: one scalar division per chunk
         const int qnext = (f0 + 1) * a.p;             // first query of the next frame (a chunk touches <= 2 frames, see launcher)
@@ -122,6 +123,7 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
         if (PIPE) {
             load_rows(chunk + stride, iv_next, nxt);       // level 2 of the next chunk
             load_idx(chunk + 2 * stride, iv_next);         // level 1 of the one after
+            __builtin_amdgcn_sched_barrier(0);             // (left alone the scheduler sinks these requests below the chunk's MFMAs, right in front of their use)
         } else {
             load_idx(chunk, iv_next);
             load_rows(chunk, iv_next, cur);
