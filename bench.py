@@ -211,6 +211,10 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             rows_, k_, cout_ = iv[0], iv[1], iv[3]
             row.update(what=f"{rows_} rows x {k_} -> {cout_} (first-layer table / wide FP level)", bound="mfma", executed_flops=2.0 * rows_ * k_ * cout_,
                        algorithmic_flops=2.0 * rows_ * k_ * cout_)
+        elif nm == "g4d_linear_interp_add_f32":
+            rows_, k_, cout_ = iv[0], iv[3], iv[5]
+            row.update(what=f"{rows_} rows x {k_} skip columns -> {cout_}, interpolated table of the known rows added in the epilogue (wide FP level)", bound="mfma",
+                       executed_flops=2.0 * rows_ * k_ * cout_, algorithmic_flops=2.0 * rows_ * k_ * cout_)
         elif nm in ("g4d_mlp_chain_group_table_f32", "g4d_mlp_chain_interp_init_f32", "g4d_mlp_chain_table_cells_f32", "g4d_mlp_chain_table_f32", "g4d_mlp_chain_f32",
                     "g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc):
             desc, layers, full = chain_desc[chain_i]
