@@ -23,7 +23,7 @@ def _eager(model, smpl, cloud, betas, pose, precision):
     return out, v, j
 
 
-@pytest.mark.parametrize("precision,k", [("fp32", 4), ("fp32", 30), ("bf16", 4)])
+@pytest.mark.parametrize("precision,k", [("fp32", 4), ("fp32", 30), ("bf16", 4), ("bf16", 30)])
 def test_coalesced_call_equals_separate_calls_bit_for_bit(precision, k):
     """k B = 8 steps as ONE call on 8 k clouds (what the executor launches; k = 30 is the reference's (8 clips, 30 frames) fold,
     modules/mesh_encoder.py:133) against k separate calls: logits, every feature level, sampled coordinates, skinned vertices and joints."""
