@@ -128,43 +128,57 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
             load_idx(chunk, iv_next);
             load_rows(chunk, iv_next, cur);
         }
-        f32x4 af[4][2];
+        // Layer 1 (VALU) and layer 2 (MFMA) as ONE software pipeline over the 8 k-columns of layer 2: column c (= hidden channel 16 ks + 4 fq + e,
+        // c = 4 ks + e) of all four row tiles is produced while the 8 MFMAs of column c - 1 run.  Issued as two phases (all of layer 1, then
+        // 64 MFMAs) the matrix pipe was 0.48 busy and the VALU 0.4: a wave cannot issue its own VALU work behind a queued MFMA, and the other
+        // wave of the SIMD was as often in the same phase as not.  Interleaved, ~4 VALU instructions fit in the 32 cycles of each MFMA.
+        float in[4][KX];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            float in[KX];
-            in[0] = cur.px[mt].x - cur.pq[mt].x;
-            in[1] = cur.px[mt].y - cur.pq[mt].y;
-            in[2] = cur.px[mt].z - cur.pq[mt].z;
+            in[mt][0] = cur.px[mt].x - cur.pq[mt].x;
+            in[mt][1] = cur.px[mt].y - cur.pq[mt].y;
+            in[mt][2] = cur.px[mt].z - cur.pq[mt].z;
             if (E == 3) {
-                in[3] = cur.pe[mt].x; in[4] = cur.pe[mt].y; in[5] = cur.pe[mt].z;
+                in[mt][3] = cur.pe[mt].x; in[mt][4] = cur.pe[mt].y; in[mt][5] = cur.pe[mt].z;
             } else {
 #pragma unroll
-                for (int e = 0; e < E; ++e) in[3 + e] = cur.ex[mt][e];
-            }
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                float h = TABLE ? cur.t[mt][c8 >> 2][c8 & 3] + bb1[c8] : bb1[c8];
-#pragma unroll
-                for (int i = 0; i < KX; ++i) h = __builtin_fmaf(w1[c8][i], in[i], h);
-                af[mt][c8 >> 2][c8 & 3] = fmaxf(h, 0.f);
+                for (int e = 0; e < E; ++e) in[mt][3 + e] = cur.ex[mt][e];
             }
         }
-        if (PIPE) cur = nxt;
         f32x4 acc[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // k outermost: eight independent accumulators between two MFMAs on the same one (no dependent-issue stalls)
+        float afc[2][4];                                    // [parity of the column][row tile]
+        auto column = [&](int c8, float (&o)[4]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int mt = 0; mt < 4; ++mt) {
+                float h = TABLE ? cur.t[mt][c8 >> 2][c8 & 3] + bb1[c8] : bb1[c8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < KX; ++i) h = __builtin_fmaf(w1[c8][i], in[mt][i], h);
+                o[mt] = fmaxf(h, 0.f);
+            }
+        };
+        column(0, afc[0]);
+        // k ascending per accumulator (ks, e) as before; eight independent accumulators between two MFMAs on the same one
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+        for (int c8 = 0; c8 < 8; ++c8) {
+            if (c8 + 1 < 8) column(c8 + 1, afc[(c8 + 1) & 1]);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][ks][e], bf[ct][ks][e], acc[mt][ct], 0, 0, 0);
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(afc[c8 & 1][mt], bf[ct][c8 >> 2][c8 & 3], acc[mt][ct], 0, 0, 0);
+            if (c8 + 1 < 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {              // one MFMA, then its share of the next column's VALU work
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (4 * (KX + 2) + 7) / 8, 0);
+                }
+            }
+        }
+        if (PIPE) cur = nxt;
         // max over the S rows of each query; acc[mt][ct][r] = row 16 mt + 4 fq + r, channel 16 ct + fi
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
