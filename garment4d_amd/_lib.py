@@ -67,6 +67,8 @@ SIGNATURES = {
                           _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
                            _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
+    "g4d_mlp_chain_cells_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp, _vp],
     "g4d_mlp_chain_bf16x3": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
                            _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],

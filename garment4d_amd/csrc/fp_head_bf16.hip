@@ -48,6 +48,8 @@ struct FpHeadHArgs {
     int relu1, relu2, relu3, relu4, cout4;
     float *out; int ldo;                  // (rows, cout4)
     float *tap; int tap_ld;               // (rows, 64): output of the second layer
+    const unsigned char *perm_rec;        // cell-ordered launch: 16-byte grid records of the unknown cloud, original index in the 4th dword (NULL: rows in place)
+    size_t perm_stride;                   // bytes per cloud
 };
 
 __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) {
@@ -75,16 +77,25 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
           lo4 = a.relu4 ? 0.f : -__builtin_inff();
     asm volatile("" : "+v"(lo1), "+v"(lo2), "+v"(lo3), "+v"(lo4));   // ReLU or not as the floor of one v_max (opaque: else folded back into max + select)
 
-    struct Raw { int i0, i1, i2; float d0, d1, d2; };
-    auto load_raw = [&](int tile) {
-        Raw r;
+    // Cell-ordered launch (perm_rec): launch row r = (cloud b, position p of the cloud's cell-sorted records) works on ORIGINAL row
+    // b n + index(p) -- its search result, its outputs.  Consecutive launch rows are then spatial neighbours and share their nearest known
+    // points (the three 512-byte feature rows per row are what this launch is bound by: 3 GB through L2 per 240-cloud call in input order).
+    // Every row is computed from its own operands only, so the order changes no bit of any output.
+    auto load_orow = [&](int tile) -> int {
         const int row = min(tile * 16 + fi, a.rows - 1);
-        const int *ix = a.nn_idx + (size_t)row * 3;
-        const float *dd = a.dist2 + (size_t)row * 3;
-        r.i0 = ix[0]; r.i1 = ix[1]; r.i2 = ix[2]; r.d0 = dd[0]; r.d1 = dd[1]; r.d2 = dd[2];
+        if (!a.perm_rec) return row;
+        const int b = row / a.n;
+        return b * a.n + reinterpret_cast<const int *>(a.perm_rec + (size_t)b * a.perm_stride)[4 * (row - b * a.n) + 3];
+    };
+    struct Raw { int i0, i1, i2; float d0, d1, d2; int orow; };
+    auto load_raw = [&](int orow) {
+        Raw r;
+        const int *ix = a.nn_idx + (size_t)orow * 3;
+        const float *dd = a.dist2 + (size_t)orow * 3;
+        r.i0 = ix[0]; r.i1 = ix[1]; r.i2 = ix[2]; r.d0 = dd[0]; r.d1 = dd[1]; r.d2 = dd[2]; r.orow = orow;
         return r;
     };
-    struct Ctx { float w0, w1, w2; unsigned k0, k1, k2; };
+    struct Ctx { float w0, w1, w2; unsigned k0, k1, k2; int orow; };
     auto make = [&](int tile, const Raw &r) {   // pointnet2_utils.py:98 sqrt; pointnet2_modules.py:140-142 inverse-distance weights (mlp_common.h make_ctx)
         Ctx c;
         const float r0 = 1.0f / (__fsqrt_rn(r.d0) + 1e-8f), r1 = 1.0f / (__fsqrt_rn(r.d1) + 1e-8f), r2 = 1.0f / (__fsqrt_rn(r.d2) + 1e-8f);
@@ -94,6 +105,7 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
         const int b0 = __builtin_amdgcn_readfirstlane((tile * 16) / a.n);   // a tile touches at most two clouds (n >= 16)
         const unsigned base = (unsigned)(b0 + (row >= (b0 + 1) * a.n ? 1 : 0)) * (unsigned)a.m;
         c.k0 = (base + (unsigned)r.i0) * D0 + g * 4; c.k1 = (base + (unsigned)r.i1) * D0 + g * 4; c.k2 = (base + (unsigned)r.i2) * D0 + g * 4;
+        c.orow = r.orow;
         return c;
     };
     // one 32-column k-step of a row: this lane's columns [32 ks + 4 g, +4) and [32 ks + 16 + 4 g, +4) of the three neighbours' feature rows
@@ -107,14 +119,16 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
     };
     auto wfrag = [&](const unsigned short *sw, int kst, int ct, int ks) -> uint4 { return *reinterpret_cast<const uint4 *>(sw + ((ct * kst + ks) * 64 + lane) * 8); };
 
-    Raw rawn = load_raw(tile_of(0));
+    Raw rawn = load_raw(load_orow(tile_of(0)));
     Ctx cur = make(tile_of(0), rawn);
-    rawn = load_raw(tile_of(1));
+    rawn = load_raw(load_orow(tile_of(1)));
+    int oron = load_orow(tile_of(2));     // three levels ahead: original row -> (index, distance) -> feature rows
     Item ring[2] = {load_item(cur, 0), load_item(cur, 1)};
     for (int it = 0; it < iters; ++it) {
         const int tile = tile_of(it);
         const Ctx nxt = make(tile_of(it + 1), rawn);   // from the loads issued one tile ago
-        rawn = load_raw(tile_of(it + 2));
+        rawn = load_raw(oron);
+        oron = load_orow(tile_of(it + 3));
         // ---- layer 1 (128 -> 128), transposed: lane (fi, g) ends with channels 16 ct + 4 g + r of row fi
         f32x4 a1[T1];
 #pragma unroll
@@ -158,7 +172,7 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
 #pragma unroll
             for (int ct = 0; ct < T2; ++ct) a2[ct] = mfma32h(wfrag(s_w2, KS1, ct, ks), b1[ks], a2[ct]);
         const bool row_ok = tile * 16 + fi < a.rows;
-        const size_t orow = (size_t)min(tile * 16 + fi, a.rows - 1);
+        const size_t orow = (size_t)cur.orow;
         uint4 b2[KS2];
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
@@ -202,7 +216,8 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
             for (int r = 0; r < 4; ++r) {
                 const float y = fmaxf(__builtin_fmaf(o[r], sc, sh), lo4);
                 const int row = tile * 16 + g * 4 + r;
-                if (fi < a.cout4 && row < a.rows) a.out[(size_t)row * a.ldo + fi] = y;
+                const int dst = __builtin_amdgcn_ds_bpermute((g * 4 + r) << 2, cur.orow);   // lane fi' = 4 g + r holds that row's original index
+                if (fi < a.cout4 && row < a.rows) a.out[(size_t)dst * a.ldo + fi] = y;
             }
         }
         cur = nxt;
@@ -216,7 +231,8 @@ using namespace g4d;
 // Takes the launch if it is the instantiated stack and large enough; returns -1 when it is not (the caller then runs the register-chain kernel).
 int g4d::fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const float *known_feats, const float *dist2, const int *nn_idx, int nlayers,
                           const unsigned short *const *W, const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
-                          const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st) {
+                          const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st,
+                          const void *perm_rec, size_t perm_stride) {
     const int on = (int)tuning("fp_head_bf16_persistent", 1);
     const long long min_rows = tuning("fp_head_bf16_min_rows", 262144);
     if (!on || rows < min_rows || rows >= (1ll << 31) - 64 || C2 != D0 || C1 != 0 || nlayers != 4 || pool != 0 || col0 != 0) return -1;
@@ -229,6 +245,7 @@ int g4d::fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const fl
     a.sc1 = scale[0]; a.sh1 = shift[0]; a.sc2 = scale[1]; a.sh2 = shift[1]; a.sc3 = scale[2]; a.sh3 = shift[2]; a.sc4 = scale[3]; a.sh4 = shift[3];
     a.relu1 = relu[0]; a.relu2 = relu[1]; a.relu3 = relu[2]; a.relu4 = relu[3]; a.cout4 = Cout[3];
     a.out = out; a.ldo = ldo; a.tap = tap_out; a.tap_ld = tap_ld;
+    a.perm_rec = reinterpret_cast<const unsigned char *>(perm_rec); a.perm_stride = perm_stride;
     static const int resident = [] {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;

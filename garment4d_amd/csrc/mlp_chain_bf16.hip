@@ -529,6 +529,23 @@ extern "C" int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float 
                            dist2, nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer, tap_out, tap_ld, stream);
 }
 
+extern "C" int g4d_mlp_chain_cells_bf16(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                                        const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                                        int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,
+                                        int nlayers, const unsigned short *const *W, const float *const *scale, const float *const *shift,
+                                        const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0,
+                                        int tap_layer, float *tap_out, int tap_ld, const void *unknown_grid, g4d_stream_t stream) {
+    if (mode == LOAD_INTERP && unknown_grid && n > 0 && known_feats && dist2 && nn_idx && W && scale && shift && Kpad && Cout && relu && out) {
+        size_t off = 0, stride = 0;
+        grid_sorted_layout(n, &off, &stride);
+        const int rc = fp_head_bf16_try(rows, n, m, C2, C1, known_feats, dist2, nn_idx, nlayers, W, scale, shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer,
+                                        tap_out, tap_ld, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned char *>(unknown_grid) + off, stride);
+        if (rc != -1) return rc;
+    }
+    return g4d_mlp_chain_bf16(mode, rows, K0, X, ldx, N, P, S, C, use_xyz, xyz, new_xyz, feats, idx, n, m, C2, C1, known_feats, skip, dist2, nn_idx, nlayers, W, scale,
+                              shift, Kpad, Cout, relu, pool, out, ldo, col0, tap_layer, tap_out, tap_ld, stream);
+}
+
 extern "C" int g4d_mlp_chain_bf16x3(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
                                     const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
                                     int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx,

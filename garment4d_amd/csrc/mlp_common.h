@@ -101,7 +101,8 @@ int fp_init_try(long long rows, int n, int m, int C1, const float *skip, const f
 // fp_head_bf16.hip: persistent form of g4d_mlp_chain_bf16 (interpolating mode) for the 128 -> 128 -> 64 -> 32 -> <= 16 stack of config 3; -1 = not its kind
 int fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const float *known_feats, const float *dist2, const int *nn_idx, int nlayers,
                      const unsigned short *const *W, const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout,
-                     const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st);
+                     const int *relu, int pool, float *out, int ldo, int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st,
+                     const void *perm_rec = nullptr, size_t perm_stride = 0);   // perm_rec: walk the rows in the cell order of the unknown cloud's grid records
 
 // sa_group_bf16.hip: persistent form of g4d_mlp_chain_bf16 (grouping mode) for the encoder's three-layer SA stacks
 int sa_group_bf16_try(long long rows, int N, int P, int S, int C, int use_xyz, const float *xyz, const float *new_xyz, const float *feats,

@@ -283,9 +283,10 @@ def wave_fits(layers, pool, S):
     return layers[0].Kpad == 32 and all(L.Cout <= 64 for L in layers[:-1]) and all(L.Kpad <= 64 for L in layers[1:])
 
 
-def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, group=None, interp=None, csr=None, tap=None):
+def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, group=None, interp=None, csr=None, tap=None, cells_grid=None):
     """One launch for the whole stack.  group = (N,P,C,use_xyz,xyz,new_xyz,feats,idx); interp = (n,m,C2,C1,known,skip,
-    dist2,nn_idx); csr = (Vg,rowptr,colidx,vals); tap = (layer_index, tensor2d)."""
+    dist2,nn_idx); csr = (Vg,rowptr,colidx,vals); tap = (layer_index, tensor2d); cells_grid = the ball-grid workspace of the unknown cloud
+    (interpolating bf16 launches may then walk the rows in cell order: same bits, shared neighbours, g4d_mlp_chain_cells_bf16)."""
     import ctypes
     n = len(layers)
     PA = ctypes.c_void_p * n
@@ -310,10 +311,11 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
     tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
     if current_precision() == "bf16" and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
         W16 = PA(*[L.Wc16.data_ptr() for L in layers])
-        _lib.call("g4d_mlp_chain_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
-                  n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
+        cells = mode == 2 and cells_grid is not None
+        _lib.call("g4d_mlp_chain_cells_bf16" if cells else "g4d_mlp_chain_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1,
+                  ik, isk, idd, ii, n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
                   ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
-                  out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
+                  out.shape[-1], col0, tl, tp, tld, *((cells_grid.data_ptr(),) if cells else ()), _lib.stream_ptr())
         return out
     if current_precision() == "bf16x3" and chain_fits(layers, pool, S, mode):
         W3 = (ctypes.c_void_p * (3 * n))(*[t.data_ptr() for L in layers for t in L.Wc16x3()])
@@ -938,7 +940,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
         if USE_STACK and stack_fits(allL, 0, 1, rows=B * n):
             logits = torch.empty((B, n, hl[-1].Cout), dtype=torch.float32, device=unknown.device)
             mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
-                      tap=(len(layers) - 1, out.view(B * n, -1)))
+                      tap=(len(layers) - 1, out.view(B * n, -1)), cells_grid=None if unknown_grid is None else unknown_grid[0])
             return out, logits
     if USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))

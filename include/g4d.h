@@ -260,6 +260,18 @@ int g4d_mlp_chain_bf16(int mode, long long rows, int K0, const float *X, int ldx
                        const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
                        float *tap_out, int tap_ld, g4d_stream_t stream);
 
+/* g4d_mlp_chain_bf16 in its interpolating mode (mode 2) with the ball-grid workspace of the UNKNOWN cloud at hand (g4d_ball_grid_build_f32 on
+ * `unknown`, any radius; n points per cloud): large launches walk the rows in the grid's cell order, so that consecutive rows share their
+ * nearest known points (fp_head_bf16.hip) -- every output row holds the same bits as with g4d_mlp_chain_bf16 (a row is computed from its
+ * own operands only); launches the cell-ordered kernel does not take run as g4d_mlp_chain_bf16 would.  dist2 / nn_idx / out / tap_out stay
+ * in the cloud's ORIGINAL row order. */
+int g4d_mlp_chain_cells_bf16(int mode, long long rows, int K0, const float *X, int ldx, int N, int P, int S, int C, int use_xyz,
+                             const float *xyz, const float *new_xyz, const float *feats, const int *idx, int n, int m, int C2,
+                             int C1, const float *known_feats, const float *skip, const float *dist2, const int *nn_idx, int nlayers,
+                             const unsigned short *const *W, const float *const *scale, const float *const *shift, const int *Kpad,
+                             const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
+                             float *tap_out, int tap_ld, const void *unknown_grid, g4d_stream_t stream);
+
 /* fp32-ACCURATE variant on the bf16 matrix cores ("bf16x3"): every fp32 operand is split exactly into three bf16 pieces
  * (hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid) and a product is the sum of the six largest piece products,
  * accumulated in fp32 -- error of the order of one fp32 rounding per product, six bf16 MFMAs instead of eight fp32 ones per

@@ -175,6 +175,13 @@ def test_fp_head_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, n, m):
                 outs[on] = fused.fp_forward(fp, unknown, known, None, kf, head=head)
     assert torch.equal(outs[0][0], outs[1][0]), "FP features differ"
     assert torch.equal(outs[0][1], outs[1][1]), "head outputs differ"
+    # the same launch over the rows in the cell order of the unknown cloud's ball grid (g4d_mlp_chain_cells_bf16): the same bits in the same rows
+    grid = fused.build_ball_grid(unknown, 0.1)
+    with torch.no_grad(), fused.precision("bf16"):
+        for on in (0, 1):
+            with tuning(fp_head_bf16_persistent=on, fp_head_bf16_min_rows=0):
+                cells = fused.fp_forward(fp, unknown, known, None, kf, head=head, unknown_grid=grid)
+                assert torch.equal(cells[0], outs[0][0]) and torch.equal(cells[1], outs[0][1]), f"cell-ordered launch differs (persistent kernel {on})"
     feats = fp(unknown, known, None, fused.to_channel_major(kf))          # fp32 module: the bf16 result is close, not equal
     scale = float(feats.abs().max())
     assert float((fused.to_channel_major(outs[1][0]) - feats).abs().max()) <= 3e-2 * scale
