@@ -67,6 +67,9 @@ SIGNATURES = {
                           _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
                            _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
+    "g4d_frag_bf16_elems": [_LL, _I],
+    "g4d_interp_concat_frag_bf16": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp],
+    "g4d_gemm_frag_bf16": [_LL, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _I, _vp, _I, _I, _vp],
     "g4d_mlp_chain_cells_bf16": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp, _vp],
     "g4d_mlp_chain_bf16x3": [_I, _LL, _I, _vp, _I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _vp, _vp, _vp,
@@ -106,7 +109,7 @@ SIGNATURES = {
 _lib = None
 
 
-RESTYPES = {"g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
+RESTYPES = {"g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):

@@ -816,6 +816,8 @@ def three_nn_multi(pairs):
 FP_WIDE_FUSED = os.environ.get("G4D_FP_WIDE_FUSED", "0") != "0"   # wide FP level: interpolation inside the first layer's loader (one launch fewer; A/B switch)
 FP_CELLS = os.environ.get("G4D_FP_CELLS", "1") != "0"   # last FP level: rows walked in the cell order of the unknown cloud's ball grid
 FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
+FP_GEMM_BF16 = os.environ.get("G4D_FP_GEMM_BF16", "1") != "0"            # wide FP level, bf16 operands, large launches: tiled GEMMs (csrc/gemm_bf16.hip) instead of the LDS stack kernel
+FP_GEMM_BF16_MIN_ROWS = int(os.environ.get("G4D_FP_GEMM_BF16_MIN_ROWS", "8192"))
 FP_WIDE_TABLE = os.environ.get("G4D_FP_WIDE_TABLE", "1") != "0"   # wide FP levels with skip features: known-feature columns pre-contracted, interpolation added in the GEMM's epilogue
 
 
@@ -942,7 +944,23 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
             mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
                       tap=(len(layers) - 1, out.view(B * n, -1)), cells_grid=None if unknown_grid is None else unknown_grid[0])
             return out, logits
-    if USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
+    if (FP_GEMM_BF16 and current_precision() == "bf16" and len(layers) == 2 and B * n >= FP_GEMM_BF16_MIN_ROWS and C2 % 8 == 0 and USE_STACK
+            and stack_fits(layers, 0, 1, rows=B * n) and not chain_fits(layers, 0, 1, 2) and all(L.Kpad % 64 == 0 and L.W.shape[0] % 128 == 0 for L in layers)
+            and layers[0].W.shape[0] >= layers[1].Kpad >= layers[0].Cout):
+        # wide FP level with bf16 operands, large launch: interpolation pre-pass + two tiled bf16 GEMMs (csrc/gemm_bf16.hip) instead of the LDS stack
+        # kernel -- bit-identical to it (same operands, roundings and k order), so the row count may decide
+        L0, L1 = layers
+        rows = B * n
+        elems = _lib.lib().g4d_frag_bf16_elems
+        x16 = torch.empty(elems(rows, L0.Kpad), dtype=torch.bfloat16, device=unknown.device)
+        h16 = torch.empty(elems(rows, L1.Kpad), dtype=torch.bfloat16, device=unknown.device)
+        _lib.call("g4d_interp_concat_frag_bf16", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm), dist2.data_ptr(), nn_idx.data_ptr(),
+                  L0.Kpad, x16.data_ptr(), stream)
+        _lib.call("g4d_gemm_frag_bf16", rows, L0.Kpad, x16.data_ptr(), L0.Wf16.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), L0.relu, L0.Cout,
+                  h16.data_ptr(), L1.Kpad, 0, 0, 0, stream)
+        _lib.call("g4d_gemm_frag_bf16", rows, L1.Kpad, h16.data_ptr(), L1.Wf16.data_ptr(), L1.scale.data_ptr(), L1.shift.data_ptr(), L1.relu, L1.Cout,
+                  0, 0, out.data_ptr(), out.shape[-1], 0, stream)
+    elif USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
     elif (layers[0].Cout > 64 and FP_WIDE_TABLE and C1 > 0 and C1 % 4 == 0 and m < n and current_precision() == "fp32"):
         # wide FP level (FP level 3 of the encoder: [384 + 192 -> 512 -> 256] over 256 points per cloud).  Split first layer:

@@ -272,6 +272,21 @@ int g4d_mlp_chain_cells_bf16(int mode, long long rows, int K0, const float *X, i
                              const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
                              float *tap_out, int tap_ld, const void *unknown_grid, g4d_stream_t stream);
 
+/* Wide feature-propagation level with bf16 operands as two tiled GEMMs behind an interpolation pre-pass (csrc/gemm_bf16.hip): the
+ * large-launch form of g4d_mlp_stack_bf16 in its interpolating mode, bit-identical to it.  Buffers in "fragment order" hold a (rows, kpad)
+ * bf16 matrix as [16-row tile][32-column k-step][64 lanes][8] -- the A operand of v_mfma_f32_16x16x32_bf16 -- with the rows padded to whole
+ * 128-row blocks: g4d_frag_bf16_elems(rows, kpad) = the number of bf16 elements to allocate (-1: bad arguments).
+ *   g4d_interp_concat_frag_bf16: x16 = bf16([three_interpolate(known_feats (b, m, C2)) ; skip (b, n, C1)]) of every row, zero padded to kpad
+ *     columns (C2 % 8 == 0; kpad % 32 == 0; pointnet2_modules.py:140-150, the interpolation in fp32, one RNE rounding per element).
+ *   g4d_gemm_frag_bf16: act((A . W^T) * scale + shift) with A in fragment order (kpad % 64 == 0), W = the layer's bf16 weights in fragment
+ *     order [16-channel tile][kpad / 32][64][8] padded to a multiple of 128 channels, fp32 accumulation; the result either rounded to bf16
+ *     in fragment order for the next layer (out16, kpad_out columns) or fp32 row-major (out, ldo, col0) -- exactly one of the two. */
+long long g4d_frag_bf16_elems(long long rows, int kpad);
+int g4d_interp_concat_frag_bf16(int b, int n, int m, int C2, int C1, const float *known_feats, const float *skip, const float *dist2,
+                                const int *nn_idx, int kpad, unsigned short *x16, g4d_stream_t stream);
+int g4d_gemm_frag_bf16(long long rows, int kpad, const unsigned short *A16, const unsigned short *W16, const float *scale, const float *shift, int relu,
+                       int Cout, unsigned short *out16, int kpad_out, float *out, int ldo, int col0, g4d_stream_t stream);
+
 /* fp32-ACCURATE variant on the bf16 matrix cores ("bf16x3"): every fp32 operand is split exactly into three bf16 pieces
  * (hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = x - hi - mid) and a product is the sum of the six largest piece products,
  * accumulated in fp32 -- error of the order of one fp32 rounding per product, six bf16 MFMAs instead of eight fp32 ones per

@@ -210,6 +210,32 @@ def test_sa_group_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, m
     assert float((fused.to_channel_major(outs[1]) - want).abs().max()) <= 3e-2 * scale
 
 
+@pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(40, 256, 64, 384, 192, [576, 512, 256]), (5, 1000, 100, 128, 60, [188, 512, 128]), (3, 333, 40, 96, 92, [188, 384, 256])])
+def test_wide_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n, m, C2, C1, mlp, monkeypatch):
+    """Config 3's wide FP level: interpolation pre-pass + two tiled bf16 GEMMs in fragment order (csrc/gemm_bf16.hip) against the LDS stack kernel
+    (g4d_mlp_stack_bf16), bit for bit; row counts that are not multiples of 128, 188 input columns (a ragged last k-step), 384 outputs
+    feeding 384 of 384 columns of the next layer."""
+    torch.manual_seed(n + C1)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, C2, device="cuda")
+    skip = torch.randn(B, n, C1, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=list(mlp)))
+    outs = {}
+    with torch.no_grad(), fused.precision("bf16"):
+        for on in (False, True):
+            monkeypatch.setattr(fused, "FP_GEMM_BF16", on)
+            monkeypatch.setattr(fused, "FP_GEMM_BF16_MIN_ROWS", 0)
+            with _lib.timed_calls() as t:
+                outs[on] = fused.fp_forward(fp, unknown, known, skip, kf)
+            names = [r[0] for r in t.results()]
+            assert ("g4d_gemm_frag_bf16" in names) == on, names
+    assert torch.equal(outs[False], outs[True])
+    want = fp(unknown, known, fused.to_channel_major(skip), fused.to_channel_major(kf))   # fp32 module: close, not equal
+    scale = float(want.abs().max())
+    assert float((fused.to_channel_major(outs[True]) - want).abs().max()) <= 3e-2 * scale
+
+
 @pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(3, 256, 64, 384, 192, [576, 512, 256]), (2, 1000, 100, 128, 64, [192, 256, 128]), (1, 333, 40, 96, 100, [196, 384])])
 def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, monkeypatch):
     """Wide FP levels with skip features (FP level 3 of the encoder): W [interp(f) ; s] = interp(Wa f) + Wb s -- table over the known rows, skip
