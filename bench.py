@@ -211,15 +211,24 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             rows_, k_, cout_ = iv[0], iv[1], iv[3]
             row.update(what=f"{rows_} rows x {k_} -> {cout_} (first-layer table / wide FP level)", bound="mfma", executed_flops=2.0 * rows_ * k_ * cout_,
                        algorithmic_flops=2.0 * rows_ * k_ * cout_)
+        elif nm == "g4d_interp_concat_frag_bf16":   # bf16 wide FP level on the GEMM route: this pre-pass + two g4d_gemm_frag_bf16 stand for one stack launch
+            b_, n_, m_, c2_, c1_, kp_ = iv[0], iv[1], iv[2], iv[3], iv[4], iv[5]
+            chain_i += 1                              # (the level's descriptor is not consumed by a chain / stack launch)
+            row.update(what=f"FP level 3 pre-pass: [interpolated {c2_} ; skip {c1_}] columns of {b_ * n_} rows rounded to bf16 in MFMA operand order", bound="hbm",
+                       algorithmic_bytes=float(b_) * n_ * (3 * 4 * c2_ + 4 * c1_ + 2 * kp_ + 24))
+        elif nm == "g4d_gemm_frag_bf16":
+            rows_, k_, cout_ = iv[0], iv[1], iv[3]
+            row.update(what=f"FP level 3: {rows_} rows x {k_} -> {cout_}, bf16 operands in fragment order (tiled GEMM)", bound="mfma", executed_flops=2.0 * rows_ * k_ * cout_,
+                       algorithmic_flops=2.0 * rows_ * k_ * cout_)
         elif nm == "g4d_linear_interp_add_f32":
             rows_, k_, cout_ = iv[0], iv[3], iv[5]
             row.update(what=f"{rows_} rows x {k_} skip columns -> {cout_}, interpolated table of the known rows added in the epilogue (wide FP level)", bound="mfma",
                        executed_flops=2.0 * rows_ * k_ * cout_, algorithmic_flops=2.0 * rows_ * k_ * cout_)
         elif nm in ("g4d_mlp_chain_group_table_f32", "g4d_mlp_chain_interp_init_f32", "g4d_mlp_chain_table_cells_f32", "g4d_mlp_chain_table_f32", "g4d_mlp_chain_f32",
-                    "g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc):
+                    "g4d_mlp_chain_bf16", "g4d_mlp_chain_cells_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc):
             desc, layers, full = chain_desc[chain_i]
             chain_i += 1
-            rows_ = iv[1] if nm in ("g4d_mlp_chain_bf16", "g4d_mlp_stack_bf16", "g4d_mlp_chain_f32") else iv[0]   # (these take the loader mode first)
+            rows_ = iv[1] if nm in ("g4d_mlp_chain_bf16", "g4d_mlp_chain_cells_bf16", "g4d_mlp_stack_bf16", "g4d_mlp_chain_f32") else iv[0]   # (these take the loader mode first)
             row.update(what=desc, bound="mfma", executed_flops=2.0 * rows_ * sum(k * c for k, c in layers), algorithmic_flops=2.0 * rows_ * sum(k * c for k, c in full))
         elif nm in ("g4d_three_nn_cells_sorted_f32", "g4d_three_nn_cells_f32"):
             b_, n_, m_ = iv[0], iv[1], iv[2]
@@ -250,7 +259,7 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     else:
         kernel_of = {"SA level 3 scale 1": "sa_group_bf16_kernel<8, 64, 192, 8>", "SA level 3 scale 0": "sa_group_bf16_kernel<4, 32, 192, 4>", "SA level 2 scale 1": "sa_group_bf16_kernel<4, 32, 96, 4>",
                      "SA level 2 scale 0": "sa_group_bf16_kernel<2, 16, 96, 4>", "SA level 1 scale 1": "sa_group_bf16_kernel<2, 32, 0, 4>", "SA level 1 scale 0": "sa_group_bf16_kernel<1, 16, 0, 4>",
-                     "FP level 1": "fp_head_bf16_kernel", "FP level 2": "mlp_chain_bf16_kernel<1, 2, 16, 8", "FP level 3": "mlp_stack_bf16_kernel<2>"}
+                     "FP level 1": "fp_head_bf16_kernel", "FP level 2": "mlp_chain_bf16_kernel<1, 2, 16, 8", "FP level 3:": "gemm_frag_bf16_kernel<true>"}
 
     def with_counters(r):
         r = dict(r)
