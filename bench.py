@@ -128,7 +128,7 @@ def pmc_sq(kernel_substr):
     return None
 
 
-VALU_LANE_OPS_PEAK = 2 * 256 * 4 * 16 * 2.4e9   # fp32 VALU lane-operations per second with packed instructions (v_pk_fma_f32: two per lane and cycle): 78.6e12
+VALU_LANE_OPS_PEAK = 2 * 256 * 4 * 16 * 2.4e9   # nominal fp32 VALU lane-operations per second (32 per SIMD and cycle): 78.6e12; measured issue rate of plain wave64 instructions: ~28 lanes per SIMD and cycle, packed instructions the same arithmetic rate (profiles/r04_valu_issue_rate.txt)
 
 
 def launch_table(model, smpl, pose_pool, pool, kco, precision):
@@ -138,7 +138,7 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     Per launch: microseconds (median of 3 passes), the same per B = 8 step, and -- where SURVEY 8(d) defines one -- the launch's algorithmic
     work against the peak that bounds it:  mfma = the MFMA flops the launch executes / 157.3 TFLOP/s fp32 (2.5 PFLOP/s with bf16 operands);
     latency = the sampling chain (dependent rounds; HBM bytes reported for completeness); valu = distance evaluations of the brute-force
-    search x 7 lane-operations each / 78.6e12 packed-fp32 lane-operations per second; hbm = bytes moved / 8 TB/s."""
+    search x 7 lane-operations each / 78.6e12 nominal fp32 lane-operations per second; hbm = bytes moved / 8 TB/s."""
     from garment4d_amd import _lib, fused, lbs as G
     B = B_CLOUDS * kco
     n = pool.shape[0]
