@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) three_nn_wide_kernel(int n, int m, const 
 static int nn_wide_split(long long queries) {
     static const int v = [] { const char *e = getenv("G4D_NN_SPLIT"); return e ? atoi(e) : 0; }();
     if (v == 1 || v == 2 || v == 4) return v;
-    return queries < 65536 ? 4 : 1;
+    return queries <= 65536 ? 4 : (queries <= 131072 ? 2 : 1);   // (round 4: throughput comes from coalesced calls of >= 1 M queries, un-split; a lone B = 8 step -- 65536 queries, one wave per SIMD un-split -- is a latency case)
 }
 #define G4D_NN_WIDE_LAUNCH(n_, b_, st_, ...)                                                                                                  \
     if (nn_wide_split((long long)(n_) * (b_)) == 4) {                                                                                                               \
