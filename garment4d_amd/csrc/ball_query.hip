@@ -198,11 +198,13 @@ __global__ void __launch_bounds__(256) ball_query_multi_kernel(const BqMulti q) 
 // SA / FP levels of the encoder) -- in ONE launch: workgroups [0, bq_blocks) are ball-query tiles, the rest three_nn tiles.  Each of
 // these launches is a few microseconds of work and costs the many-streams regime about its own duration (launches of different
 // streams barely overlap when they are this short: profiles/r03_launch_cost_isolated_vs_16streams.txt).
-template <int NS, int FM>
+// QW queries per wave: 1 for a lone B = 8 step (more, smaller workgroups: latency), 4 for a coalesced call (a workgroup's LDS staging of
+// the cloud and its fixed costs are shared by 16 queries instead of 4; the per-query arithmetic is the same: identical outputs).
+template <int NS, int FM, int QW>
 __global__ void __launch_bounds__(256) search_multi_kernel(const BqMulti q, const NNMulti nq, int bq_blocks) {
     if ((int)blockIdx.x < bq_blocks) {
-        if ((int)blockIdx.x < q.blk0) ball_query_body<1, NS, FM>(q.n[0], q.m[0], q.a[0], q.new_xyz[0], q.xyz[0], blockIdx.x, blockIdx.y);
-        else ball_query_body<1, NS, FM>(q.n[1], q.m[1], q.a[1], q.new_xyz[1], q.xyz[1], (int)blockIdx.x - q.blk0, blockIdx.y);
+        if ((int)blockIdx.x < q.blk0) ball_query_body<QW, NS, FM>(q.n[0], q.m[0], q.a[0], q.new_xyz[0], q.xyz[0], blockIdx.x, blockIdx.y);
+        else ball_query_body<QW, NS, FM>(q.n[1], q.m[1], q.a[1], q.new_xyz[1], q.xyz[1], (int)blockIdx.x - q.blk0, blockIdx.y);
     } else {
         three_nn_multi_role<FM>(nq, (int)blockIdx.x - bq_blocks, blockIdx.y);
     }
@@ -657,10 +659,15 @@ extern "C" int g4d_search_multi_f32(int b, int nscales, int n0, int m0, const fl
         nq.blk_end[i] = nblocks;
     }
     nq.count = nn_count;
-    const int bq_blocks = q.blk0 + (m1 + 3) / 4;
+    static const int qw_env = getenv("G4D_SEARCH_MULTI_QW") ? atoi(getenv("G4D_SEARCH_MULTI_QW")) : 0;   // tuning hook: 1 | 4
+    const int qw = qw_env == 1 || qw_env == 4 ? qw_env : ((long long)b * (m0 + m1) >= 32768 ? 4 : 1);
+    q.blk0 = (m0 + 4 * qw - 1) / (4 * qw);
+    const int bq_blocks = q.blk0 + (m1 + 4 * qw - 1) / (4 * qw);
     dim3 grid((unsigned)(bq_blocks + nblocks), (unsigned)b);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define G4D_SM(NSV) G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((search_multi_kernel<NSV, FM>), grid, dim3(256), 0, st, q, nq, bq_blocks))
+#define G4D_SM(NSV)                                                                                                                                          \
+    if (qw == 4) { G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((search_multi_kernel<NSV, FM, 4>), grid, dim3(256), 0, st, q, nq, bq_blocks)) }   \
+    else { G4D_WITH_FM(distance_contraction(), hipLaunchKernelGGL((search_multi_kernel<NSV, FM, 1>), grid, dim3(256), 0, st, q, nq, bq_blocks)) }
     switch (nscales) {
         case 1: G4D_SM(1) break;
         case 2: G4D_SM(2) break;

@@ -445,14 +445,15 @@ def test_fps_gather_grid_equals_the_two_launches(n, m, contraction_mode):
     assert all(torch.equal(p, q) for p, q in zip(a, s))
 
 
-def test_search_multi_equals_the_separate_launches():
+@pytest.mark.parametrize("B,m0,m1", [(3, 256, 64), (110, 255, 61)])
+def test_search_multi_equals_the_separate_launches(B, m0, m1):
     """g4d_search_multi_f32: the two multi-scale ball queries and the two three_nn searches of the encoder's inner levels in one launch --
-    every output bit-identical to g4d_ball_query_msg2_f32 / g4d_three_nn_multi_f32."""
+    every output bit-identical to g4d_ball_query_msg2_f32 / g4d_three_nn_multi_f32.  B = 110: a coalesced call's size, four queries per
+    wave in the ball-query tiles (query counts that are not multiples of 16)."""
     from garment4d_amd import fused
-    B = 3
     x0 = dev(syn.body_like_cloud(B, 1024, seed=3, dup_frac=0.2, zero_frac=0.1))
-    c0 = fused.fps_gather(x0, 256)
-    c1 = fused.fps_gather(c0, 64)
+    c0 = fused.fps_gather(x0, m0)
+    c1 = fused.fps_gather(c0, m1)
     q0, q1 = ([0.1, 0.2], [16, 32], x0, c0), ([0.2, 0.4], [32, 64], c0, c1)
     pairs = [(c0, c1), (x0, c0), (c1, c0)]
     o0, o1, nn = fused.search_multi(q0, q1, pairs)
