@@ -360,6 +360,8 @@ static int grid_query(int b, int n, int m, int nscales, const float *radii, cons
     const long long queries = (long long)b * m;
     int qpw = 1;
     while (qpw < 8 && queries / (qpw * 2) >= 32768) qpw <<= 1;  // keep >= 32k waves (4 per SIMD lane of the chip) before batching
+    static const int qpw_env = getenv("G4D_BG_QPW") ? atoi(getenv("G4D_BG_QPW")) : 0;   // tuning hook
+    if (qpw_env > 0) qpw = qpw_env;
     dim3 grid((unsigned)((m + 4 * qpw - 1) / (4 * qpw)), (unsigned)b);
     G4D_WITH_FM(distance_contraction(), switch (nscales) {
         case 1: grid_query_launch<1, FM>(grid, st, n, m, qpw, a, new_xyz, xyz, ws); break;
