@@ -5,7 +5,8 @@
 // matrix pipe could run) and every wave re-reads the whole A tile from LDS (5 ds_read_b128 per 16 MFMAs): 60 % of the fp32 MFMA peak at
 // 240 clouds per call.  Here the block tile is 128 x 128 (half the L2 traffic per flop), a wave owns 64 x 64 of it (16 accumulator tiles:
 // 8 ds_read_b128 per 64 MFMAs), and workgroups that share a row block run next to each other on ONE XCD (its L2 serves the A rows to all
-// column blocks).  Operand order, k order and epilogue are linear_kernel's: results are bit-identical.
+// column blocks).  Products, k order and epilogue arithmetic are linear_kernel's (the MFMAs run with the operands swapped, which changes
+// neither): results are bit-identical.
 #include <cstdlib>
 
 #include "mlp_common.h"
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // (weights as the A operand: see the epilogue)
         }
         if (more) {
             const int nxt = cur ^ 1;
@@ -95,32 +96,43 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
         }
         __syncthreads();
     }
-    // epilogue.  C/D layout of the 16x16 MFMA: column (channel) = lane & 15, rows = (lane >> 4) * 4 + reg
-    if (a.tab) {   // + three_interpolate(tab) of the row (g4d_linear_interp_add_f32): as linear_kernel, added to the finished contraction
+    // epilogue.  The MFMAs ran transposed (A = weights, B = activations: the same products summed in the same k order, i.e. the same bits as
+    // linear_kernel's orientation), so lane (fi, fq) holds channels 4 fq .. 4 fq + 3 of tile j for row fi of tile i: ONE interpolation context
+    // per (lane, row tile) instead of one per output row of four, 16-byte table loads and 16-byte stores instead of dword ones.
+    const bool vec = (a.ldo & 3) == 0 && (a.col0 & 3) == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0;   // launch-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + fi;
+        const int rowc = min(row, a.rows - 1);
+        InterpRow c = {};
+        if (a.tab) c = interp_row(a, rowc);   // + three_interpolate(tab) of the row (g4d_linear_interp_add_f32): as linear_kernel, added to the finished contraction
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch0 = n0 + wc * 64 + j * 16 + fq * 4;
+            const int chc = min(ch0, cpad - 4);            // the packed scale / shift are padded to 64 channels
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + chc), sh = *reinterpret_cast<const f32x4 *>(a.shift + chc);
+            f32x4 y = acc[i][j];
+            if (a.tab) {   // (the launcher guarantees Cout % 128 == 0, tab_ld % 4 == 0 and a 16-byte aligned table: whole 16-byte groups inside the row)
+                const f32x4 t0 = *reinterpret_cast<const f32x4 *>(a.tab + c.k0 + ch0), t1 = *reinterpret_cast<const f32x4 *>(a.tab + c.k1 + ch0),
+                            t2 = *reinterpret_cast<const f32x4 *>(a.tab + c.k2 + ch0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = y[r] + (c.w0 * t0[r] + c.w1 * t1[r] + c.w2 * t2[r]);   // interp_at(), element by element
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const InterpRow c = interp_row(a, min(row0 + wr * 64 + i * 16 + fq * 4 + r, a.rows - 1));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] = acc[i][j][r] + interp_at(a, c, min(n0 + wc * 64 + j * 16 + fi, a.Cout - 1));
+                y[r] = __builtin_fmaf(y[r], sc[r], sh[r]);
+                if (a.relu) y[r] = fmaxf(y[r], 0.f);
             }
-    }
+            if (row < a.rows) {
+                float *o = a.out + (size_t)row * a.ldo + a.col0 + ch0;
+                if (vec && ch0 + 3 < a.Cout) *reinterpret_cast<f32x4 *>(o) = y;
+                else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ch = n0 + wc * 64 + j * 16 + fi;
-        const int chc = min(ch, cpad - 1);
-        const float sc = a.scale[chc], sh = a.shift[chc];
-        const bool ch_ok = ch < a.Cout;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float y = __builtin_fmaf(acc[i][j][r], sc, sh);
-                if (a.relu) y = fmaxf(y, 0.f);
-                const int row = row0 + wr * 64 + i * 16 + fq * 4 + r;
-                if (ch_ok && row < a.rows) a.out[(size_t)row * a.ldo + a.col0 + ch] = y;
+                    for (int r = 0; r < 4; ++r)
+                        if (ch0 + r < a.Cout) o[r] = y[r];
+                }
             }
+        }
     }
 }
 
@@ -131,6 +143,7 @@ bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
     const int enabled = (int)tuning("gemm_tile", 1);
     const long long min_rows = tuning("gemm_tile_min_rows", 32768);
     if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < (a.tab ? 128 : 256) || a.Cout < 256 || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
+    if (a.tab && ((a.tab_ld & 3) || (reinterpret_cast<size_t>(a.tab) & 15))) return false;
     const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
     static unsigned long long attr = 0;
     *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_tile_kernel), lds, attr, "g4d_linear_f32(tile)");
