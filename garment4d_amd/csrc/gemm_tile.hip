@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
 bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
     const int enabled = (int)tuning("gemm_tile", 1);
     const long long min_rows = tuning("gemm_tile_min_rows", 32768);
-    if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < (a.tab ? 128 : 256) || a.Cout < 256 || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
+    const int min_cout = (int)tuning("gemm_tile_min_cout", 128), min_kpad = (int)tuning("gemm_tile_min_kpad", 128);   // (A/B switches; 256 / 256 until the epilogue stored 16 bytes per lane)
+    if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < (a.tab ? 128 : min_kpad) || a.Cout < min_cout || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
     if (a.tab && ((a.tab_ld & 3) || (reinterpret_cast<size_t>(a.tab) & 15))) return false;
     const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
     static unsigned long long attr = 0;

@@ -190,7 +190,9 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
     if out is None:
         out = torch.empty((orow, layer.Cout), dtype=torch.float32, device=x2d.device)
     streams = STREAM_GEMM and not pool and rows >= 65536 and layer.Cout % 128 == 0 and layer.Kpad <= 128   # csrc/gemm_stream.hip takes these inside g4d_linear_f32
-    if not streams and not pool and current_precision() == "fp32" and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
+    tiles = (not pool and rows >= 32768 and layer.K % 4 == 0 and ldx % 4 == 0 and layer.Cout % 128 == 0 and layer.Kpad >= 128
+             and x2d.data_ptr() % 16 == 0)   # csrc/gemm_tile.hip takes these inside g4d_linear_f32 (983040 x 324 -> 128: 87 TFLOP/s against 66 on the chain kernel)
+    if not streams and not tiles and not pool and current_precision() == "fp32" and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
         # ragged K (e.g. the 323- / 195-wide GCN inputs) or a very narrow output: the chain kernel streams the rows with
         # unaligned 16-byte loads and wins (82 vs 60 TFLOP/s at 323 -> 128); results are bit-identical (same k order)
         return mlp_stack(0, rows, layer.K, [layer], out, col0=col0, X=x2d, ldx=ldx)

@@ -131,6 +131,21 @@ class GraphConvolution(torch.nn.Module):
             self._g4d_packed = hit
         return hit[1]
 
+    def _packed_support_padded(self, width):
+        """The support contraction for an input whose rows carry `width` >= in_features columns, the extra ones ZERO (the caller pads a ragged
+        feature width -- 323, 195 -- to a multiple of 4 so that the rows are 16-byte aligned and the tiled GEMM takes the launch): the weight
+        gets zero rows for them, every partial sum keeps its value and its k order -- the same bits as _packed()[0] on the unpadded rows."""
+        key = (self.weight.data_ptr(), self.weight._version, int(width))
+        hit = getattr(self, "_g4d_packed_pad", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                dev = self.weight.device
+                wt = torch.zeros((self.out_features, int(width)), dtype=torch.float32, device=dev)
+                wt[:, :self.in_features] = self.weight.detach().float().t()
+                hit = (key, PackedLayer(wt, torch.ones(self.out_features, device=dev), torch.zeros(self.out_features, device=dev), relu=False))
+            self._g4d_packed_pad = hit
+        return hit[1]
+
     def forward(self, input, adj, ismlp=False, relu=False):
         """input (B,N,Fin) or (N,Fin); adj sparse (N,N).  ismlp=True skips the aggregation (layers.py:43,51).
         relu=True (extension) fuses the caller's F.relu into the SpMM epilogue."""
@@ -166,10 +181,13 @@ class GraphConvolution(torch.nn.Module):
 FUSE_STACK = os.environ.get("G4D_GCN_FUSED", "1") != "0"
 
 
-def gcn_stack_forward(layers, x, adj, relu_last=False, keep=()):
+def gcn_stack_forward(layers, x, adj, relu_last=False, keep=(), in_width=None):
     """h_0 = x;  h_{i+1} = layers[i](h_i, adj) with ReLU after every layer but the last (ReLU there iff relu_last) -- the regressor
     loop of modules/mesh_encoder.py:477-481.  Returns [h_1, ..., h_n] with None for the intermediate activations nobody asked for
     (`keep` = indices i whose output layers[i](...) must exist; the last always does).
+
+    in_width: the real feature width when x carries extra ZERO columns behind it (a ragged width padded to a multiple of 4 by the caller:
+    16-byte aligned rows for the tiled GEMM); must equal layers[0].in_features.
 
     Same operation order as chaining GraphConvolution.forward (contract, aggregate, bias, ReLU); what changes is where the
     tensors live: the aggregation of layer i and the contraction of layer i+1 run in ONE launch (g4d_gcn_agg_linear_f32) whenever
@@ -185,8 +203,12 @@ def gcn_stack_forward(layers, x, adj, relu_last=False, keep=()):
         return (FUSE_STACK and i + 1 < n and layers[i].out_features == 128
                 and (layers[i + 1].out_features == 128 or layers[i + 1].out_features <= 16))
 
+    if in_width is not None:
+        assert in_width == layers[0].in_features and x.shape[-1] >= in_width, "in_width must be the first layer's input width"
+        if x.shape[-1] == in_width:
+            in_width = None
     if not any(fusable(i) for i in range(n)):
-        h = x
+        h = x if in_width is None else x[..., :in_width]
         for i, m in enumerate(layers):
             h = m(h, adj, False, relu=(i + 1 < n or relu_last))
             outs[i] = h
@@ -204,6 +226,8 @@ def gcn_stack_forward(layers, x, adj, relu_last=False, keep=()):
         L_support, _, bias = m._packed()
         relu = i + 1 < n or relu_last
         if S is None:
+            if i == 0 and in_width is not None:   # rows padded with zero columns (see the docstring): the padded weight, the same bits
+                L_support = m._packed_support_padded(xb.shape[-1])
             S = linear(h.reshape(B * N, -1), L_support).view(B, N, -1)                 # layers.py:42
         if fusable(i):
             nxt = layers[i + 1]

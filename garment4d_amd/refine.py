@@ -195,7 +195,10 @@ class GarmentRefinementHead(nn.Module):
                   for i in range(3)]
         for it in range(self.iteration):
             width = self.graph_start_feature_dim + (self.hidden_dim if it > 0 else 0)
-            feat = torch.empty((F_, Vg, width), dtype=torch.float32, device=dev)
+            wpad = (width + 3) // 4 * 4    # 195 / 323 columns: rows padded to 16 bytes (zero columns) so that the tiled GEMM takes the regressor's first contraction
+            feat = torch.empty((F_, Vg, wpad), dtype=torch.float32, device=dev)
+            if wpad > width:
+                feat[..., width:] = 0
             feat[..., :3] = cur                                                      # cur_positional_encoding (:465)
             col = 3
             body_idx = fused.ball_query_msg(self.body_radius_list, self.body_sample_num_list, body_v, cur, coherent=True)   # one pass, 3 radii
@@ -213,7 +216,7 @@ class GarmentRefinementHead(nn.Module):
                 pending = None
             # :477-481 -- four chained GraphConvolutions; only the third one's output (the next round's attention input) and the
             # last one's are kept, the rest never leaves the fused aggregate + contract launches (gcn.gcn_stack_forward)
-            hs = gcn_stack_forward(regress[it], feat, adj, relu_last=False, keep=(2,))
+            hs = gcn_stack_forward(regress[it], feat, adj, relu_last=False, keep=(2,), in_width=width)
             lbs_iter_feat += hs
             h = hs[-1]
             if it + 1 < self.iteration and gdist.resolve_group(group) is not None:
