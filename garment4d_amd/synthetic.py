@@ -153,3 +153,57 @@ def garment_scene(nbatch, T, N, body_rc=(25, 28), garment_rc=(12, 16), pca_dim=6
     }
     body = dict(parents=P["parents"], faces=faces, J_regressor=P["J_regressor"], v_template=bv)
     return dict(x=x, batch=batch, body=body, pca=pca, template=(gv, gq))
+
+
+def refine_state_dict(seed=0, feat=32, hidden=128, garment_in=(67, 99, 387)):
+    """Seeded weights under the reference's state-dict names for PCALBSGarmentUseSegEncoderSeg (modules/mesh_encoder.py:201-284):
+    six positional encoders (Linear in->32, Linear 32->32), two bias-free temporal q/k/v Linears, three 4-layer GCN regressors
+    (195 | 323 -> 128 -> 128 -> 128 -> 3; GraphConvolution stores weight as (in, out), modules/pygcn/layers.py:19).  numpy, fp32."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def uni(shape, bound):
+        return ((rng.random(shape) * 2 - 1) * bound).astype(F32)
+    for i in range(3):
+        for name, cin in (("body_positional_encoding%d" % i, 6), ("garment_positional_encoding%d" % i, garment_in[i])):
+            sd[name + ".0.weight"] = uni((feat, cin), 1.0 / np.sqrt(cin))
+            sd[name + ".0.bias"] = uni((feat,), 1.0 / np.sqrt(cin))
+            sd[name + ".2.weight"] = uni((feat, feat), 1.0 / np.sqrt(feat))
+            sd[name + ".2.bias"] = uni((feat,), 1.0 / np.sqrt(feat))
+    for i in (1, 2):
+        sd["temporal_qkv_%d.weight" % i] = uni((3 * hidden, hidden), 0.3 / np.sqrt(hidden))
+    start = 6 * feat + 3
+    for r in range(3):
+        dims = [start + (hidden if r > 0 else 0), hidden, hidden, hidden, 3]
+        for l in range(4):
+            p = "lbs_graph_regress%d.%d" % (r + 1, l)
+            sd[p + ".weight"] = uni((dims[l], dims[l + 1]), 0.5 / np.sqrt(dims[l + 1]) if l < 3 else 0.02)
+            sd[p + ".bias"] = uni((dims[l + 1],), 0.5 / np.sqrt(dims[l + 1]) if l < 3 else 0.005)
+    return sd
+
+
+def refine_golden_case(seed=70, nbatch=2, T=3):
+    """The inputs of tests/golden/refine.npz (written by tests/golden/make_golden_refine.py, which runs the reference's own
+    modules/mesh_encoder.py on them): a 700-vertex body cylinder, the 64-vertex quad-cylinder garment template, three garment
+    point levels (128 / 48 / 16 points with 64 / 96 / 384 features, as mesh_encoder.py:236-240 expects), per-clip garment
+    templates.  Regenerated from the seed on both sides; refine_golden_checksum() guards against generator drift."""
+    sc = garment_scene(nbatch, T, 4, garment_rc=(8, 8), seed=seed)
+    rng = np.random.default_rng(seed + 7)
+    gv, gq = sc["template"]
+    Vg = gv.shape[0]
+    F_ = nbatch * T
+    tpose_garment = (gv[None] + rng.standard_normal((nbatch, Vg, 3)) * 0.004).astype(F32)
+    centre = sc["batch"]["smpl_vertices_torch"].reshape(F_, -1, 3).mean(1, keepdims=True) - sc["body"]["v_template"].mean(0)
+    lv, lf = [], []
+    for n, c in ((128, 64), (48, 96), (16, 384)):
+        sel = rng.integers(0, Vg, n)
+        lv.append((gv[sel][None] + centre + rng.standard_normal((F_, n, 3)) * 0.03).astype(F32))
+        lf.append(rng.standard_normal((F_, n, c)).astype(F32))                      # point-major (F,N_i,C_i)
+    return dict(seed=seed, nbatch=nbatch, T=T, Vg=Vg, batch=sc["batch"], body=sc["body"], template_verts=gv, template_faces=gq,
+                tpose_garment=tpose_garment, garment_v_list=lv, garment_f_list=lf)
+
+
+def refine_golden_checksum(case):
+    items = [case["tpose_garment"]] + case["garment_v_list"] + case["garment_f_list"] + [v for _, v in sorted(case["batch"].items())]
+    items += [v for _, v in sorted(refine_state_dict(seed=case["seed"] + 100).items())]
+    return np.array([float(np.asarray(a, dtype=np.float64).sum()) for a in items])

@@ -70,3 +70,14 @@ def request_finalizers(request):
     yield fns
     for f in reversed(fns):
         f()
+
+
+@pytest.fixture(scope="session")
+def golden_refine():
+    """tests/golden/refine.npz = outputs of the reference's own modules/mesh_encoder.py (make_golden_refine.py); the inputs are
+    regenerated from the seed here and checked against the stored checksums."""
+    from garment4d_amd import synthetic as syn
+    g = load_golden("refine.npz")
+    case = syn.refine_golden_case()
+    assert np.array_equal(syn.refine_golden_checksum(case), g["checksum"]), "synthetic.refine_golden_case drifted from refine.npz"
+    return g, case

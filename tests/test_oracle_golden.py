@@ -174,3 +174,60 @@ def test_admissible_labels_accepts_near_ties_only():
     assert flips == 0 and np.array_equal(lab, own)
     with pytest.raises(AssertionError):
         MOr.admissible_labels(logits, np.array([[0, 1, 1, 0]]))              # point 1: a full unit apart
+
+
+# ---- the f1 surface: oracle/refine_oracle.py + model_oracle.py against the reference's own modules/mesh_encoder.py ------------
+# (tests/golden/refine.npz, written by tests/golden/make_golden_refine.py; only chamferdist.knn_points is a stand-in there)
+def _refine_adj(case):
+    return (gcn_oracle.adjacency_from_faces(case["template_faces"], case["Vg"]),
+            gcn_oracle.adjacency_old_from_faces(case["template_faces"], case["Vg"]))
+
+
+def test_refine_adjacency_equals_the_reference_constructor(golden_refine):
+    """mesh_encoder.py:286-307 (edges -> symmetrise -> normalize(A + I)) as built by the reference's __init__."""
+    import scipy.sparse as sp
+    g, case = golden_refine
+    adj, _ = _refine_adj(case)
+    ref = sp.csr_matrix((g["adj_val"], (g["adj_row"], g["adj_col"])), shape=(case["Vg"], case["Vg"]))
+    assert abs(adj - ref).max() < 1e-7
+
+
+@pytest.mark.parametrize("K_", [3, 256])
+def test_refine_oracle_lbs_garment_interpolation(golden_refine, K_):
+    from oracle import refine_oracle as RO
+    g, case = golden_refine
+    b = case["batch"]
+    _, adj_old = _refine_adj(case)
+    posed, (d1, i1), stage1 = RO.lbs_garment_interpolation(
+        case["tpose_garment"], b["Tpose_smpl_vertices_torch"], b["Tpose_smpl_root_joints_torch"], b["zeropose_smpl_vertices_torch"],
+        case["body"]["parents"], b["pose_torch"], b["T_J_regressor"], b["T_lbs_weights"], adj_old, K=K_)
+    assert np.array_equal(i1, g[f"lbs_k{K_}_nn_idx"])
+    np.testing.assert_allclose(d1, g[f"lbs_k{K_}_nn_dists"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(stage1, g[f"lbs_k{K_}_stage1"], **TOL)
+    np.testing.assert_allclose(posed, g[f"lbs_k{K_}_posed"], **TOL)
+
+
+def test_model_oracle_vertex_normals(golden_refine):
+    from oracle import model_oracle as MOr
+    g, case = golden_refine
+    body_v = case["batch"]["smpl_vertices_torch"].reshape(case["nbatch"] * case["T"], -1, 3)
+    np.testing.assert_allclose(MOr.compute_vnorms(body_v, case["body"]["faces"]), g["body_vn"], **TOL)
+
+
+@pytest.mark.parametrize("iteration", [1, 3])
+def test_refine_oracle_rounds(golden_refine, iteration):
+    """PCALBSGarmentUseSegEncoderSeg.forward's loop (mesh_encoder.py:445-486): body normals, K = 3 garment LBS, then 1 / 3
+    refinement rounds (ball queries around the previous round's vertices, six positional encoders, temporal attention, GCN)."""
+    from oracle import model_oracle as MOr, refine_oracle as RO
+    g, case = golden_refine
+    nbatch, T = case["nbatch"], case["T"]
+    adj, _ = _refine_adj(case)
+    sd = syn.refine_state_dict(seed=case["seed"] + 100)
+    body_v = case["batch"]["smpl_vertices_torch"].reshape(nbatch * T, -1, 3)
+    body_vn = MOr.compute_vnorms(body_v, case["body"]["faces"])
+    cur = g[f"fwd_it{iteration}_lbs_pred"].reshape(nbatch * T, -1, 3)
+    np.testing.assert_allclose(cur, g["lbs_k3_posed"].reshape(cur.shape), rtol=0, atol=0)
+    outs = RO.refinement_head(sd, cur, body_v, body_vn, case["garment_v_list"], case["garment_f_list"], adj, nbatch, T, iteration=iteration)
+    assert len(outs) == iteration
+    for r, o in enumerate(outs):
+        np.testing.assert_allclose(o, g[f"fwd_it{iteration}_round{r}"], **TOL)
