@@ -95,8 +95,8 @@ def test_cfg2_encoder_full_size_bf16x3_split_vs_fp32_oracle():
 
 
 def test_cfg3_encoder_bf16_full_size_vs_bf16_oracle(monkeypatch):
-    """BASELINE config 3 precision at N = 8192: bf16 MLP operands, fp32 accumulate; sampling stays bit-exact."""
-    B, N = 1, 8192
+    """BASELINE config 3 precision at its real batch, B = 8 x N = 8192: bf16 MLP operands, fp32 accumulate; sampling stays bit-exact."""
+    B, N = 8, 8192
     xyz = syn.unit_cloud(B, N, seed=22)
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=6).eval()
     sd = {k: v.numpy() for k, v in model.state_dict().items()}
@@ -115,13 +115,14 @@ def test_cfg3_encoder_bf16_full_size_vs_bf16_oracle(monkeypatch):
     # on its longest path and sums contributions of independent flips in quadrature rather than linearly; the worst element over
     # 65536 x 7 outputs is ~4.5 sigma.  With a flip probability of ~2^-9 x (fan-in <= 576) per layer input that gives
     #     sigma ~ 2^-8 * sqrt(L * p_flip * fan_in) ~ 2^-8 * sqrt(15 * 1.1) ~ 1.6e-2 of scale for the typical worst path,
-    # measured: 2.6e-2 on the logits (q99.9 2.0e-2), 1e-2 on the feature tensors.  Gate: 3e-2 of the tensor scale (round 2 had 4e-2).
+    # measured at B = 1: 2.6e-2 on the logits, 1e-2 on the feature tensors.  Gate: 3e-2 of the tensor scale (round 2 had 4e-2).
     def bf16_gate(name, got, want):
         mx, _, _, scale = stats(name, got, want)
         err = np.abs(got.detach().cpu().numpy() - want)
         q = float(np.quantile(err, 0.999))
         print(f"[parity] {name}: q99.9 {q:.3g}")
         assert mx <= 3e-2 * max(scale, 1.0), (name, q, mx, scale)
+        assert q <= 1e-2 * max(scale, 1.0), (name, q, mx, scale)          # the bulk: 99.9 % of the elements within 1e-2 of the scale
 
     for lvl in range(0, 4):
         bf16_gate(f"cfg3 l_features[{lvl}] (bf16 vs bf16-emulating oracle)", l_f[lvl], want_f[lvl])

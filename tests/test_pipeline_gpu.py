@@ -48,6 +48,55 @@ def test_coalesced_call_equals_separate_calls_bit_for_bit(precision, k):
             assert torch.equal(bv[sl], v) and torch.equal(bj[sl], j), f"step {i}: lbs() differs"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_clouds_of_a_240_cloud_call_vs_the_oracle_directly(precision, monkeypatch):
+    """The launch bench.py times -- ONE call on 240 clouds (8 clips x 30 frames) plus its lbs() -- checked against the ORACLE with no
+    transitive link: clouds {0, 13, 239} go to modules_oracle.encoder_forward (fp32: elementwise 1e-5, sampled centroids bit-exact;
+    bf16: the bf16-emulating oracle, max <= 3e-2 and q99.9 <= 1e-2 of the tensor scale) and frames {0, 119, 239} to lbs_oracle.lbs (1e-5).
+    Cloud 13 is a tie-heavy body-like cloud (duplicates + zero padding)."""
+    from oracle import lbs_oracle as LO, modules_oracle as MO
+    B, N = 240, 8192
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=0).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    P = syn.smpl_like_params(seed=1)
+    smpl = {k: torch.from_numpy(v).cuda() for k, v in P.items()}
+    g = torch.Generator(device="cuda").manual_seed(3)
+    clouds = torch.rand((B, N, 3), generator=g, device="cuda")
+    clouds[8:16] = torch.from_numpy(syn.body_like_cloud(8, N, seed=5)).cuda()
+    betas_np, pose_np = syn.smpl_like_pose(B, seed=7)
+    with torch.no_grad():
+        out, v, j = _eager(model, smpl, clouds, torch.from_numpy(betas_np).cuda(), torch.from_numpy(pose_np).cuda(), precision)
+    pick = [0, 13, 239]
+    monkeypatch.setattr(MO, "BF16", precision == "bf16")
+    want_logits, want_f, want_xyz = MO.encoder_forward(clouds[pick].cpu().numpy(), sd)
+    logits = out[1][pick].cpu().numpy()                                          # (3, N, 7) point-major
+    for lvl in range(1, 4):
+        assert np.array_equal(out[3][lvl][pick].cpu().numpy(), want_xyz[lvl]), f"sampled centroids of level {lvl}: not bit-exact"
+
+    def gate(name, got, want):
+        err = np.abs(got.astype(np.float64) - want)
+        scale = max(float(np.abs(want).max()), 1.0)
+        print(f"[parity] 240-cloud {precision} {name}: max_abs {err.max():.3g} q99.9 {np.quantile(err, 0.999):.3g} scale {scale:.3g}")
+        if precision == "fp32":
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=name)
+        else:
+            assert err.max() <= 3e-2 * scale and np.quantile(err, 0.999) <= 1e-2 * scale, (name, err.max(), scale)
+
+    want_logits_pm = want_logits if want_logits.shape == logits.shape else np.transpose(want_logits, (0, 2, 1))
+    gate("sem_logits", logits, want_logits_pm)
+    for lvl, f in enumerate(out[2]):
+        if f is None:
+            continue
+        got = f[pick].cpu().numpy()
+        w = want_f[lvl]
+        gate(f"l_features[{lvl}]", got, w if w.shape == got.shape else np.transpose(w, (0, 2, 1)))
+    fr = [0, 119, 239]
+    wv, wj = LO.lbs(betas_np[fr], pose_np[fr], P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"])
+    np.testing.assert_allclose(v[fr].cpu().numpy(), wv, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(j[fr].cpu().numpy(), wj, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("coalesce,streams", [(4, 3), (1, 2), (5, 1)])
 def test_forty_steps_through_the_executor_equal_the_eager_calls(coalesce, streams):
     """40 different B = 2 batches submitted one at a time; every step's (logits, vertices, joints) must equal the eager call on that batch,
@@ -89,3 +138,28 @@ def test_result_after_slot_reuse_raises():
     assert f1.result()[1] is None and f1.result()[0].shape == (B, N, 7)
     with pytest.raises(RuntimeError):
         f0.result()
+
+
+def test_inputs_may_be_dropped_right_after_submit():
+    """submit() copies the caller's tensors on the slot's stream, behind the slot's previous call.  The caller drops
+    its tensors at once and allocates + fills new ones of the same size on ITS stream (the allocator would hand the freed blocks out
+    again): every step must still see the data it was submitted with."""
+    B, N, STEPS = 2, 4096, 12
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=0).cuda().eval()
+    smpl = _smpl()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    keep = torch.rand((STEPS, B, N, 3), generator=g, device="cuda")
+    poses = [tuple(torch.from_numpy(a).cuda() for a in syn.smpl_like_pose(B, seed=40 + s)) for s in range(STEPS)]
+    pipe = StepPipeline(model, smpl, clouds_per_step=B, n_points=N, coalesce=1, streams=1)
+    got = []
+    for s in range(STEPS):
+        cloud, betas, pose = keep[s].clone(), poses[s][0].clone(), poses[s][1].clone()
+        fut = pipe.submit(cloud, betas, pose)
+        del cloud, betas, pose                       # freed while the copy is still queued behind the previous call
+        junk = [torch.full((B, N, 3), 7.0, device="cuda"), torch.full((B, 10), 7.0, device="cuda"), torch.full((B, 72), 7.0, device="cuda")]
+        got.append(fut.result(copy=True))
+        del junk
+    with torch.no_grad():
+        for s in range(STEPS):
+            out, v, j = _eager(model, smpl, keep[s], poses[s][0], poses[s][1], "fp32")
+            assert torch.equal(got[s][0], out[1]) and torch.equal(got[s][1], v) and torch.equal(got[s][2], j), f"step {s} saw clobbered inputs"
