@@ -150,7 +150,7 @@ class StepPipeline:
             # The copy is queued behind the slot's previous call (milliseconds); the caller may drop or overwrite its tensors as soon as
             # submit() returns.  Tell the caching allocator that the slot's stream still reads them, so that a freed block is not handed
             # out again (and overwritten on the caller's stream) before the copy has run.  Overwriting a LIVE input in place remains the
-            # caller's race, as with any asynchronous copy: wait on the returned future's `copied` event first.
+            # caller's race, as with any asynchronous copy (wait for the step's future, or hand over a fresh tensor per step).
             for _, src in pairs:
                 if src.is_cuda:
                     src.record_stream(s.stream)
