@@ -83,14 +83,12 @@ def test_clouds_of_a_240_cloud_call_vs_the_oracle_directly(precision, monkeypatc
         else:
             assert err.max() <= 3e-2 * scale and np.quantile(err, 0.999) <= 1e-2 * scale, (name, err.max(), scale)
 
-    want_logits_pm = want_logits if want_logits.shape == logits.shape else np.transpose(want_logits, (0, 2, 1))
-    gate("sem_logits", logits, want_logits_pm)
+    gate("sem_logits", logits, want_logits)                                       # both (3, N, classes)
     for lvl, f in enumerate(out[2]):
         if f is None:
             continue
         got = f[pick].cpu().numpy()
-        w = want_f[lvl]
-        gate(f"l_features[{lvl}]", got, w if w.shape == got.shape else np.transpose(w, (0, 2, 1)))
+        gate(f"l_features[{lvl}]", got, np.transpose(want_f[lvl], (0, 2, 1)))     # the oracle's levels are channel-major (B, C, N)
     fr = [0, 119, 239]
     wv, wj = LO.lbs(betas_np[fr], pose_np[fr], P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"])
     np.testing.assert_allclose(v[fr].cpu().numpy(), wv, rtol=1e-5, atol=1e-5)
