@@ -52,7 +52,7 @@ def test_coalesced_call_equals_separate_calls_bit_for_bit(precision, k):
 def test_clouds_of_a_240_cloud_call_vs_the_oracle_directly(precision, monkeypatch):
     """The launch bench.py times -- ONE call on 240 clouds (8 clips x 30 frames) plus its lbs() -- checked against the ORACLE with no
     transitive link: clouds {0, 13, 239} go to modules_oracle.encoder_forward (fp32: elementwise 1e-5, sampled centroids bit-exact;
-    bf16: the bf16-emulating oracle, max <= 3e-2 and q99.9 <= 1e-2 of the tensor scale) and frames {0, 119, 239} to lbs_oracle.lbs (1e-5).
+    bf16: the bf16-emulating oracle, max <= 3e-2 and q99.9 <= 1e-2 (logits: 2e-2) of the tensor scale) and frames {0, 119, 239} to lbs_oracle.lbs (1e-5).
     Cloud 13 is a tie-heavy body-like cloud (duplicates + zero padding)."""
     from oracle import lbs_oracle as LO, modules_oracle as MO
     B, N = 240, 8192
@@ -81,7 +81,11 @@ def test_clouds_of_a_240_cloud_call_vs_the_oracle_directly(precision, monkeypatc
         if precision == "fp32":
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=name)
         else:
-            assert err.max() <= 3e-2 * scale and np.quantile(err, 0.999) <= 1e-2 * scale, (name, err.max(), scale)
+            # two bf16 pipelines differ where an activation falls on the other side of a bf16 rounding boundary; the logits sit behind
+            # 15 layers of such flips (derivation: tests/test_parity_fullsize_gpu.py).  Measured: feature levels q99.9 <= 3.4e-3 of the
+            # scale, logits 1.0e-2 (1.5e-2 at B = 8, cfg3) -- so the bulk gate is 1e-2 for the feature levels and 2e-2 for the logits.
+            qgate = 2e-2 if name == "sem_logits" else 1e-2
+            assert err.max() <= 3e-2 * scale and np.quantile(err, 0.999) <= qgate * scale, (name, err.max(), scale)
 
     gate("sem_logits", logits, want_logits)                                       # both (3, N, classes)
     for lvl, f in enumerate(out[2]):
