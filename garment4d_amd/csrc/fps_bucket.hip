@@ -102,10 +102,17 @@ __device__ __forceinline__ unsigned part1by2(unsigned v) {  // spread the low 10
 
 // W waves, P buckets (slots) per wave; handles N <= 64*W*P points.  LDS: max(8*Npad sort keys, 12*N SoA) + 512.
 // KMAX > 1: the multi-pick round loop (below); KMAX = 1: one sample per round.
-template <int W, int P, int FM, int KMAX = 1>
+// SOA: the LDS copy of the cloud (96 KB at n = 8192) that the winner's coordinates are read from.  SOA = false (multi-pick rounds only,
+// round 5): the coordinates come from the owning lane's REGISTERS -- the tie rank carries the slot number in its low bits, the wave's
+// best / second-best slot is a wave-uniform register index (s_set_gpr_idx_on + v_mov: the point arrays live in ONE 4 P-wide vector so
+// that the compiler indexes it instead of expanding a select chain), three v_readlane -- and the workgroup needs 70 KB of LDS (sort keys
+// + pick list) instead of 104: a 72 KB shared-MLP workgroup of another stream fits beside it on the same CU.
+template <int W, int P, int FM, int KMAX = 1, bool SOA = true>
 __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs, int deal_kcap, int pick_off, const float *__restrict__ xyz_all,
                                                 float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all, int cloud) {
     constexpr int T = 64 * W, NPAD = T * P;
+    static_assert(SOA || KMAX > 1, "the register form exists for the multi-pick loop only");
+    constexpr int SB = SOA ? 0 : (P == 4 ? 2 : P == 8 ? 3 : P == 16 ? 4 : 5);   // slot bits below the tie rank (register form)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);         // [2][16] candidate keys
     float *red = reinterpret_cast<float *>(smem_raw + 256);                                // [6][16] bbox partials
@@ -172,7 +179,12 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
     }
     // ---- C. deal buckets of 64 sorted points to the waves, load the points into registers ----------------------------
     int pk[P];                     // original index of the slot's point (or -1)
-    float px[P], py[P], pz[P], md[P];
+    typedef float fvec __attribute__((ext_vector_type(4 * P)));
+    fvec pv;                       // [0, P) x, [P, 2P) y, [2P, 3P) z, [3P, 4P) running min-distance of the lane's P points
+#define px(i) pv[(i)]
+#define py(i) pv[P + (i)]
+#define pz(i) pv[2 * P + (i)]
+#define md(i) pv[3 * P + (i)]
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         // buckets are dealt to the waves in runs of `deal` consecutive (Morton-adjacent) buckets: slot i of wave w holds bucket
@@ -187,24 +199,38 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
     for (int i = 0; i < P; ++i) {
         const bool ok = pk[i] >= 0;
         const int k = ok ? pk[i] : 0;
-        px[i] = ok ? xyz[k * 3 + 0] : 0.f;
-        py[i] = ok ? xyz[k * 3 + 1] : 0.f;
-        pz[i] = ok ? xyz[k * 3 + 2] : 0.f;
-        md[i] = ok ? (temp ? temp[k] : 1e10f) : -2.f;  // -2: below every real min-distance, never a candidate
-        if (ok) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
+        px(i) = ok ? xyz[k * 3 + 0] : 0.f;
+        py(i) = ok ? xyz[k * 3 + 1] : 0.f;
+        pz(i) = ok ? xyz[k * 3 + 2] : 0.f;
+        md(i) = ok ? (temp ? temp[k] : 1e10f) : -2.f;  // -2: below every real min-distance, never a candidate
+        if constexpr (SOA) { if (ok) { sx[k] = px(i); sy[k] = py(i); sz[k] = pz(i); } }
     }
+    const float x0 = xyz[0], y0 = xyz[1], z0 = xyz[2];   // the first sample is point 0 (sampling_gpu.cu:118)
     // bucket boxes, lane l holds the box of bucket l % P (64 / P copies: the multi-pick loop tests 64 / P samples at once); per-slot tie ranks
     float blx = INF, bly = INF, blz = INF, bhx = -INF, bhy = -INF, bhz = -INF;
     unsigned rk[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const bool ok = pk[i] >= 0;
-        rk[i] = ok ? fpsb_rank(pk[i], bs, log2bs) : 0xffffffffu;
-        const float a0 = wave_min_f32(ok ? px[i] : INF), a1 = wave_min_f32(ok ? py[i] : INF), a2 = wave_min_f32(ok ? pz[i] : INF);
-        const float a3 = wave_max_f32(ok ? px[i] : -INF), a4 = wave_max_f32(ok ? py[i] : -INF), a5 = wave_max_f32(ok ? pz[i] : -INF);
+        rk[i] = ok ? ((fpsb_rank(pk[i], bs, log2bs) << SB) | (SOA ? 0u : (unsigned)i)) : 0xffffffffu;
+        const float a0 = wave_min_f32(ok ? px(i) : INF), a1 = wave_min_f32(ok ? py(i) : INF), a2 = wave_min_f32(ok ? pz(i) : INF);
+        const float a3 = wave_max_f32(ok ? px(i) : -INF), a4 = wave_max_f32(ok ? py(i) : -INF), a5 = wave_max_f32(ok ? pz(i) : -INF);
         if ((lane & (P - 1)) == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }   // lane l holds the box of bucket l % P
     }
     if (t == 0) { spick[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
+    // register form: the boxes wait in LDS (the sort keys are dead: everybody read its keys before the barrier above) and are re-read at the
+    // head of every round -- six registers that are NOT live while the top-two trees run (the kernel has to fit 64 VGPRs so that a
+    // 256-register shared-MLP wave of another stream shares the SIMD with four FPS waves); a bucket's box = 32 bytes, 8 distinct per wave
+    float *sbox = reinterpret_cast<float *>(smem_raw + kFpsHdr) + (wave * P + (lane & (P - 1))) * 8;
+    if constexpr (!SOA) {
+        typedef float f32x4b __attribute__((ext_vector_type(4)));
+        typedef float f32x2b __attribute__((ext_vector_type(2)));
+        if (lane < P) {
+            *reinterpret_cast<f32x4b *>(sbox) = (f32x4b){blx, bly, blz, bhx};
+            *reinterpret_cast<f32x2b *>(sbox + 4) = (f32x2b){bhy, bhz};
+        }
+        if (lane < 2) slots[(wave * 2 + lane) * 4] = 0ull;   // = rec[..]: "no candidate" until the wave's first sweep publishes one
+    }
     __syncthreads();
 
 #ifdef G4D_FPS_DEBUG
@@ -241,14 +267,15 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         unsigned *nstop = reinterpret_cast<unsigned *>(smem_raw + 1024);                // [2] the round's length: LDS atomic min over the candidates' stop positions (two slots, alternating)
         float *res = reinterpret_cast<float *>(smem_raw + 1024 + 256);                  // [KE0] the round's samples in rank order: x, y, z, value
         const int ls = lane / P;                             // which sample of the round this lane tests its box against
-        float xs = sx[0], ys = sy[0], zs = sz[0];            // lane layout: sample lane / P; round 1: the one sample is point 0
+        float xs = x0, ys = y0, zs = z0;                     // lane layout: sample lane / P; round 1: the one sample is point 0
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         int ns = 1, j = 1, rpar = 0;
         if (t == 0) { nstop[0] = 0xffu; nstop[1] = 0xffu; }   // (ordered before the first use by the barriers of round 1)
         float gval = INF;
         // this wave's best (lane 0) and second-best (lane 1) candidate: key (0 = none) and the point's coordinates; kept until a bucket of the wave is swept
+        // (register form: the record in LDS IS the cache -- an unswept wave simply leaves its two records alone)
         unsigned long long rkey = 0ull;
-        float rx = sx[0], ry = sy[0], rz = sz[0];
+        float rx = x0, ry = y0, rz = z0;
 #ifdef G4D_FPS_DEBUG
         long long dbg_rounds = 0, dbg_stop[4] = {0, 0, 0, 0}, dbg_ph[4] = {0, 0, 0, 0}, dbg_actw = 0, dbg_a[4] = {0, 0, 0, 0}, dbg_pairs = 0, dbg_c1 = 0;   // stop: dirty | zero | cap | second key
 #endif
@@ -257,6 +284,13 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
             dbg_c0 = clock64(); ++dbg_rounds;
 #endif
             // 1. which (sample, bucket) pairs can change anything?
+            if constexpr (!SOA) {
+                typedef float f32x4b __attribute__((ext_vector_type(4)));
+                typedef float f32x2b __attribute__((ext_vector_type(2)));
+                const f32x4b b0 = *reinterpret_cast<const volatile f32x4b *>(sbox);
+                const f32x2b b1_ = *reinterpret_cast<const volatile f32x2b *>(sbox + 4);
+                blx = b0.x; bly = b0.y; blz = b0.z; bhx = b0.w; bhy = b1_.x; bhz = b1_.y;
+            }
             const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
             const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
             const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
@@ -273,8 +307,8 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 #pragma unroll
                     for (int q = 0; q < P; ++q) {
                         if ((mi >> q) & 1u) {
-                            const float dx = px[q] - ax, dy = py[q] - ay, dz = pz[q] - az;
-                            md[q] = fpsb_min(dist2<FM>(dx, dy, dz), md[q]);
+                            const float dx = px(q) - ax, dy = py(q) - ay, dz = pz(q) - az;
+                            md(q) = fpsb_min(dist2<FM>(dx, dy, dz), md(q));
                         }
                     }
                 }
@@ -284,7 +318,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 // 3. the lane's best and second-best slot (value, then smallest rank), then the wave's
                 float tv[P];
 #pragma unroll
-                for (int i = 0; i < P; ++i) tv[i] = md[i];
+                for (int i = 0; i < P; ++i) tv[i] = md(i);
 #pragma unroll
                 for (int w = P; w > 1; w >>= 1)
 #pragma unroll
@@ -292,21 +326,21 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 const float b1 = tv[0];
                 unsigned tr[P];
 #pragma unroll
-                for (int i = 0; i < P; ++i) tr[i] = (md[i] == b1) ? rk[i] : 0xffffffffu;
+                for (int i = 0; i < P; ++i) tr[i] = (md(i) == b1) ? rk[i] : 0xffffffffu;
 #pragma unroll
                 for (int w = P; w > 1; w >>= 1)
 #pragma unroll
                     for (int i = 0; i < w / 2; ++i) tr[i] = min(tr[i], tr[i + w / 2]);
                 const unsigned r1 = tr[0];
 #pragma unroll
-                for (int i = 0; i < P; ++i) tv[i] = (rk[i] == r1) ? -2.f : md[i];   // ranks of real points are unique: this drops exactly the best slot
+                for (int i = 0; i < P; ++i) tv[i] = (rk[i] == r1) ? -2.f : md(i);   // ranks of real points are unique: this drops exactly the best slot
 #pragma unroll
                 for (int w = P; w > 1; w >>= 1)
 #pragma unroll
                     for (int i = 0; i < w / 2; ++i) tv[i] = fmax_raw(tv[i], tv[i + w / 2]);
                 const float b2 = tv[0];
 #pragma unroll
-                for (int i = 0; i < P; ++i) tr[i] = (md[i] == b2 && rk[i] != r1) ? rk[i] : 0xffffffffu;
+                for (int i = 0; i < P; ++i) tr[i] = (md(i) == b2 && rk[i] != r1) ? rk[i] : 0xffffffffu;
 #pragma unroll
                 for (int w = P; w > 1; w >>= 1)
 #pragma unroll
@@ -334,15 +368,37 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 const float c2v = wave_max_f32(v2);
                 hit = __builtin_amdgcn_ballot_w64(v2 == c2v);
                 unsigned c2r;
-                if (__builtin_popcountll(hit) == 1) c2r = (unsigned)__builtin_amdgcn_readlane((int)q2, __builtin_ctzll(hit));
-                else c2r = wave_min_u32(v2 == c2v ? q2 : 0xffffffffu);
+                int h2;
+                if (__builtin_popcountll(hit) == 1) {
+                    h2 = __builtin_ctzll(hit);
+                    c2r = (unsigned)__builtin_amdgcn_readlane((int)q2, h2);
+                } else {
+                    c2r = wave_min_u32(v2 == c2v ? q2 : 0xffffffffu);
+                    h2 = SOA ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(v2 == c2v && q2 == c2r) | (1ull << 63));
+                }
                 {
                     const float cvv = lane == 0 ? c1v : c2v;
                     const unsigned crr = lane == 0 ? c1r : c2r;
                     rkey = (cvv < 0.f || crr == 0xffffffffu) ? 0ull : (((unsigned long long)__float_as_uint(cvv) << 32) | (unsigned)(~crr));
-                    const unsigned ccls = log2bs ? (__builtin_bitreverse32(crr >> 16) >> (32 - log2bs)) : 0u;
-                    const int ci = (rkey && lane < 2) ? (int)(((crr & 0xffffu) << log2bs) | ccls) : 0;
-                    rx = sx[ci]; ry = sy[ci]; rz = sz[ci];
+                    if constexpr (SOA) {
+                        const unsigned ccls = log2bs ? (__builtin_bitreverse32(crr >> 16) >> (32 - log2bs)) : 0u;
+                        const int ci = (rkey && lane < 2) ? (int)(((crr & 0xffffu) << log2bs) | ccls) : 0;
+                        rx = sx[ci]; ry = sy[ci]; rz = sz[ci];
+                    } else {
+                        // the two candidates' coordinates out of their owners' registers: slot = the rank's low bits (wave-uniform index)
+                        const int s1 = (int)(c1r & (unsigned)(P - 1)), s2 = (int)(c2r & (unsigned)(P - 1));
+                        const float ax1 = pv[s1], ay1 = pv[P + s1], az1 = pv[2 * P + s1];
+                        const float ax2 = pv[s2], ay2 = pv[P + s2], az2 = pv[2 * P + s2];
+                        const float bx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax1), h1)), bx2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax2), h2));
+                        const float by1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay1), h1)), by2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay2), h2));
+                        const float bz1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az1), h1)), bz2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az2), h2));
+                        rx = lane == 0 ? bx1 : bx2; ry = lane == 0 ? by1 : by2; rz = lane == 0 ? bz1 : bz2;
+                        if (lane < 2) {   // publish here: the record doubles as the wave's cache
+                            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<u64x2 *>(&rec[(wave * 2 + lane) * 4]) = (u64x2){rkey, ((unsigned long long)__float_as_uint(ry) << 32) | __float_as_uint(rx)};
+                            reinterpret_cast<float *>(rec)[(wave * 2 + lane) * 8 + 4] = rz;
+                        }
+                    }
                 }
 #ifdef G4D_FPS_DEBUG
                 { const long long now_ = clock64(); dbg_a[3] += now_ - dbg_c1; dbg_c1 = now_; }
@@ -352,7 +408,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
             { const long long now_ = clock64(); dbg_ph[0] += now_ - dbg_c0; dbg_c0 = now_; dbg_actw += active != 0ull; }
 #endif
             // 4. publish the two candidates as records {key, x, y, z}; barrier A
-            if (lane < 2) {
+            if (SOA && lane < 2) {
                 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<u64x2 *>(&rec[(wave * 2 + lane) * 4]) = (u64x2){rkey, ((unsigned long long)__float_as_uint(ry) << 32) | __float_as_uint(rx)};
                 reinterpret_cast<float *>(rec)[(wave * 2 + lane) * 8 + 4] = rz;
@@ -389,7 +445,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                     // where the walk stops because of this candidate: AT it (bad) or right AFTER it; the round's length is the smallest
                     atomicMin(&nstop[rpar], bad ? (unsigned)rank : (after ? (unsigned)rank + 1u : 0xffu));
                     if (rank < KE) {   // ranks are unique among real keys: slot `rank` of the round has one writer (empty slots all carry point 0)
-                        const unsigned crk = ~(unsigned)km;
+                        const unsigned crk = (~(unsigned)km) >> SB;
                         const unsigned ccls = log2bs ? (__builtin_bitreverse32(crk >> 16) >> (32 - log2bs)) : 0u;
                         *reinterpret_cast<f32x4 *>(&res[rank * 4]) = (f32x4){mx, my, mz, mv};
                         if (j + rank < m) spick[j + rank] = km ? (int)(((crk & 0xffffu) << log2bs) | ccls) : 0;
@@ -417,6 +473,9 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         if (temp && ns > 1) {
             // the reference's scratch ends up holding the min-distances to every sample but the LAST one (sampling_gpu.cu:129-141 updates
             // with idx[j - 1] before it picks idx[j]): apply the final round's samples except its last
+            if constexpr (!SOA) {
+                blx = sbox[0]; bly = sbox[1]; blz = sbox[2]; bhx = sbox[3]; bhy = sbox[4]; bhz = sbox[5];
+            }
             const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
             const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
             const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
@@ -428,7 +487,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), i * P));
 #pragma unroll
                 for (int q = 0; q < P; ++q)
-                    if ((mi >> q) & 1u) md[q] = fpsb_min(dist2<FM>(px[q] - ax, py[q] - ay, pz[q] - az), md[q]);
+                    if ((mi >> q) & 1u) md(q) = fpsb_min(dist2<FM>(px(q) - ax, py(q) - ay, pz(q) - az), md(q));
             }
         }
 #ifdef G4D_FPS_DEBUG
@@ -466,15 +525,15 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 #pragma unroll
                 for (int i = 0; i < P; ++i) {
                     if ((active >> i) & 1u) {
-                        const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-                        md[i] = fpsb_min(dist2<FM>(dx, dy, dz), md[i]);
+                        const float dx = px(i) - x1, dy = py(i) - y1, dz = pz(i) - z1;
+                        md(i) = fpsb_min(dist2<FM>(dx, dy, dz), md(i));
                     }
                 }
                 // 3. lane candidate: max value over its P points, smallest rank among the points holding it; then the wave's
                 //    (balanced trees: the round is a dependent-issue chain at ~6 cycles per instruction, depth is what counts)
                 float tv[P];
 #pragma unroll
-                for (int i = 0; i < P; ++i) tv[i] = md[i];
+                for (int i = 0; i < P; ++i) tv[i] = md(i);
 #pragma unroll
                 for (int w = P; w > 1; w >>= 1)
 #pragma unroll
@@ -482,7 +541,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 const float b = tv[0];
                 unsigned tr[P];
 #pragma unroll
-                for (int i = 0; i < P; ++i) tr[i] = (md[i] == b) ? rk[i] : 0xffffffffu;
+                for (int i = 0; i < P; ++i) tr[i] = (md(i) == b) ? rk[i] : 0xffffffffu;
 #pragma unroll
                 for (int w = P; w > 1; w >>= 1)
 #pragma unroll
@@ -524,13 +583,24 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
     for (int j = t; j < m; j += T) {
         const int k = spick[j];
         idx[j] = k;
-        if (nx) { nx[j * 3 + 0] = sx[k]; nx[j * 3 + 1] = sy[k]; nx[j * 3 + 2] = sz[k]; }
+        if (nx) {
+            if constexpr (SOA) { nx[j * 3 + 0] = sx[k]; nx[j * 3 + 1] = sy[k]; nx[j * 3 + 2] = sz[k]; }
+            else { nx[j * 3 + 0] = xyz[k * 3 + 0]; nx[j * 3 + 1] = xyz[k * 3 + 1]; nx[j * 3 + 2] = xyz[k * 3 + 2]; }   // (L2 hits: the cloud was read twice above)
+        }
     }
     if (temp) {
 #pragma unroll
         for (int i = 0; i < P; ++i)
-            if (pk[i] >= 0) temp[pk[i]] = md[i];
+            if (rk[i] != 0xffffffffu) {   // the slot's original index, decoded from its tie rank (pk[] does not stay live through the round loop)
+                const unsigned r = rk[i] >> SB;
+                const unsigned c = log2bs ? (__builtin_bitreverse32(r >> 16) >> (32 - log2bs)) : 0u;
+                temp[((r & 0xffffu) << log2bs) | c] = md(i);
+            }
     }
+#undef px
+#undef py
+#undef pz
+#undef md
 #ifdef G4D_FPS_DEBUG
     __syncthreads();
     if (lane == 0 && temp) atomicAdd(&temp[0], (float)dbg_active);  // debug only: total active (wave, bucket) sweeps
@@ -542,13 +612,31 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 template <int W, int P, int FM, int KMAX>
 __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all,
                                                            float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
-    fps_bucket_body<W, P, FM, KMAX>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
+    fps_bucket_body<W, P, FM, KMAX, true>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
+}
+
+// the register form (multi-pick, no LDS cloud copy), held to 64 VGPRs: four of its waves + one 256-register wave fill a SIMD's 512
+template <int W, int P, int FM, int KMAX>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(8, 8)))
+fps_bucket_reg_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all, float *__restrict__ temp_all,
+                      int *__restrict__ idx_all, float *__restrict__ nx_all) {
+    fps_bucket_body<W, P, FM, KMAX, false>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
 }
 
 // samples per round of the bucketed kernels: 8 (multi-pick, default) or 1 (G4D_FPS_MULTI=1: one arg-max per round, the round-2 loop)
 static int fps_multi() {
     static const int k = getenv("G4D_FPS_MULTI") ? atoi(getenv("G4D_FPS_MULTI")) : 8;
     return k > 1 ? 8 : 1;
+}
+// Which multi-pick form a launch of b clouds takes.  The LDS-copy form (rounds 3-4: 74 VGPRs, 104 KB) has the shorter round (0.61 us per pick
+// against 0.67 at b = 8): it serves the small launches, where the sampling chain is the latency of the step.  The register form (64 VGPRs,
+// 70 KB) serves the coalesced calls (b >= 32 clouds): there every CU hosts a sampling workgroup and what counts is which launches of the OTHER
+// calls in flight fit beside it -- measured at 240 clouds per call, four calls in flight, both arms on one box: 51.9k -> 53.6k frames/s
+// fp32, 94.4k -> 96.8k bf16 (profiles/r05_overlap_pairs_240clouds.txt: next to fp_init 0.98 -> 0.80 of the sum, next to the tiled GEMMs
+// 0.97 -> 0.86-0.91).  G4D_FPS_SOA=1 / 0 forces one form.
+static bool fps_soa(int b) {
+    static const int k = getenv("G4D_FPS_SOA") ? atoi(getenv("G4D_FPS_SOA")) : -1;
+    return k < 0 ? b < 32 : k != 0;
 }
 static int fps_kcap() {   // tuning hook: at most this many samples per round
     static const int k = getenv("G4D_FPS_KCAP") ? atoi(getenv("G4D_FPS_KCAP")) : 8;
@@ -562,21 +650,31 @@ template <int FM, int KMAX>
 __global__ void __launch_bounds__(1024) fps_bucket_grid_kernel(int b, int n, int m, int bs, int log2bs, int deal, int pick_off,
                                                               const float *__restrict__ xyz_all, int *__restrict__ idx_all, float *__restrict__ nx_all,
                                                               int cmax, float cell_req, unsigned char *__restrict__ ws_all, size_t ws_stride) {
-    if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM, KMAX>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
+    if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM, KMAX, true>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
+    else ball_grid_build_body(n, cmax, cmax, cell_req, xyz_all, ws_all, ws_stride, (int)blockIdx.x - b);
+}
+
+template <int FM, int KMAX>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+fps_bucket_grid_reg_kernel(int b, int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all, int *__restrict__ idx_all,
+                           float *__restrict__ nx_all, int cmax, float cell_req, unsigned char *__restrict__ ws_all, size_t ws_stride) {
+    if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM, KMAX, false>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
     else ball_grid_build_body(n, cmax, cmax, cell_req, xyz_all, ws_all, ws_stride, (int)blockIdx.x - b);
 }
 
 template <int W, int P, int FM>
 static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
-    const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
+    const bool multi = fps_multi() > 1;
+    const bool soa = !multi || fps_soa(b) || W != 16;   // (the register form is held to 64 VGPRs: 16 waves x 4 or 8 points per lane only)
+    const size_t body = (!soa || npad * 8 > (size_t)n * 12) ? npad * 8 : (size_t)n * 12;
     const size_t pick_off = (kFpsHdr + body + 15) & ~(size_t)15;
     const size_t lds = pick_off + (size_t)m * 4;
     if (lds > 160 * 1024 - 1024) return -1;   // the pick list lives in LDS: m beyond ~15.8k at n = 8192 goes to the next route (fps.hip)
-    const bool multi = fps_multi() > 1;
     auto kern = multi ? fps_bucket_kernel<W, P, FM, 8> : fps_bucket_kernel<W, P, FM, 1>;
-    static unsigned long long attr_done[2] = {0, 0};  // one bit per device
-    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done[multi], "g4d_fps_f32(bucketed)")) return rc;
+    if constexpr (W == 16) { if (!soa) kern = fps_bucket_reg_kernel<W, P, FM, 8>; }
+    static unsigned long long attr_done[3] = {0, 0, 0};  // one bit per device
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done[multi ? (soa ? 1 : 2) : 0], "g4d_fps_f32(bucketed)")) return rc;
     // measured at N = 8192, M = 1024, B = 8 (scripts/time_fps.py): deal 1 / 2 / 4 / 8 -> 0.812 / 0.783 / 0.757 / 0.748 us per round
     static const int deal_env = getenv("G4D_FPS_DEAL") ? atoi(getenv("G4D_FPS_DEAL")) : 0;  // tuning hook: 1 | 2 | 4 | ... | P; 0 = P
     const int deal = (deal_env >= 1 && deal_env <= P && P % deal_env == 0) ? deal_env : P;
@@ -595,26 +693,26 @@ int fps_bucket_grid_launch(int b, int n, int m, int bs, int log2bs, const float 
     if (!(n > 4096 && n <= 8192)) return -1;
     constexpr int W = 16, P = 8;
     const size_t npad = (size_t)64 * W * P;
-    const size_t body = npad * 8 > (size_t)n * 12 ? npad * 8 : (size_t)n * 12;
+    const bool multi = fps_multi() > 1;
+    const bool soa = !multi || fps_soa(b);
+    const size_t body = (!soa || npad * 8 > (size_t)n * 12) ? npad * 8 : (size_t)n * 12;
     const size_t pick_off = (kFpsHdr + body + 15) & ~(size_t)15;
     const int cmax = grid_cmax(n);
     const size_t lds_fps = pick_off + (size_t)m * 4, lds_grid = ((size_t)cmax + 1) * 4 + 16 * 8 * 4;
     const size_t lds = lds_fps > lds_grid ? lds_fps : lds_grid;
     if (lds > 160 * 1024 - 1024) return -1;   // (pick list too long for LDS: the caller falls back to two launches)
-    static unsigned long long attr[6] = {0, 0, 0, 0, 0, 0};
+    static unsigned long long attr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int mode = distance_contraction();
-    const bool multi = fps_multi() > 1;
-    const int slot = (mode == 0 ? 0 : (mode == 1 ? 1 : 2)) + (multi ? 3 : 0);
+    const int slot = (mode == 0 ? 0 : (mode == 1 ? 1 : 2)) + (multi ? (soa ? 3 : 6) : 0);
     const void *k = nullptr;
-    G4D_WITH_FM(mode, k = multi ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 8>) : reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 1>))
+    G4D_WITH_FM(mode, k = multi ? (soa ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 8>) : reinterpret_cast<const void *>(fps_bucket_grid_reg_kernel<FM, 8>))
+                                : reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 1>))
     if (const int rc = ensure_dynamic_lds(k, 160 * 1024 - 1024, attr[slot], "g4d_fps_gather_grid_f32")) return rc;
-    if (multi) {
-        G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_bucket_grid_kernel<FM, 8>), dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P | (fps_kcap() << 8), (int)pick_off, xyz, idx, nx,
-                                             cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
-    } else {
-        G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_bucket_grid_kernel<FM, 1>), dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P | (fps_kcap() << 8), (int)pick_off, xyz, idx, nx,
-                                             cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
-    }
+#define G4D_GRID_LAUNCH(KM, KERN)                                                                                                                                    \
+    G4D_WITH_FM(mode, hipLaunchKernelGGL((KERN<FM, KM>), dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P | (fps_kcap() << 8), (int)pick_off, xyz, idx, nx, \
+                                         cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
+    if (multi && soa) { G4D_GRID_LAUNCH(8, fps_bucket_grid_kernel) } else if (multi) { G4D_GRID_LAUNCH(8, fps_bucket_grid_reg_kernel) } else { G4D_GRID_LAUNCH(1, fps_bucket_grid_kernel) }
+#undef G4D_GRID_LAUNCH
     return check_launch("g4d_fps_gather_grid_f32");
 }
 
