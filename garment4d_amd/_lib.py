@@ -92,6 +92,9 @@ SIGNATURES = {
     "g4d_launch_group_abort": [],
     "g4d_lbs_one_supported": [_I, _I],
     "g4d_lbs_one_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "g4d_lbs_mfma_supported": [_I, _I],
+    "g4d_lbs_mfma_ws_bytes": [_I, _I],
+    "g4d_lbs_mfma_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
     "g4d_lbs_fused_f32": [_I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_segment_select_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp],
     "g4d_segment_take_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp],
@@ -109,7 +112,7 @@ SIGNATURES = {
 _lib = None
 
 
-RESTYPES = {"g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
+RESTYPES = {"g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):

@@ -453,6 +453,272 @@ __global__ void __launch_bounds__(64 * kOneKS) lbs_one_kernel(int B, int V, int 
   }
 }
 
+
+// ---- lbs() on the matrix pipe (round 5) -----------------------------------------------------------------------------------------------
+// The pose / shape blend of B frames is a (V*3 x NC) . (NC x B) GEMM (NC = NB + 9 (J - 1) = 217 for SMPL) and the blend of the joint
+// transforms T = W . A a (V x J) . (J x 12 B) one; lbs_one_kernel runs both on the VALU and repeats the per-frame Rodrigues + kinematic
+// chain in every vertex tile (189 us per 240 frames, 0.04 of the HBM roofline).  Here:
+//   lbs_frame_kernel   one wave per frame, ONCE: rotations, joints from betas, the 23-step chain (the code of lbs_one_kernel's step 2),
+//                      A / posed joints to their outputs, and the two B operands of the GEMMs in fragment order to a workspace:
+//                      coefficients C[f][q][ks] = c_f[4 ks + q] (c = [betas | R - I], zero padded to 4 KS) and transforms
+//                      At[f][q][e][js] = A_f[4 js + q][e] (e = 0..11 of the 3x4 part, zero beyond J);
+//   lbs_mfma_kernel    a workgroup owns 32 vertices: their blend rows (NC x 96 floats = 86 KB, read from HBM once per launch) sit in
+//                      LDS in A-operand fragment order, their skinning weights in registers; its 8 waves walk the 16-frame tiles.  Per
+//                      (frame tile, 16-vertex half): v_posed^T (vertices x frames, one accumulator tile per coordinate, started from
+//                      v_template) = 3 x KS v_mfma_f32_16x16x4_f32, T^T (one tile per transform entry) = 12 x JS, and because both are
+//                      (vertices x frames) tiles a lane ends with the posed vertex AND the complete 3x4 transform of the same four
+//                      (vertex, frame) pairs: the final T . [v; 1] is 9 FMAs per pair in registers, 48 contiguous bytes stored per lane.
+// Every output element is one accumulator chain over k ascending, whatever the batch: a frame's bits do not depend on the frames it is
+// launched with (tests/test_pipeline_gpu.py, test_large_launch_gpu.py).
+namespace {
+constexpr int kMfKS = 56;     // k-steps of 4 blend rows (224 >= 217)
+constexpr int kMfVT = 32;     // vertices per workgroup (two 16-vertex halves)
+constexpr int kMfWaves = 8;
+typedef float mf_f4 __attribute__((ext_vector_type(4)));
+typedef float mf_f2 __attribute__((ext_vector_type(2)));
+}  // namespace
+
+__global__ void __launch_bounds__(256) lbs_frame_kernel(int B, int J, int NB, int JS, int pose2rot, const float *__restrict__ betas, int betas_bstride,
+                                                        const float *__restrict__ pose, const float *__restrict__ Jt, const float *__restrict__ Js,
+                                                        const int *__restrict__ parents, float *__restrict__ A_out, float *__restrict__ posed_joints,
+                                                        float *__restrict__ Cws, float *__restrict__ Aws) {
+    __shared__ float sR_[4][kOneJ * 9], sJ_[4][kOneJ * 3], sL_[4][kOneJ * 12], sG_[4][kOneJ * 12], sC_[4][4 * kMfKS];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= B) return;   // (wave-local LDS exchange only: no workgroup barrier below)
+    float *R_ = sR_[w], *J_ = sJ_[w], *L_ = sL_[w], *G_ = sG_[w], *C_ = sC_[w];
+    const int NC = NB + (J - 1) * 9;
+    for (int i = l; i < 4 * kMfKS; i += 64) C_[i] = 0.f;
+    wave_sync_lds();
+    if (l < J) {
+        float R[9];
+        if (pose2rot) {
+            const float *pp = pose + ((size_t)b * J + l) * 3;
+            rodrigues(pp[0], pp[1], pp[2], R);
+        } else {
+            const float *pp = pose + ((size_t)b * J + l) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = pp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R_[l * 9 + k] = R[k];
+        const float *be = betas + (size_t)b * betas_bstride;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {   // J_regressor (v_template + shapedirs beta) = Jt + Js beta  (lbs.py:209 through two model constants)
+            float acc = Jt[l * 3 + r];
+#pragma unroll 10
+            for (int k = 0; k < NB; ++k) acc = fmaf(Js[(l * 3 + r) * NB + k], be[k], acc);
+            J_[l * 3 + r] = acc;
+        }
+        if (l > 0) {                    // lbs.py:217 / :222  (R[1:] - I)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) C_[NB + (l - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
+        }
+    }
+    if (l < NB) C_[l] = betas[(size_t)b * betas_bstride + l];
+    wave_sync_lds();
+    if (l < J) {  // local transform [R | J - J_parent]  (lbs.py:390-396)
+        const int p = parents[l];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            L_[l * 12 + r * 4 + 0] = R_[l * 9 + r * 3 + 0];
+            L_[l * 12 + r * 4 + 1] = R_[l * 9 + r * 3 + 1];
+            L_[l * 12 + r * 4 + 2] = R_[l * 9 + r * 3 + 2];
+            L_[l * 12 + r * 4 + 3] = (l > 0) ? (J_[l * 3 + r] - J_[p * 3 + r]) : J_[l * 3 + r];
+        }
+    }
+    wave_sync_lds();
+    if (l < 12) G_[l] = L_[l];
+    wave_sync_lds();
+    for (int i = 1; i < J; ++i) {  // G_i = G_parent(i) . L_i   (lbs.py:399-405)
+        if (l < 12) {
+            const int p = parents[i], r = l >> 2, c = l & 3;
+            float acc = G_[p * 12 + r * 4 + 0] * L_[i * 12 + 0 * 4 + c];
+            acc = fmaf(G_[p * 12 + r * 4 + 1], L_[i * 12 + 1 * 4 + c], acc);
+            acc = fmaf(G_[p * 12 + r * 4 + 2], L_[i * 12 + 2 * 4 + c], acc);
+            if (c == 3) acc += G_[p * 12 + r * 4 + 3];
+            G_[i * 12 + l] = acc;
+        }
+        wave_sync_lds();
+    }
+    if (l < J) {  // A = G with the rest-pose joint removed (lbs.py:414-417)
+        const float jx = J_[l * 3 + 0], jy = J_[l * 3 + 1], jz = J_[l * 3 + 2];
+        float *Ag = A_out + ((size_t)b * J + l) * 16;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float g0 = G_[l * 12 + r * 4 + 0], g1 = G_[l * 12 + r * 4 + 1], g2 = G_[l * 12 + r * 4 + 2], g3 = G_[l * 12 + r * 4 + 3];
+            const float tr = g3 - fmaf(g2, jz, fmaf(g1, jy, g0 * jx));
+            Ag[r * 4 + 0] = g0; Ag[r * 4 + 1] = g1; Ag[r * 4 + 2] = g2; Ag[r * 4 + 3] = tr;
+            if (posed_joints) posed_joints[((size_t)b * J + l) * 3 + r] = g3;  // lbs.py:410
+            L_[l * 12 + r * 4 + 0] = g0; L_[l * 12 + r * 4 + 1] = g1; L_[l * 12 + r * 4 + 2] = g2; L_[l * 12 + r * 4 + 3] = tr;
+        }
+        Ag[12] = 0.f; Ag[13] = 0.f; Ag[14] = 0.f; Ag[15] = 1.f;
+    }
+    wave_sync_lds();
+    // the GEMMs' B operands in fragment order PER 16-FRAME TILE: load g of the main kernel's lane (frame fi, quarter fq) is the 16 bytes at
+    // [tile][g][fq * 16 + fi][0..3] -- one 1 KB run per wave and load.  (Per-frame rows, 16 bytes out of a different cache line for every
+    // lane, kept the CU's vector-memory path busier than its matrix pipe: 55 us per 240 frames instead of 35.)
+    const int tile = b >> 4, bi = b & 15;
+    float *cw = Cws + (size_t)tile * (kMfKS / 4) * 256;
+    for (int i = l; i < 4 * kMfKS; i += 64) {      // i = (g, q, s): coefficient k = 4 (4 g + s) + q
+        const int g = i >> 4, q = (i >> 2) & 3, s4 = i & 3, k = 4 * (4 * g + s4) + q;
+        cw[(g * 64 + q * 16 + bi) * 4 + s4] = k < NC ? C_[k] : 0.f;
+    }
+    float *aw = Aws + (size_t)tile * 3 * JS * 256;
+    for (int i = l; i < 4 * 12 * JS; i += 64) {    // i = (q, flat = e JS + js): transform entry e of joint j = 4 js + q, flat / 4 = load, flat % 4 = element
+        const int q = i / (12 * JS), flat = i - q * 12 * JS, e = flat / JS, js = flat - e * JS, j = 4 * js + q;
+        aw[((flat >> 2) * 64 + q * 16 + bi) * 4 + (flat & 3)] = j < J ? L_[j * 12 + e] : 0.f;
+    }
+}
+
+template <int JS>
+__global__ void __launch_bounds__(64 * kMfWaves) lbs_mfma_kernel(int B, int V, int J, int NC, const float *__restrict__ v_template,
+                                                                const float *__restrict__ blend_dirs, const float *__restrict__ weights,
+                                                                const float *__restrict__ Cws, const float *__restrict__ Aws, float *__restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) float mf_smem[];   // [2 halves][3 coords][14 groups][4 q][16 vertices][4 k-steps]
+    constexpr int KG = kMfKS / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fq = lane >> 4;
+    const int v0 = blockIdx.x * kMfVT;
+    const size_t E = (size_t)V * 3;
+    // ---- the tile's blend rows, HBM -> LDS once.  Row k, column e = 3 (v - v0) + c  ->  [half][c][k / 16][k % 4][v % 16][(k / 4) % 4]
+    // (the first frame tile's coefficients do not depend on the tile: requested first, they arrive while the rows are staged)
+    const int nft = (B + 15) / 16;
+    // work units: (frame tile ft, half st), u = 2 ft + st.  Many frame tiles: a wave takes both halves of tiles wave, wave + 8, ... one after
+    // the other (the second half's B operands are the first's again: L1 hits); few (small batches): unit u goes to wave u % 8, so that two
+    // waves share even a single tile.
+    const bool split = nft < kMfWaves;
+    const int nunit = 2 * nft;
+    const int u_first = split ? wave : 2 * wave;
+    auto next_unit = [&](int u) { return split ? u + kMfWaves : ((u & 1) ? u + 2 * kMfWaves - 1 : u + 1); };
+    mf_f4 cf4[KG];
+    auto load_cf = [&](int u) {                                // (always executed: a load under a condition makes the compiler drain every load at the join)
+        const int tile = min(u, nunit - 1) >> 1;                // units past the end: clamped, never used.  Frames past B in the last tile: columns of
+        const mf_f4 *cp = reinterpret_cast<const mf_f4 *>(Cws + (size_t)tile * KG * 256) + lane;   // their own in every MFMA, never stored (the workspace covers whole tiles)
+#pragma unroll
+        for (int g = 0; g < KG; ++g) cf4[g] = cp[g * 64];
+    };
+    load_cf(u_first);
+    {
+        const int ncol = min(kMfVT * 3, (int)(E - (size_t)v0 * 3));          // (the last tile is ragged)
+        constexpr int NIT = 4 * kMfKS * (kMfVT * 3 / 2) / (64 * kMfWaves);   // 21 float2 per thread, all requested before the first is stored
+        static_assert(NIT * 64 * kMfWaves == 4 * kMfKS * (kMfVT * 3 / 2), "row staging: whole passes");
+        mf_f2 d[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 64 * kMfWaves;
+            const int k = i / (kMfVT * 3 / 2), e = (i - k * (kMfVT * 3 / 2)) * 2;
+            d[it] = (mf_f2){0.f, 0.f};
+            if (k < NC && e < ncol) {   // 3 v0 + e is even: a row's pairs are 8-byte aligned when k E is (E even: every row; E odd: every other one)
+                const float *src = blend_dirs + (size_t)k * E + (size_t)v0 * 3 + e;
+                if (((E & 1) == 0 || (k & 1) == 0) && e + 1 < ncol) d[it] = *reinterpret_cast<const mf_f2 *>(src);
+                else { d[it].x = src[0]; d[it].y = e + 1 < ncol ? src[1] : 0.f; }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 64 * kMfWaves;
+            const int k = i / (kMfVT * 3 / 2), e = (i - k * (kMfVT * 3 / 2)) * 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ee = e + h, vv = ee / 3, c = ee - vv * 3;
+                mf_smem[(((((vv >> 4) * 3 + c) * KG + (k >> 4)) * 4 + (k & 3)) * 16 + (vv & 15)) * 4 + ((k >> 2) & 3)] = h ? d[it].y : d[it].x;
+            }
+        }
+    }
+    // skinning weights of the two halves as A-operand fragments (lane (vertex fi, quarter fq) holds W[v][4 js + fq]) and the template
+    // coordinates of the tile, both in LDS behind the blend rows: what a lane keeps in registers across the frame tiles is B operands only
+    float *s_w = mf_smem + 2 * 3 * KG * 256;          // [2][JS][64]
+    float *s_t = s_w + 2 * JS * 64;                   // [32][3] + pad
+    for (int i = tid; i < 2 * JS * 64; i += 64 * kMfWaves) {
+        const int st = i / (JS * 64), js = (i / 64) % JS, ln = i & 63;
+        const int v = min(v0 + st * 16 + (ln & 15), V - 1), j = 4 * js + (ln >> 4);
+        s_w[i] = j < J ? weights[(size_t)v * J + j] : 0.f;
+    }
+    for (int i = tid; i < kMfVT * 3; i += 64 * kMfWaves) s_t[i] = v_template[min((size_t)v0 * 3 + i, E - 1)];
+    __syncthreads();
+
+    // B operands: the coefficients of the NEXT unit are requested when this unit's blend has consumed them (they fly during the transform
+    // blend), the transforms of THIS unit at its start (first used after 168 MFMAs).
+    for (int u = u_first; u < nunit; u = next_unit(u)) {
+        const int ft = u >> 1, st = u & 1;
+        mf_f4 am4[3 * JS];                                      // am4[flat / 4][flat % 4], flat = e JS + js: A_f[4 js + fq][e]
+        {
+            const mf_f4 *ap = reinterpret_cast<const mf_f4 *>(Aws + (size_t)ft * 3 * JS * 256) + lane;
+#pragma unroll
+            for (int i4 = 0; i4 < 3 * JS; ++i4) am4[i4] = ap[i4 * 64];
+        }
+        {
+            mf_f4 vp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[c] = (mf_f4){0.f, 0.f, 0.f, 0.f};
+            // pose + shape blend: rows = the half's 16 vertices, columns = the tile's 16 frames, k ascending
+            const float *dl = mf_smem + (size_t)st * 3 * KG * 256 + (fq * 16 + fi) * 4;
+            {   // the three coordinates' accumulators take turns (consecutive MFMAs are independent; each accumulator still sees k ascending); the
+                // fragments of k-group g + 1 are requested before group g's MFMAs; fenced, or the scheduler requests all 42 up front (168 registers)
+                mf_f4 ring[2][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ring[0][c] = *reinterpret_cast<const mf_f4 *>(dl + (c * KG) * 256);
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    if (g + 1 < KG) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) ring[(g + 1) & 1][c] = *reinterpret_cast<const mf_f4 *>(dl + (c * KG + g + 1) * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) vp[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[g & 1][c][s4], cf4[g][s4], vp[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_cf(next_unit(u));
+            __builtin_amdgcn_sched_barrier(0);
+            // v_posed = v_template + blend  (lbs.py:205, :223-229: the template is added to the finished sums, as the reference does)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vp[c][r] += s_t[(st * 16 + 4 * fq + r) * 3 + c];
+            float wfr[JS];
+#pragma unroll
+            for (int js = 0; js < JS; ++js) wfr[js] = s_w[(st * JS + js) * 64 + lane];
+            const bool frame_ok = ft * 16 + fi < B;
+            float *o = verts + (size_t)(ft * 16 + fi) * E + (size_t)(v0 + st * 16 + 4 * fq) * 3;
+            float res[12];                                      // the lane's four vertices x three coordinates: 48 contiguous bytes of the frame
+            // T = W . A  (lbs.py:238), one tile per entry of the 3x4 transform, a row of the transform (four entries) at a time; then
+            // verts = T . [v_posed; 1]  (lbs.py:244): lane (frame fi, vertices 4 fq + r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                mf_f4 T[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T[e] = (mf_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int js = 0; js < JS; ++js) {
+                        const int flat = (4 * c + e) * JS + js;
+                        T[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[js], am4[flat / 4][flat % 4], T[e], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[r * 3 + c] = fmaf(T[2][r], vp[2][r], fmaf(T[1][r], vp[1][r], T[0][r] * vp[0][r])) + T[3][r];
+            }
+            if (frame_ok) {
+                if (v0 + st * 16 + 4 * fq + 3 < V) {   // three 16-byte stores (dword-aligned addresses: a frame's rows start at multiples of 4 E bytes)
+                    typedef float mf_f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) *reinterpret_cast<mf_f4u *>(o + 4 * h) = (mf_f4u){res[4 * h], res[4 * h + 1], res[4 * h + 2], res[4 * h + 3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (v0 + st * 16 + 4 * fq + r < V) { o[r * 3 + 0] = res[r * 3 + 0]; o[r * 3 + 1] = res[r * 3 + 1]; o[r * 3 + 2] = res[r * 3 + 2]; }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace g4d
 
 using namespace g4d;
@@ -576,4 +842,41 @@ extern "C" int g4d_lbs_one_f32(int b, int v, int j, int nb, int pose2rot, const 
     hipLaunchKernelGGL(lbs_one_kernel, dim3(vt, gy), dim3(64 * kOneKS), lds, G4D_S(stream), b, v, j, nb, pose2rot,
                        betas, betas_bstride, pose, v_template, blend_dirs, J_template, J_shapedirs, parents, lbs_weights, A_out, posed_joints, verts);
     return check_launch("g4d_lbs_one_f32");
+}
+
+// lbs() on the matrix pipe (lbs_frame_kernel + lbs_mfma_kernel, above).  ws: device workspace of g4d_lbs_mfma_ws_bytes(b, j) bytes
+// (16-byte aligned), owned by the caller (the B operands of the two GEMMs in fragment order).
+extern "C" int g4d_lbs_mfma_supported(int j, int nb) { return j > 0 && j <= kOneJ && nb >= 0 && nb + (j - 1) * 9 <= 4 * kMfKS; }
+extern "C" long long g4d_lbs_mfma_ws_bytes(int b, int j) {
+    const int js = j <= 24 ? 6 : 8;
+    return (long long)((b > 0 ? b : 0) + 15) / 16 * 16 * 4 * (kMfKS + 12 * js) * (long long)sizeof(float);   // whole 16-frame tiles
+}
+extern "C" int g4d_lbs_mfma_f32(int b, int v, int j, int nb, int pose2rot, const float *betas, int betas_bstride, const float *pose,
+                                const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
+                                const int *parents, const float *lbs_weights, float *A_out, float *posed_joints, float *verts, void *ws,
+                                long long ws_bytes, g4d_stream_t stream) {
+    G4D_REQUIRE(b >= 0 && v > 0 && g4d_lbs_mfma_supported(j, nb), "g4d_lbs_mfma_f32: need V > 0, J <= 32 and NB + 9 (J - 1) <= 224 (use g4d_lbs_fused_f32)");
+    if (b == 0) return G4D_OK;
+    G4D_REQUIRE(betas && pose && v_template && blend_dirs && J_template && J_shapedirs && parents && lbs_weights && A_out && verts && ws,
+                "g4d_lbs_mfma_f32: null pointer");
+    G4D_REQUIRE(ws_bytes >= g4d_lbs_mfma_ws_bytes(b, j) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "g4d_lbs_mfma_f32: workspace too small or not 16-byte aligned");
+    const int js = j <= 24 ? 6 : 8;
+    float *Cws = reinterpret_cast<float *>(ws), *Aws = Cws + (size_t)((b + 15) / 16) * 16 * 4 * kMfKS;
+    hipLaunchKernelGGL(lbs_frame_kernel, dim3((b + 3) / 4), dim3(256), 0, G4D_S(stream), b, j, nb, js, pose2rot, betas, betas_bstride, pose, J_template,
+                       J_shapedirs, parents, A_out, posed_joints, Cws, Aws);
+    if (const int rc = check_launch("g4d_lbs_mfma_f32(frames)")) return rc;
+    const int lds = (int)sizeof(float) * (2 * 3 * (kMfKS / 4) * 256 + 2 * js * 64 + kMfVT * 3 + 32);   // 86 KB of blend rows + weights + template
+    const int nc = nb + (j - 1) * 9;
+    if (js == 6) {
+        static unsigned long long attr = 0;
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(lbs_mfma_kernel<6>), lds, attr, "g4d_lbs_mfma_f32")) return rc;
+        hipLaunchKernelGGL(lbs_mfma_kernel<6>, dim3((v + kMfVT - 1) / kMfVT), dim3(64 * kMfWaves), lds, G4D_S(stream), b, v, j, nc, v_template, blend_dirs,
+                           lbs_weights, Cws, Aws, verts);
+    } else {
+        static unsigned long long attr = 0;
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(lbs_mfma_kernel<8>), lds, attr, "g4d_lbs_mfma_f32")) return rc;
+        hipLaunchKernelGGL(lbs_mfma_kernel<8>, dim3((v + kMfVT - 1) / kMfVT), dim3(64 * kMfWaves), lds, G4D_S(stream), b, v, j, nc, v_template, blend_dirs,
+                           lbs_weights, Cws, Aws, verts);
+    }
+    return check_launch("g4d_lbs_mfma_f32");
 }

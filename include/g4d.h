@@ -31,7 +31,7 @@ typedef struct ihipStream_t *g4d_stream_t; /* == hipStream_t */
 #define G4D_OK 0
 #define G4D_EINVAL 10001 /* bad argument (negative size, null pointer, unsupported width) */
 
-int g4d_version(void); /* 100 * major + minor: 200 = round 2 (the `boxes` scratch of g4d_ball_query_boxes_f32 grew to 16-point sub-blocks) */
+int g4d_version(void); /* 100 * major + minor: 200 = round 2 (the `boxes` scratch of g4d_ball_query_boxes_f32 grew to 16-point sub-blocks); 205 = round 5 (entry points added, none changed) */
 const char *g4d_last_error(void);
 
 /* ---- numerics: how the squared distance of FPS / ball query / three_nn / knn is rounded ---------------------------------
@@ -519,6 +519,20 @@ int g4d_lbs_one_f32(int b, int v, int j, int nb, int pose2rot, const float *beta
                     const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
                     const int *parents, const float *lbs_weights, float *A_out, float *posed_joints, float *verts,
                     g4d_stream_t stream);
+
+/* lbs() on the matrix pipe (round 5; csrc/lbs.hip lbs_frame_kernel + lbs_mfma_kernel), same constants and outputs as g4d_lbs_one_f32
+ * (replaces /root/reference/smplx/smplx/lbs.py:152-248 for a batch of frames).  Launch 1, one wave per frame, ONCE per frame: Rodrigues, joints
+ * from betas, kinematic chain -> A_out, posed_joints and the B operands of the two GEMMs (fragment order) in `ws`.  Launch 2, a workgroup per
+ * 32 vertices: their blend rows (NC x 96 floats, 86 KB) in LDS, read from HBM once per launch; per (16-frame tile, 16-vertex half)
+ * v_posed^T and T^T = (W . A)^T as fp32 MFMA tiles (vertices x frames), so a lane ends with the posed vertex and the full 3x4 transform of the
+ * same four (vertex, frame) pairs.  Every output element is one accumulator chain over k ascending: a frame's bits do not depend on the batch.
+ * ws: device memory, 16-byte aligned, >= g4d_lbs_mfma_ws_bytes(b, j) bytes, owned by the caller.  Supported when J <= 32, NB + 9 (J - 1) <= 224. */
+int g4d_lbs_mfma_supported(int j, int nb);
+long long g4d_lbs_mfma_ws_bytes(int b, int j);
+int g4d_lbs_mfma_f32(int b, int v, int j, int nb, int pose2rot, const float *betas, int betas_bstride, const float *pose,
+                     const float *v_template, const float *blend_dirs, const float *J_template, const float *J_shapedirs,
+                     const int *parents, const float *lbs_weights, float *A_out, float *posed_joints, float *verts, void *ws,
+                     long long ws_bytes, g4d_stream_t stream);
 
 /* ---- callers around the hot path ---------------------------------------------- */
 
