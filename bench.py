@@ -235,6 +235,17 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             ev = float(b_) * n_ * m_
             row.update(what=f"three_nn {n_} <- {m_} known points, {b_} clouds: brute-force scan over cell-ordered queries", bound="valu", evals=ev,
                        lane_ops_per_eval=7, achieved=ev * 7 / (t_us * 1e-6), peak=VALU_LANE_OPS_PEAK, unit="lane-op/s", algorithmic_bytes=b_ * (12 * (n_ + m_) + 24 * n_))
+        elif nm == "g4d_lbs_mfma_f32":
+            b_, v_, j_, nb_ = iv[0], iv[1], iv[2], iv[3]
+            nc_ = nb_ + (j_ - 1) * 9
+            by = b_ * (12 * v_ + 64 * j_ + 12 * v_) + 4.0 * v_ * 3 * nc_ + 4.0 * v_ * j_
+            # the matrix-pipe work the two launches execute: whole 16-frame x 16-vertex tiles, 56 k-steps of the blend, 6 of the transform blend
+            tiles = ((b_ + 15) // 16) * ((v_ + 31) // 32) * 2
+            ex = tiles * (3 * 56 + 12 * (6 if j_ <= 24 else 8)) * 2048.0
+            row.update(what=f"lbs() of {b_} frames (V = {v_}, J = {j_}): per-frame rigid chains (one launch), then pose / shape blend and transform blend as fp32 MFMA "
+                            "tiles, the 32-vertex tile's blend rows in LDS (read from HBM once per launch), vertices out",
+                       bound="hbm", algorithmic_bytes=by, mfma_executed_flops=ex, mfma_frac=ex / (t_us * 1e-6) / mfma_peak if precision == "fp32" else ex / (t_us * 1e-6) / (MFMA_F32_PEAK_TFLOPS * 1e12),
+                       algorithmic_flops=b_ * (2.0 * v_ * 3 * nc_ + 2.0 * v_ * j_ * 12 + 18.0 * v_))
         elif nm == "g4d_lbs_one_f32":
             b_, v_, j_, nb_ = iv[0], iv[1], iv[2], iv[3]
             by = b_ * (12 * v_ + 64 * j_ + 12 * v_) + 4.0 * v_ * 3 * (nb_ + (j_ - 1) * 9) + 4.0 * v_ * j_
@@ -276,13 +287,14 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
         roof["roofline"]["note"] = ("the launch with the largest GPU time of a coalesced call; timed live with HIP events on the launching stream; `achieved` counts the MFMA flops "
                                     "the launch executes (the feature part of its first layer runs once per source point in the table launch before it)")
         ex = sum(r["executed_flops"] for r in mf)
+        roof["executed_flops_per_call"] = ex + sum(r.get("mfma_executed_flops", 0.0) for r in rows_out)
         roof["roofline_mfma_all"] = {"bound": "mfma", "launches": len(mf), "us": sum(r["us"] for r in mf), "executed_flops": ex,
                                      "achieved": ex / (sum(r["us"] for r in mf) * 1e-6) / 1e12, "peak": mfma_peak / 1e12, "unit": "TFLOP/s",
                                      "frac": ex / (sum(r["us"] for r in mf) * 1e-6) / mfma_peak, "share_of_call": sum(r["us"] for r in mf) / total}
     fps = next((r for r in rows_out if r["entry"] == "g4d_fps_gather_grid_f32"), None)
     if fps is not None:
-        tr = pmc_traffic("fps_bucket_grid_kernel")
-        roof["roofline_fps"] = dict(fps, kernel="fps_bucket_grid_kernel<FM, 8>", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
+        tr = pmc_traffic("fps_bucket_grid_reg_kernel") or pmc_traffic("fps_bucket_grid_kernel")
+        roof["roofline_fps"] = dict(fps, kernel="fps_bucket_grid_reg_kernel<FM, 8> (register form: 64 VGPRs, 70 KB of LDS; from 32 clouds per launch on)", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
                                     traffic_source=None if tr is None else tr["source"], share_of_call=fps["us"] / total,
                                     traffic_over_algorithmic_incl_grid_role=None if tr is None else tr["bytes"] / (fps["algorithmic_bytes"] + fps["grid_role_bytes"]),
                                     note="serial-dependency bound: dependent rounds, one workgroup per cloud; neither HBM nor MFMA limits it (frac is against HBM only "
@@ -588,7 +600,7 @@ def main():
             "config": {"workload": ("cfg2: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head) fp32" if args.precision == "fp32" else
                                     f"cfg3 precision on the cfg2 step: B=8 N=8192 Pointnet2MSGSEG-spec encoder (3xSA-MSG + 3xFP + head), shared-MLP operands {args.precision}")
                                    + (" + SMPL lbs() of the 8 frames (V=6890,J=24)" if with_lbs else ""),
-                       "frames_per_step": B_CLOUDS, "coalesce": kco, "clouds_per_call": B_CLOUDS * kco, "calls_in_flight": ns,
+                       "frames_per_step": B_CLOUDS, "repeats": repeats, "timed_seconds": dt, "timed_steps": total_steps, "coalesce": kco, "clouds_per_call": B_CLOUDS * kco, "calls_in_flight": ns,
                        "batches_in_flight": ns * kco, "hipgraph": not args.no_graph,
                        "executor": "garment4d_amd.pipeline.StepPipeline: steps are submitted one B=8 batch at a time; `coalesce` consecutive steps run as "
                                    "one call on 8*coalesce clouds (bit-identical per cloud), `calls_in_flight` calls overlap on their own streams",
@@ -611,6 +623,11 @@ def main():
                                                                                               for k, v in r.items() if k in ("entry", "what", "us", "us_per_step", "bound", "frac")} for r in table]},
             # SURVEY 8(d) whole-path fractions, per GPU: frames/s x per-frame algorithmic cost / peak
             "whole_path": {"mfma_frac": per_gpu * 2.22e9 / (MFMA_F32_PEAK_TFLOPS * 1e12 if args.precision == "fp32" else 2.5e15),
+                           # what the matrix pipe actually delivers: the MFMA flops one coalesced call EXECUTES (first layers pre-contracted per source point in fp32
+                           # mode; lbs()'s tiles included) per frame x frames/s / peak -- utilisation, where mfma_frac is the algorithmic-work rate
+                           "mfma_frac_executed": None if not roof.get("executed_flops_per_call") else
+                           per_gpu * roof["executed_flops_per_call"] / (B_CLOUDS * kco) / (MFMA_F32_PEAK_TFLOPS * 1e12 if args.precision == "fp32" else 2.5e15),
+                           "executed_gflop_per_frame": None if not roof.get("executed_flops_per_call") else roof["executed_flops_per_call"] / (B_CLOUDS * kco) / 1e9,
                            "mfma_peak": "157.3 TFLOP/s fp32" if args.precision == "fp32" else "2.5 PFLOP/s bf16 dense",
                            "hbm_frac_of_unfused_op_traffic": per_gpu * 42.5e6 / (HBM_PEAK_GBS * 1e9),
                            "hbm_frac_of_fused_lower_bound": per_gpu * 8.0e6 / (HBM_PEAK_GBS * 1e9),
