@@ -784,14 +784,15 @@ extern "C" int g4d_mlp_chain_table_cells_f32(long long rows, int n, int m, int C
 //   W [x_j - q ; f_j] = Wx (x_j - q) + Wf f_j,   and Wf f_j depends on the SOURCE point j only
 // -- `table` row j (stride tab_ld, Kt columns used) = Wf f_j, computed once per level over the N source points instead of once per
 // (centroid, sample) pair; tab_wx = Wx transposed, [3][Kt]; the layer itself is relu((table[j] + Wx (x_j - q)) * pre_scale + pre_shift)
-// inside the loader.  W / scale / ... describe the REMAINING layers; pooling as in g4d_mlp_chain_f32.
+// inside the loader.  W / scale / ... describe the REMAINING layers; pooling as in g4d_mlp_chain_f32.  tab_ld = 0: every source point shares
+// ONE table row (an xyz-only stack: a row of zeros -- BASELINE config 5's [3, 64, 64, 128] on the persistent kernel of sa_table.hip).
 extern "C" int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx,
                                              const float *table, int tab_ld, int Kt, const float *tab_wx, const float *pre_scale,
                                              const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
                                              const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool,
                                              float *out, int ldo, int col0, g4d_stream_t stream) {
     G4D_REQUIRE(table && Kt > 0, "g4d_mlp_chain_group_table_f32: null table");
-    if (xyz && new_xyz && idx && tab_wx && pre_scale && pre_shift && W && scale && shift && Kpad && Cout && relu && out && tab_ld >= Kt && tab_ld % 4 == 0 &&
+    if (xyz && new_xyz && idx && tab_wx && pre_scale && pre_shift && W && scale && shift && Kpad && Cout && relu && out && (tab_ld >= Kt || tab_ld == 0) && tab_ld % 4 == 0 &&
         (reinterpret_cast<size_t>(table) & 15) == 0 && P > 0 && N > 0) {
         // large launches: the persistent, software-pipelined kernel (sa_table.hip; bit-identical results).  Inside a launch group it simply goes out
         // on its own -- merging launches pays only while they are small.

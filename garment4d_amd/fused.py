@@ -40,7 +40,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3", "_raw")
+    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3", "_raw", "_xyz_table")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -63,7 +63,7 @@ class PackedLayer:
         Wc16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 32)[..., kperm].permute(0, 2, 3, 1, 4).contiguous()
         self.W, self.Wf, self.Wf16, self.Wc16, self.scale, self.shift = W, Wf, Wf16, Wc16, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
-        self._kperm, self._x3, self._raw = kperm, None, None
+        self._kperm, self._x3, self._raw, self._xyz_table = kperm, None, None, None
 
     def raw(self):
         """The same contraction without the affine and the ReLU (scale 1, shift 0): the table side of a pre-contracted layer."""
@@ -611,6 +611,7 @@ SA_XYZ_PAIR = os.environ.get("G4D_SA_XYZ_PAIR", "1") != "0"   # ... and both suc
 USE_SA_XYZ = os.environ.get("G4D_SA_XYZ", "1") != "0"   # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
 
 
+SA_XYZ_TABLE = os.environ.get("G4D_SA_XYZ_TABLE", "1") != "0"   # wide xyz-only stacks ([3, C, C, 2C], C = 32 / 64 / 128) on sa_table.hip's persistent kernel (A/B switch)
 SA_TABLE = os.environ.get("G4D_SA_TABLE", "1") != "0"   # SA levels with features: feature part of the first layer pre-contracted per source point
 
 
@@ -647,7 +648,7 @@ def sa_level_table(sa, packed, feats_pm, scales):
     return table, offs
 
 
-def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=None):
+def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=None, tab_ld=None):
     """One scale of an SA level: gather idx (B,P,S) around new_xyz, the shared-MLP stack `layers`, pooling over S, into out[..., col0:].
     Picks the kernel family (sa_xyz.hip / register chain / LDS stack / per layer).  table = (tensor (B*N, ld), column offset, Wx^T):
     the feature part of the first layer already contracted per source point (sa_level_table)."""
@@ -660,7 +661,7 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
         L0, rest = layers[0], layers[1:]
         PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
         _lib.call("g4d_mlp_chain_group_table_f32", B * P * S, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
-                  tab.data_ptr() + 4 * c0, tab.shape[-1], L0.Cout, wxT.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), len(rest),
+                  tab.data_ptr() + 4 * c0, tab.shape[-1] if tab_ld is None else tab_ld, L0.Cout, wxT.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), len(rest),
                   ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p),
                   ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p),
                   ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p),
@@ -680,6 +681,18 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
                   L1.W.data_ptr(), L1.Kpad, L1.scale.data_ptr(), L1.shift.data_ptr(), L2.Wf.data_ptr(), L2.Kpad, L2.scale.data_ptr(),
                   L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), pool, out.data_ptr(),
                   out.shape[-1], col0, stream)
+    elif (SA_XYZ_TABLE and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers) and pool == 1
+          and layers[0].Cout in (32, 64, 128) and layers[1].Cout == layers[0].Cout and layers[2].Cout == 2 * layers[0].Cout and S in (16, 32, 64)
+          and layers[1].Kpad == layers[0].Cout and layers[2].Kpad == layers[0].Cout and B * P * S >= 262144):
+        # a WIDE xyz-only stack (BASELINE config 5: [3, 64, 64, 128] over 64 samples): the persistent kernel of sa_table.hip with its weights in
+        # LDS, fed a shared row of zeros as the "feature part" of the first layer (tab_ld = 0) -- 0 + Wx (x_j - q) is the layer itself
+        L0 = layers[0]
+        hit = L0._xyz_table
+        if hit is None:
+            with torch.no_grad():
+                hit = (torch.zeros(128, dtype=torch.float32, device=xyz.device), L0.W[:L0.Cout, :3].t().contiguous())
+            L0._xyz_table = hit
+        sa_scale_mlp(xyz, new_xyz, None, idx, layers, use_xyz, pool, out, col0, table=(hit[0].view(1, -1), 0, hit[1]), tab_ld=0)
     elif USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
         mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
                   group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))

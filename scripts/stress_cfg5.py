@@ -23,7 +23,7 @@ with torch.no_grad():
     layers = fused.pack_conv_stack(sa.mlps[0])
     out = torch.empty((B, P, 128), device='cuda')
     rows = B * P * S
-    t_mlp = timeit(lambda: fused.mlp_stack(1, rows, 3, layers, out, pool=1, S=S, group=(N, P, 0, 1, xyz, new_xyz, None, idx)))
+    t_mlp = timeit(lambda: fused.sa_scale_mlp(xyz, new_xyz, None, idx, layers, 1, 1, out, 0))   # what sa_forward runs for this module
 bq_bytes = 12 * B * (N + P) + 4 * B * P * S
 evals = B * P * N
 mlp_bytes = 4 * rows + 12 * rows + 4 * B * P * 128          # idx + gathered xyz + pooled output (no grouped tensor, no hidden activations)
