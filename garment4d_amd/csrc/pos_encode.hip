@@ -45,19 +45,32 @@ __device__ __forceinline__ f32x4 ldf4(const float *base, unsigned elem) {
     return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (elem << 2));
 }
 
-template <int E, bool TABLE, bool SBIG, bool PIPE>  // PIPE: software-pipelined gathers (pays for the table rows, costs occupancy otherwise); SBIG: nsample >= 16, a 16-row tile belongs to ONE query -> its centre is wave-uniform
+// L1M (round 5): layer 1 on the matrix pipe too.  D1 = W1 (16 channels x K) . in^T (K x 16 rows) per (row tile, channel tile), K = 3 + E <= 8 padded
+// to one or two k-steps of v_mfma_f32_16x16x4_f32, the accumulator started from table row + bias: lane (row fi, fq) ends with channels 16 ks + 4 fq + r
+// -- exactly the A-operand layout layer 2 wants (above), and the same k-ascending FMA chain as the VALU form (bit-identical).  A lane then loads only
+// the ONE input component per k-step it feeds (4 bytes instead of three 12-byte rows), holds 4 weight registers instead of 8 KX, and the layer costs
+// 8-16 MFMAs + 32 v_max per 64 rows instead of 32 (KX + 2) VALU instructions (VALU work is ADDED to the matrix pipe's time on this chip).
+template <int E, bool TABLE, bool SBIG, bool PIPE, bool L1M>  // PIPE: software-pipelined gathers (pays for the table rows, costs occupancy otherwise); SBIG: nsample >= 16, a 16-row tile belongs to ONE query -> its centre is wave-uniform
 __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
     constexpr int KX = 3 + E;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fi = lane & 15, fq = lane >> 4;
-    float w1[8][KX], bb1[8];
+    constexpr int KK = L1M ? (KX + 3) / 4 : 1;   // k-steps of layer 1 on the matrix pipe
+    float w1[L1M ? 1 : 8][KX], bb1[8];
+    float w1f[2][KK];                           // L1M: A fragments of W1: lane (channel fi, fq) holds W1[16 ks + fi][4 kk + fq] (0 beyond KX)
 #pragma unroll
     for (int c8 = 0; c8 < 8; ++c8) {
         const int c = (c8 >> 2) * 16 + fq * 4 + (c8 & 3);
+        if constexpr (!L1M) {
 #pragma unroll
-        for (int i = 0; i < KX; ++i) w1[c8][i] = a.W1[c * KX + i];
+            for (int i = 0; i < KX; ++i) w1[c8][i] = a.W1[c * KX + i];
+        }
         bb1[c8] = a.b1 ? a.b1[c] : 0.f;
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) w1f[ks][kk] = (L1M && 4 * kk + fq < KX) ? a.W1[(ks * 16 + fi) * KX + min(4 * kk + fq, KX - 1)] : 0.f;
     f32x4 bf[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -77,6 +90,7 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
         F3 px[4], pq[4], pe[4];
         float ex[4][E == 3 ? 1 : (E ? E : 1)];
         f32x4 t[4][2];
+        float c0[4], q0[4], e0[4], c1[4];   // L1M: the lane's own input component of k-step 0 (coordinate / centre / first extra) and of k-step 1
     };
     // (a chunk past the wave's last one is clamped onto the launch's last chunk -- loaded again, never used: a conditional load makes the
     //  compiler wait for the whole prefetch where the branches join, i.e. at once, and the gathers of a wave then overlap nothing)
@@ -97,12 +111,20 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
             if (SBIG) qi = __builtin_amdgcn_readfirstlane(qi);
             const int f = f0 + (qi >= qnext ? 1 : 0);
             const unsigned src = (unsigned)(f * a.n + iv[mt]);
+            if constexpr (L1M) {
+                const unsigned fq2 = (unsigned)min(fq, 2);
+                rw.c0[mt] = ldf(a.xyz, src * 3 + fq2);               // in[4 kk + fq]: kk = 0 -> dx | dy | dz | extra 0
+                rw.q0[mt] = ldf(a.new_xyz, (unsigned)qi * 3 + fq2);
+                if (E > 0) rw.e0[mt] = ldf(a.extra, src * E);
+                if (E > 1) rw.c1[mt] = ldf(a.extra, src * E + (unsigned)min(1 + fq, E - 1));   // kk = 1 -> extra 1 + fq (0 beyond E)
+            } else {
             rw.px[mt] = ldf3(a.xyz, src * 3);
             rw.pq[mt] = ldf3(a.new_xyz, (unsigned)qi * 3);
             if (E == 3) rw.pe[mt] = ldf3(a.extra, src * 3);
             else {
 #pragma unroll
                 for (int e = 0; e < E; ++e) rw.ex[mt][e] = ldf(a.extra, src * E + e);
+            }
             }
             if (TABLE) {
                 rw.t[mt][0] = ldf4(a.table, src * 32 + fq * 4);
@@ -133,8 +155,25 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
         // 64 MFMAs) the matrix pipe was 0.48 busy and the VALU 0.4: a wave cannot issue its own VALU work behind a queued MFMA, and the other
         // wave of the SIMD was as often in the same phase as not.  Interleaved, ~4 VALU instructions fit in the 32 cycles of each MFMA.
         float in[4][KX];
+        f32x4 d1[4][2];
+        if constexpr (L1M) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float dif = cur.c0[mt] - cur.q0[mt];   // the coordinate difference first, in fp32, like the reference
+                const float b0 = fq < 3 ? dif : (E > 0 ? cur.e0[mt] : 0.f);
+                const float b1_ = (E > 1 && 1 + fq < E) ? cur.c1[mt] : 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d1[mt][ks][e] = TABLE ? cur.t[mt][ks][e] + bb1[ks * 4 + e] : bb1[ks * 4 + e];
+                    d1[mt][ks] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[ks][0], b0, d1[mt][ks], 0, 0, 0);
+                    if constexpr (KK > 1) d1[mt][ks] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[ks][KK - 1], b1_, d1[mt][ks], 0, 0, 0);
+                }
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+            if constexpr (L1M) continue;
             in[mt][0] = cur.px[mt].x - cur.pq[mt].x;
             in[mt][1] = cur.px[mt].y - cur.pq[mt].y;
             in[mt][2] = cur.px[mt].z - cur.pq[mt].z;
@@ -154,6 +193,7 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
         auto column = [&](int c8, float (&o)[4]) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
+                if constexpr (L1M) { o[mt] = fmaxf(d1[mt][c8 >> 2][c8 & 3], 0.f); continue; }
                 float h = TABLE ? cur.t[mt][c8 >> 2][c8 & 3] + bb1[c8] : bb1[c8];
 #pragma unroll
                 for (int i = 0; i < KX; ++i) h = __builtin_fmaf(w1[c8][i], in[mt][i], h);
@@ -174,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {              // one MFMA, then its share of the next column's VALU work
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, (4 * (KX + 2) + 7) / 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, L1M ? 1 : (4 * (KX + 2) + 7) / 8, 0);
                 }
             }
         }
@@ -223,18 +263,21 @@ template <bool TABLE, bool SBIG>
 static void launch_pe(int E, dim3 grid, hipStream_t st, const PeArgs &a) {
     static const int pipe_env = getenv("G4D_PE_PIPE") ? atoi(getenv("G4D_PE_PIPE")) : -1;  // tuning hook: 0 | 1, default by variant
     const bool pipe = pipe_env >= 0 ? pipe_env != 0 : (TABLE && E == 0);                 // measured: +10 % with a table, -17 % without
+    static const int l1m_env = getenv("G4D_PE_L1_MFMA") ? atoi(getenv("G4D_PE_L1_MFMA")) : 1;   // A/B switch: layer 1 on the matrix pipe (round 5)
+#define G4D_PE_LAUNCH(EE, PP, LL) hipLaunchKernelGGL((pos_encode_kernel<EE, TABLE, SBIG, PP, LL>), grid, dim3(256), 0, st, a)
 #define G4D_PE_CASE(EE)                                                                                     \
     case EE:                                                                                                \
-        if (pipe) hipLaunchKernelGGL((pos_encode_kernel<EE, TABLE, SBIG, true>), grid, dim3(256), 0, st, a);  \
-        else hipLaunchKernelGGL((pos_encode_kernel<EE, TABLE, SBIG, false>), grid, dim3(256), 0, st, a);      \
+        if (l1m_env) { if (pipe) G4D_PE_LAUNCH(EE, true, true); else G4D_PE_LAUNCH(EE, false, true); }      \
+        else { if (pipe) G4D_PE_LAUNCH(EE, true, false); else G4D_PE_LAUNCH(EE, false, false); }            \
         break;
     switch (E) {
         G4D_PE_CASE(0) G4D_PE_CASE(1) G4D_PE_CASE(2) G4D_PE_CASE(3) G4D_PE_CASE(4)
         default:
-            if (pipe) hipLaunchKernelGGL((pos_encode_kernel<5, TABLE, SBIG, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((pos_encode_kernel<5, TABLE, SBIG, false>), grid, dim3(256), 0, st, a);
+            if (l1m_env) { if (pipe) G4D_PE_LAUNCH(5, true, true); else G4D_PE_LAUNCH(5, false, true); }
+            else { if (pipe) G4D_PE_LAUNCH(5, true, false); else G4D_PE_LAUNCH(5, false, false); }
     }
 #undef G4D_PE_CASE
+#undef G4D_PE_LAUNCH
 }
 
 }  // namespace g4d
