@@ -51,6 +51,7 @@ SIGNATURES = {
     "g4d_copy_segments_f32": [_I, _vp, _vp, _vp, _vp],
     "g4d_linear_interp_add_f32": [_LL, _I, _I, _I, _I, _I, _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_tuning_set": [ctypes.c_char_p, _LL],
+    "g4d_tuning_set_thread": [ctypes.c_char_p, ctypes.c_longlong, _I],
     "g4d_interp_concat_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_spmm_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp],
     "g4d_gcn_agg_linear_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp],
@@ -179,7 +180,7 @@ def call(name, *args):
     if _TRACE:
         import sys
         print("g4d call", name, *[a for a in args if isinstance(a, (int, float)) and abs(a) < (1 << 31)], file=sys.stderr)
-    if _TIMED is not None and args and name not in ("g4d_tuning_set", "g4d_launch_group_begin"):
+    if _TIMED is not None and args and name not in ("g4d_tuning_set", "g4d_tuning_set_thread", "g4d_launch_group_begin"):
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

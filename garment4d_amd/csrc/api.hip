@@ -49,19 +49,39 @@ Tune g_tune[] = {{"sa_table_persistent", 0, 0}, {"sa_table_min_rows", 0, 0}, {"s
                  {"fp_table_min_rows", 0, 0}, {"gemm_tile", 0, 0}, {"gemm_tile_min_rows", 0, 0}, {"gemm_tile_min_cout", 0, 0}, {"gemm_tile_min_kpad", 0, 0}, {"fp_init_persistent", 0, 0}, {"fp_init_min_rows", 0, 0},
                  {"fp_head_bf16_persistent", 0, 0}, {"fp_head_bf16_min_rows", 0, 0}, {"sa_group_bf16_persistent", 0, 0}, {"sa_group_bf16_min_rows", 0, 0}};
 }
+// per-host-thread overrides (g4d_tuning_set_thread): an executor that holds its own tuning applies it around its launches without touching
+// the process-wide table -- two executors driven from two threads do not see each other's settings (kernel selection happens on the host, at
+// launch time, on the launching thread)
+struct ThreadTune { long long value; bool set; };
+thread_local ThreadTune t_tune[sizeof(g_tune) / sizeof(g_tune[0])] = {};
+
 long long tuning(const char *key, long long dflt) {
+    int i = 0;
     for (Tune &t : g_tune) {
+        const int slot = i++;
         if (strcmp(t.key, key)) continue;
-        if (__atomic_load_n(&t.state, __ATOMIC_ACQUIRE) == 0) {
+        if (t_tune[slot].set) return t_tune[slot].value;
+        int st = __atomic_load_n(&t.state, __ATOMIC_ACQUIRE);
+        if (st == 0) {
             char env[64] = "G4D_";
             size_t n = 4;
             for (const char *c = key; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
             env[n] = 0;
             const char *e = getenv(env);
-            t.value = e && *e ? atoll(e) : dflt;
-            __atomic_store_n(&t.state, 1, __ATOMIC_RELEASE);
+            const long long v = e && *e ? atoll(e) : dflt;
+            // state 0 -> 3 (being initialised) by ONE thread; a concurrent g4d_tuning_set (state 2) is never overwritten, a concurrent reader
+            // that loses the race computes the same value from the same environment and returns it without storing
+            int expect = 0;
+            if (__atomic_compare_exchange_n(&t.state, &expect, 3, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+                __atomic_store_n(&t.value, v, __ATOMIC_RELAXED);
+                expect = 3;
+                __atomic_compare_exchange_n(&t.state, &expect, 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+                return v;
+            }
+            st = expect;
+            if (st == 3) return v;
         }
-        return t.value;
+        return __atomic_load_n(&t.value, __ATOMIC_RELAXED);
     }
     return dflt;
 }
@@ -71,11 +91,28 @@ extern "C" int g4d_tuning_set(const char *key, long long value) {
     if (key)
         for (g4d::Tune &t : g4d::g_tune)
             if (!strcmp(t.key, key)) {
-                t.value = value;
+                __atomic_store_n(&t.value, value, __ATOMIC_RELAXED);
                 __atomic_store_n(&t.state, 2, __ATOMIC_RELEASE);
                 return G4D_OK;
             }
     g4d::set_error("g4d_tuning_set: unknown key '%s'", key ? key : "(null)");
+    return G4D_EINVAL;
+}
+
+// set != 0: `value` overrides the key for launches made by the CALLING host thread; set == 0: the override is dropped (value ignored).
+extern "C" int g4d_tuning_set_thread(const char *key, long long value, int set) {
+    if (key) {
+        int i = 0;
+        for (g4d::Tune &t : g4d::g_tune) {
+            const int slot = i++;
+            if (!strcmp(t.key, key)) {
+                g4d::t_tune[slot].value = value;
+                g4d::t_tune[slot].set = set != 0;
+                return G4D_OK;
+            }
+        }
+    }
+    g4d::set_error("g4d_tuning_set_thread: unknown key '%s'", key ? key : "(null)");
     return G4D_EINVAL;
 }
 

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import fused
 from . import pytorch_utils as pt_utils
+from .tuning import current as _T
 from .pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 
 CLASS_NUM = 7  # utils/dataloader.py:24
@@ -82,13 +83,13 @@ class Pointnet2MSGSEG(nn.Module):
         feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None  # already point-major
         l_xyz, l_feats = [xyz], [feats]
         grid0 = None
-        if fused.OVERLAP_SAMPLING:
+        if _T().overlap_sampling:
             # sampling depends on coordinates only: the three FPS -> gather steps run as one chain on a side stream, overlapping
             # the ball-grid build of level 1 and the ball queries + MLPs of the levels before them
             cur = torch.cuda.current_stream(xyz.device)
             chain = fused.sampling_chain(xyz, [sa.npoint for sa in self.SA_modules])
             grid = None
-            if xyz.shape[1] >= fused.GRID_MIN_N:
+            if xyz.shape[1] >= _T().grid_min_n:
                 grid = fused.build_ball_grid(xyz, max(g.radius for g in self.SA_modules[0].groupers))
             for sa, (nx, ready, _sidx) in zip(self.SA_modules, chain):   # `chain` (and the index buffers in it) lives until the loop ends
                 cur.wait_event(ready)
@@ -102,10 +103,10 @@ class Pointnet2MSGSEG(nn.Module):
             SAs = list(self.SA_modules)
             pre_nx, pre_idx = {}, {}
             pre_nn = None
-            if (fused.BQ_MULTI and len(SAs) == 3 and all(sa.npoint is not None for sa in SAs) and SAs[0].npoint < fused.GRID_MIN_N
+            if (_T().bq_multi and len(SAs) == 3 and all(sa.npoint is not None for sa in SAs) and SAs[0].npoint < _T().grid_min_n
                     and len(SAs[1].groupers) == len(SAs[2].groupers) <= 4):
                 r0 = [g.radius for g in SAs[0].groupers]
-                if fused.GRID_MIN_N <= xyz.shape[1] <= 12800 and max(r0) <= 2.01 * min(r0) and xyz.shape[0] > 0:
+                if _T().grid_min_n <= xyz.shape[1] <= 12800 and max(r0) <= 2.01 * min(r0) and xyz.shape[0] > 0:
                     pre_nx[0], grid0 = fused.fps_gather_grid(xyz, SAs[0].npoint, max(r0))   # level 1's sampling + the cloud's cell grid: one launch
                 else:
                     pre_nx[0] = fused.fps_gather(xyz, SAs[0].npoint)
@@ -118,7 +119,7 @@ class Pointnet2MSGSEG(nn.Module):
                 bq = (([g.radius for g in SAs[1].groupers], [g.nsample for g in SAs[1].groupers], pre_nx[0], pre_nx[1]),
                       ([g.radius for g in SAs[2].groupers], [g.nsample for g in SAs[2].groupers], pre_nx[1], pre_nx[2]))
                 nfp_ = len(self.FP_modules)
-                if fused.SEARCH_MULTI and fused.NN_MULTI and nfp_ == 3 and max(pre_nx[0].shape[1], pre_nx[1].shape[1]) < 4096:
+                if _T().search_multi and _T().nn_multi and nfp_ == 3 and max(pre_nx[0].shape[1], pre_nx[1].shape[1]) < 4096:
                     # ... and so can the three-NN searches of the inner FP levels (256 <- 64 and 1024 <- 256 points): they, too, depend
                     # on the sampled coordinates only
                     pre_idx[1], pre_idx[2], nn_out = fused.search_multi(bq[0], bq[1], [(pre_nx[1], pre_nx[2]), (pre_nx[0], pre_nx[1])])
@@ -128,7 +129,7 @@ class Pointnet2MSGSEG(nn.Module):
             for li, sa in enumerate(self.SA_modules):
                 grid = None
                 radii = [g.radius for g in sa.groupers]
-                if li == 0 and xyz.shape[1] >= fused.GRID_MIN_N and sa.npoint is not None and max(radii) <= 2.01 * min(radii):
+                if li == 0 and xyz.shape[1] >= _T().grid_min_n and sa.npoint is not None and max(radii) <= 2.01 * min(radii):
                     # the level-0 cloud's cell grid: the first level's ball query uses it, and so does the three-NN of the LAST
                     # feature-propagation level (same cloud as its unknown set)
                     if grid0 is None:
@@ -144,9 +145,9 @@ class Pointnet2MSGSEG(nn.Module):
         #  frames/s: its long workgroups and the short ones share a launch badly; it keeps its own)
         inner = [i for i in range(-1, -nfp, -1) if l_xyz[i - 1].shape[1] < 4096]
         pre = {}
-        if not fused.OVERLAP_SAMPLING and pre_nn is not None and sorted(inner) == sorted(pre_nn):
+        if not _T().overlap_sampling and pre_nn is not None and sorted(inner) == sorted(pre_nn):
             pre = pre_nn     # (searched together with the ball queries of SA levels 2 and 3, above)
-        elif fused.NN_MULTI and 2 <= len(inner) <= 4:
+        elif _T().nn_multi and 2 <= len(inner) <= 4:
             pre = dict(zip(inner, fused.three_nn_multi([(l_xyz[i - 1], l_xyz[i]) for i in inner])))
         # the last FP level has no skip features: its first layer is a table over ITS known rows = the output rows of the level before,
         # which that level's chain launch can produce as one more layer

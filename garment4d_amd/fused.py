@@ -22,11 +22,12 @@ import torch.nn as nn
 
 from . import _lib
 from . import pointnet2_utils as PU
+from .tuning import current as _T
 
 _KC = 32
 _BN = 64
-USE_WAVE = os.environ.get("G4D_MLP_WAVE", "1") != "0"  # wave-autonomous kernel for narrow stacks (csrc/mlp_wave.hip)
-USE_STACK = True  # whole-stack fusion (csrc/mlp_stack.hip); False = one launch per layer (csrc/mlp.hip)
+# (USE_WAVE -> tuning.Tuning.use_wave) wave-autonomous kernel for narrow stacks (csrc/mlp_wave.hip)
+# (USE_STACK -> tuning.Tuning.use_stack) whole-stack fusion (csrc/mlp_stack.hip); False = one launch per layer (csrc/mlp.hip)
 
 
 def _ptr(t):
@@ -178,7 +179,7 @@ def to_channel_major(x):
     return out
 
 
-STREAM_GEMM = os.environ.get("G4D_GEMM_STREAM", "1") != "0"   # tall contractions (>= 65536 rows, K <= 128, Cout a multiple of 128) on the row-streaming GEMM
+# (STREAM_GEMM -> tuning.Tuning.stream_gemm) tall contractions (>= 65536 rows, K <= 128, Cout a multiple of 128) on the row-streaming GEMM
 
 
 def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
@@ -189,7 +190,7 @@ def linear(x2d, layer, out=None, col0=0, pool=0, S=1):
     orow = rows // S if pool else rows
     if out is None:
         out = torch.empty((orow, layer.Cout), dtype=torch.float32, device=x2d.device)
-    streams = STREAM_GEMM and not pool and rows >= 65536 and layer.Cout % 128 == 0 and layer.Kpad <= 128   # csrc/gemm_stream.hip takes these inside g4d_linear_f32
+    streams = _T().stream_gemm and not pool and rows >= 65536 and layer.Cout % 128 == 0 and layer.Kpad <= 128   # csrc/gemm_stream.hip takes these inside g4d_linear_f32
     tiles = (not pool and rows >= 32768 and layer.K % 4 == 0 and ldx % 4 == 0 and layer.Cout % 128 == 0 and layer.Kpad >= 128
              and x2d.data_ptr() % 16 == 0)   # csrc/gemm_tile.hip takes these inside g4d_linear_f32 (983040 x 324 -> 128: 87 TFLOP/s against 66 on the chain kernel)
     if not streams and not tiles and not pool and current_precision() == "fp32" and (layer.K % 32 != 0 or layer.Cout <= 16) and chain_fits([layer], 0, 1, 0):
@@ -240,11 +241,11 @@ class precision:
 # Launches below this many rows stay on the fp32 kernels in bf16 mode.  0 since round 4: the precision of a cloud's result must not depend on
 # how many clouds share the call (the executor coalesces steps: FP level 3 has 2048 rows at 8 clouds, 8192 at 32 -- it used to switch
 # precision in between; tests/test_pipeline_gpu.py).  Was 8192 (below 128 workgroups of 64 rows the one-launch bf16 stack leaves the chip idle).
-_BF16_MIN_ROWS = int(os.environ.get("G4D_BF16_MIN_ROWS", "0"))
+# (_BF16_MIN_ROWS -> tuning.Tuning.bf16_min_rows)
 
 
 def _use_bf16(rows):
-    return current_precision() == "bf16" and (rows is None or rows >= _BF16_MIN_ROWS)
+    return current_precision() == "bf16" and (rows is None or rows >= _T().bf16_min_rows)
 
 
 _POOL_WINDOWS = (4, 8, 16, 32, 64)  # pool windows the LDS-resident kernels reduce in registers
@@ -263,7 +264,7 @@ def stack_fits(layers, pool, S, rows=None):
     return 4 * 64 * (w[0] + 4 + w[1] + 4) <= _MAX_STACK_LDS
 
 
-USE_CHAIN = os.environ.get("G4D_MLP_CHAIN", "1") != "0"
+# (USE_CHAIN -> tuning.Tuning.use_chain)
 _CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8, 8), (8, 4), (16, 8), (1,), (2,), (4,), (8,), (8, 4, 2, 1),
                 (4, 2, 1), (2, 4), (4, 8), (8, 16), (16,), (16, 8, 8)}
 
@@ -271,14 +272,14 @@ _CHAIN_TILES = {(1, 1, 2), (2, 2, 4), (4, 4, 8), (8, 8, 16), (2, 2), (4, 4), (8,
 def chain_fits(layers, pool, S, mode):
     """Register-resident chain kernel (csrc/mlp_chain.hip): DIRECT / GROUP loader, 1..3 layers whose 16-channel tile counts
     are one of the instantiated combinations (mirrors g4d_mlp_chain_supported)."""
-    if not USE_CHAIN or mode not in (0, 1, 2) or (pool and S not in _POOL_WINDOWS):
+    if not _T().use_chain or mode not in (0, 1, 2) or (pool and S not in _POOL_WINDOWS):
         return False
     return tuple((L.Cout + 15) // 16 for L in layers) in _CHAIN_TILES
 
 
 def wave_fits(layers, pool, S):
     """Narrow stack (every hidden width <= 64): eligible for the wave-autonomous kernel (csrc/mlp_wave.hip)."""
-    if not USE_WAVE or not (1 <= len(layers) <= 4) or (pool and S not in _POOL_WINDOWS):
+    if not _T().use_wave or not (1 <= len(layers) <= 4) or (pool and S not in _POOL_WINDOWS):
         return False
     # measured: wins for xyz-only first levels (K0 <= 32); with wide gathered inputs the workgroup-cooperative
     # stack kernel is faster (its whole-tile gather keeps more loads in flight)
@@ -389,15 +390,15 @@ def _run_stack(first_call, layers, rows, S, pool, out, col0, device):
 # encoder: FPS chain on a side stream (sampling_chain).  OFF by default -- measured on MI355X / ROCm 7.2 (bench.py, cfg2): inside a
 # captured hipGraph the fork / join costs more than the overlap gains (single-batch latency 1.46 -> 1.57 ms, 16-batch throughput
 # 23.3k -> 10.8k frames/s: the runtime serialises graph branches through extra cross-stream dependencies); DESIGN.md section 5
-OVERLAP_SAMPLING = os.environ.get("G4D_OVERLAP_SAMPLING", "0") != "0"
+# (OVERLAP_SAMPLING -> tuning.Tuning.overlap_sampling)
 # coherent=True route.  Default: wave-per-query walk over 16-point sub-block bounds (g4d_ball_query_boxes_f32), robust to the vertex
 # numbering: 0.58-0.69 ms on config 4's body query (983k queries x 6890 points, scripts/time_body_query.py; plain scan 1.3-1.8 ms).
 # G4D_BQ_LANES=1: one LANE per query (g4d_ball_query_lanes_f32) -- 0.78 ms when the queries of a wave sit at one height of a ring-ordered body (the
 # synthetic scene), but 2.0 ms for a patch-ordered body and 4.1-4.6 ms for incoherent queries; cell-sorting the queries
 # first (G4D_BQ_LANES_SORT=1) makes waves compact but lets their lanes fill at different times: 2.2-2.7 ms.  Off by default.
-LANES_SORT = os.environ.get("G4D_BQ_LANES_SORT", "0") != "0"
-COHERENT_LANES = os.environ.get("G4D_BQ_LANES", "0") != "0"
-GRID_MIN_N = int(os.environ.get("G4D_BQ_GRID_MIN_N", "4096"))  # clouds at least this large go through the cell grid (csrc/ball_grid.hip)
+# (LANES_SORT -> tuning.Tuning.lanes_sort)
+# (COHERENT_LANES -> tuning.Tuning.coherent_lanes)
+# (GRID_MIN_N -> tuning.Tuning.grid_min_n) clouds at least this large go through the cell grid (csrc/ball_grid.hip)
 
 
 def build_ball_grid(xyz, rmax):
@@ -413,14 +414,14 @@ def build_ball_grid(xyz, rmax):
 def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
     """All scales of an MSG layer in one pass over the cloud; returns one (B,P,nsample) int32 tensor per scale.
     coherent=True: the cloud's index order is spatially coherent (mesh vertices) -> block-bounds skipping (same results).
-    grid: None = automatic (cell grid for clouds of >= GRID_MIN_N points), False = scan, True = build a grid, or a
+    grid: None = automatic (cell grid for clouds of >= Tuning.grid_min_n points), False = scan, True = build a grid, or a
     (workspace, rmax) pair from build_ball_grid.  Every route returns the same indices, bit for bit."""
     import ctypes
     B, N, _ = xyz.shape
     P = new_xyz.shape[1]
     outs = [torch.empty((B, P, ns), dtype=torch.int32, device=xyz.device) for ns in nsamples]
     if grid is None:   # the cells are sized by the largest radius: a much smaller scale would wade through 64x its share of points
-        grid = (not coherent) and N >= GRID_MIN_N and max(radii) <= 2.01 * min(radii)
+        grid = (not coherent) and N >= _T().grid_min_n and max(radii) <= 2.01 * min(radii)
     if grid is True:
         grid = build_ball_grid(xyz, max(float(r) for r in radii)) if (B and N and P) else False
     done = 0
@@ -434,8 +435,8 @@ def ball_query_msg(radii, nsamples, xyz, new_xyz, coherent=False, grid=None):
                       new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), grid[0].data_ptr(), grid[1], _lib.stream_ptr())
         elif coherent and N >= 256:
             boxes = torch.empty((B, (N + 15) // 16, 6), dtype=torch.float32, device=xyz.device)   # 16-point sub-block bounds
-            if COHERENT_LANES:   # one lane per query; the queries are cell-sorted first so that a wave's 64 are compact
-                qs = torch.empty(max(_lib.lib().g4d_ball_query_lanes_qsort_bytes(B, P), 16), dtype=torch.uint8, device=xyz.device) if LANES_SORT else None
+            if _T().coherent_lanes:   # one lane per query; the queries are cell-sorted first so that a wave's 64 are compact
+                qs = torch.empty(max(_lib.lib().g4d_ball_query_lanes_qsort_bytes(B, P), 16), dtype=torch.uint8, device=xyz.device) if _T().lanes_sort else None
                 _lib.call("g4d_ball_query_lanes_f32", B, N, P, n, ctypes.cast(R, ctypes.c_void_p), ctypes.cast(NS, ctypes.c_void_p),
                           new_xyz.data_ptr(), xyz.data_ptr(), ctypes.cast(IP, ctypes.c_void_p), boxes.data_ptr(), _ptr(qs), _lib.stream_ptr())
             else:
@@ -472,14 +473,14 @@ def fps_gather_grid(xyz, npoint, rmax):
     return new_xyz, (ws, float(rmax))
 
 
-FPS_PAIR = os.environ.get("G4D_FPS_PAIR", "1") != "0"   # two consecutive small FPS levels in one launch
+# (FPS_PAIR -> tuning.Tuning.fps_pair) two consecutive small FPS levels in one launch
 
 
 def fps_gather_pair(xyz, m1, m2):
     """(new_xyz1 (B,m1,3), new_xyz2 (B,m2,3)) = fps_gather(xyz, m1) and fps_gather(new_xyz1, m2) in one launch (g4d_fps_gather_pair_f32), or
     None when the shape is not one the paired kernel covers."""
     B, N, _ = _chk(xyz).shape
-    if not (FPS_PAIR and B > 0 and _lib.lib().g4d_fps_gather_pair_supported(N, m1, m2)):
+    if not (_T().fps_pair and B > 0 and _lib.lib().g4d_fps_gather_pair_supported(N, m1, m2)):
         return None
     dev = xyz.device
     i1, i2 = torch.empty((B, m1), dtype=torch.int32, device=dev), torch.empty((B, m2), dtype=torch.int32, device=dev)
@@ -488,7 +489,7 @@ def fps_gather_pair(xyz, m1, m2):
     return n1, n2
 
 
-BQ_MULTI = os.environ.get("G4D_BQ_MULTI", "1") != "0"   # the ball queries of two small SA levels in one launch
+# (BQ_MULTI -> tuning.Tuning.bq_multi) the ball queries of two small SA levels in one launch
 
 
 def ball_query_msg2(q0, q1):
@@ -507,7 +508,7 @@ def ball_query_msg2(q0, q1):
     return o0, o1
 
 
-SEARCH_MULTI = os.environ.get("G4D_SEARCH_MULTI", "1") != "0"   # the inner levels' ball queries AND three-NN searches in one launch
+# (SEARCH_MULTI -> tuning.Tuning.search_multi) the inner levels' ball queries AND three-NN searches in one launch
 
 
 def search_multi(q0, q1, pairs):
@@ -607,12 +608,12 @@ class launch_group:
         return False
 
 
-SA_XYZ_PAIR = os.environ.get("G4D_SA_XYZ_PAIR", "1") != "0"   # ... and both such scales of a level in one launch
-USE_SA_XYZ = os.environ.get("G4D_SA_XYZ", "1") != "0"   # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
+# (SA_XYZ_PAIR -> tuning.Tuning.sa_xyz_pair) ... and both such scales of a level in one launch
+# (USE_SA_XYZ -> tuning.Tuning.use_sa_xyz) xyz-only 3-layer SA stacks on csrc/sa_xyz.hip (A/B switch)
 
 
-SA_XYZ_TABLE = os.environ.get("G4D_SA_XYZ_TABLE", "1") != "0"   # wide xyz-only stacks ([3, C, C, 2C], C = 32 / 64 / 128) on sa_table.hip's persistent kernel (A/B switch)
-SA_TABLE = os.environ.get("G4D_SA_TABLE", "1") != "0"   # SA levels with features: feature part of the first layer pre-contracted per source point
+# (SA_XYZ_TABLE -> tuning.Tuning.sa_xyz_table) wide xyz-only stacks ([3, C, C, 2C], C = 32 / 64 / 128) on sa_table.hip's persistent kernel (A/B switch)
+# (SA_TABLE -> tuning.Tuning.sa_table) SA levels with features: feature part of the first layer pre-contracted per source point
 
 
 def sa_table_fits(layers, C, use_xyz, pool, S, table_rows, grouped_rows):
@@ -620,7 +621,7 @@ def sa_table_fits(layers, C, use_xyz, pool, S, table_rows, grouped_rows):
     operands (BASELINE config 3) the first layer is cheap on the bf16 matrix cores and the table launch + the fp32 loader arithmetic
     cost more than they save (measured with table loaders in mlp_chain_bf16.hip: 38.0k -> 36.0k frames/s; bf16x3 27.9k -> 28.3k), and
     the result would no longer be what a bf16-operand evaluation of the reference's layer gives -- not kept."""
-    if not (SA_TABLE and USE_CHAIN and C > 0 and use_xyz and len(layers) >= 2 and current_precision() == "fp32" and table_rows < grouped_rows):
+    if not (_T().sa_table and _T().use_chain and C > 0 and use_xyz and len(layers) >= 2 and current_precision() == "fp32" and table_rows < grouped_rows):
         return False
     L0, rest = layers[0], layers[1:]
     return bool(L0.relu and L0.Cout % 16 == 0 and L0.K == 3 + C and chain_fits(rest, pool, S, 1))
@@ -673,7 +674,7 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
                   _ptr(feats_pm), idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                   L.shift.data_ptr(), L.relu, pl, o.data_ptr(), o.shape[-1], c0, stream)
 
-    if (USE_SA_XYZ and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers)
+    if (_T().use_sa_xyz and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers)
             and B * N * 12 < 2 ** 32 and _lib.lib().g4d_sa_xyz_mlp3_supported(layers[0].Cout, layers[1].Cout, layers[2].Cout, S)):
         # xyz-only 3-layer stack (the first level of the encoder): persistent waves, weights in registers, layer 1 on the VALU
         L1, L2, L3 = layers
@@ -681,7 +682,7 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
                   L1.W.data_ptr(), L1.Kpad, L1.scale.data_ptr(), L1.shift.data_ptr(), L2.Wf.data_ptr(), L2.Kpad, L2.scale.data_ptr(),
                   L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), pool, out.data_ptr(),
                   out.shape[-1], col0, stream)
-    elif (SA_XYZ_TABLE and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers) and pool == 1
+    elif (_T().sa_xyz_table and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers) and pool == 1
           and layers[0].Cout in (32, 64, 128) and layers[1].Cout == layers[0].Cout and layers[2].Cout == 2 * layers[0].Cout and S in (16, 32, 64)
           and layers[1].Kpad == layers[0].Cout and layers[2].Kpad == layers[0].Cout and B * P * S >= 262144):
         # a WIDE xyz-only stack (BASELINE config 5: [3, 64, 64, 128] over 64 samples): the persistent kernel of sa_table.hip with its weights in
@@ -693,7 +694,7 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
                 hit = (torch.zeros(128, dtype=torch.float32, device=xyz.device), L0.W[:L0.Cout, :3].t().contiguous())
             L0._xyz_table = hit
         sa_scale_mlp(xyz, new_xyz, None, idx, layers, use_xyz, pool, out, col0, table=(hit[0].view(1, -1), 0, hit[1]), tab_ld=0)
-    elif USE_STACK and stack_fits(layers, pool, S, rows=B * P * S):
+    elif _T().use_stack and stack_fits(layers, pool, S, rows=B * P * S):
         mlp_stack(1, B * P * S, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=S,
                   group=(N, P, C, use_xyz, xyz, new_xyz, feats_pm, idx))
     else:
@@ -720,7 +721,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
         col0 = 0
         if idxs is None:   # (else: the caller's ball_query_msg / ball_query_msg2 result for exactly these centroids)
             idxs = ball_query_msg([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, grid=grid)
-        if (USE_SA_XYZ and SA_XYZ_PAIR and C == 0 and len(packed) == 2 and current_precision() == "fp32" and B * N * 12 < 2 ** 32
+        if (_T().use_sa_xyz and _T().sa_xyz_pair and C == 0 and len(packed) == 2 and current_precision() == "fp32" and B * N * 12 < 2 ** 32
                 and all(int(g.use_xyz) for g in sa.groupers) and all(len(L_) == 3 and all(L.relu for L in L_) for L_ in packed)
                 and [L.Cout for L in packed[0]] == [16, 16, 32] and [L.Cout for L in packed[1]] == [32, 32, 64]
                 and [g.nsample for g in sa.groupers] == [16, 32]):
@@ -766,7 +767,7 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
                       idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), L.relu, pl,
                       o.data_ptr(), o.shape[-1], c0, stream)
 
-        if USE_STACK and stack_fits(layers, pool, N, rows=B * N):
+        if _T().use_stack and stack_fits(layers, pool, N, rows=B * N):
             mlp_stack(1, B * N, (3 if use_xyz else 0) + C, layers, out, col0=col0, pool=pool, S=N,
                       group=(N, 1, C, use_xyz, xyz, zero_c, feats_pm, idx))
         else:
@@ -775,15 +776,15 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
     return None, out
 
 
-THREE_NN_GRID_MIN_M = int(os.environ.get("G4D_NN_GRID_MIN_M", "4096"))  # known sets at least this large search the cell grid (csrc/ball_grid.hip); below, the scan wins
+# (THREE_NN_GRID_MIN_M -> tuning.Tuning.three_nn_grid_min_m) known sets at least this large search the cell grid (csrc/ball_grid.hip); below, the scan wins
 
 
-NN_CELLS = os.environ.get("G4D_NN_CELLS", "1") != "0"   # three_nn scan over cell-ordered queries when the unknown cloud's ball grid exists
+# (NN_CELLS -> tuning.Tuning.nn_cells) three_nn scan over cell-ordered queries when the unknown cloud's ball grid exists
 
 
 def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=None):
     """Three nearest `known` (B,m,3) points of every `unknown` (B,n,3) point: (dist2 (B,n,3) squared, idx (B,n,3) int32).
-    grid=None: the cell-grid search from m = THREE_NN_GRID_MIN_M on, the scan below; True / False force a route (identical output).
+    grid=None: the cell-grid search from m = Tuning.three_nn_grid_min_m on, the scan below; True / False force a route (identical output).
     unknown_grid: the (workspace, rmax) pair of build_ball_grid(unknown, ...), if the caller has it: the scan then takes the queries
     in cell order (g4d_three_nn_cells_f32; identical output)."""
     B, n, _ = _chk(unknown).shape
@@ -793,12 +794,12 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=No
         dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
     if nn_idx is None:
         nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=dev)
-    if NN_CELLS and unknown_grid is not None and grid is None and n >= 4096 and 256 <= m < THREE_NN_GRID_MIN_M and B > 0:
+    if _T().nn_cells and unknown_grid is not None and grid is None and n >= 4096 and 256 <= m < _T().three_nn_grid_min_m and B > 0:
         _lib.call("g4d_three_nn_cells_f32", B, n, m, unknown.data_ptr(), unknown_grid[0].data_ptr(), known.data_ptr(), dist2.data_ptr(),
                   nn_idx.data_ptr(), _lib.stream_ptr())
         return dist2, nn_idx
     if grid is None:
-        grid = m >= THREE_NN_GRID_MIN_M
+        grid = m >= _T().three_nn_grid_min_m
     if grid and m > 0 and B * n > 0:
         ws = torch.empty(max(_lib.lib().g4d_ball_grid_bytes(B, m), 16), dtype=torch.uint8, device=dev)
         _lib.call("g4d_three_nn_grid_f32", B, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), ws.data_ptr(),
@@ -808,7 +809,7 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=No
     return dist2, nn_idx
 
 
-NN_MULTI = os.environ.get("G4D_NN_MULTI", "1") != "0"   # the small three_nn searches of the inner FP levels in one launch
+# (NN_MULTI -> tuning.Tuning.nn_multi) the small three_nn searches of the inner FP levels in one launch
 
 
 def three_nn_multi(pairs):
@@ -828,12 +829,12 @@ def three_nn_multi(pairs):
     return outs
 
 
-FP_WIDE_FUSED = os.environ.get("G4D_FP_WIDE_FUSED", "0") != "0"   # wide FP level: interpolation inside the first layer's loader (one launch fewer; A/B switch)
-FP_CELLS = os.environ.get("G4D_FP_CELLS", "1") != "0"   # last FP level: rows walked in the cell order of the unknown cloud's ball grid
-FP_TABLE = os.environ.get("G4D_FP_TABLE", "1") != "0"   # FP levels without skip features: first layer pre-contracted over the known rows
-FP_GEMM_BF16 = os.environ.get("G4D_FP_GEMM_BF16", "1") != "0"            # wide FP level, bf16 operands, large launches: tiled GEMMs (csrc/gemm_bf16.hip) instead of the LDS stack kernel
-FP_GEMM_BF16_MIN_ROWS = int(os.environ.get("G4D_FP_GEMM_BF16_MIN_ROWS", "8192"))
-FP_WIDE_TABLE = os.environ.get("G4D_FP_WIDE_TABLE", "1") != "0"   # wide FP levels with skip features: known-feature columns pre-contracted, interpolation added in the GEMM's epilogue
+# (FP_WIDE_FUSED -> tuning.Tuning.fp_wide_fused) wide FP level: interpolation inside the first layer's loader (one launch fewer; A/B switch)
+# (FP_CELLS -> tuning.Tuning.fp_cells) last FP level: rows walked in the cell order of the unknown cloud's ball grid
+# (FP_TABLE -> tuning.Tuning.fp_table) FP levels without skip features: first layer pre-contracted over the known rows
+# (FP_GEMM_BF16 -> tuning.Tuning.fp_gemm_bf16) wide FP level, bf16 operands, large launches: tiled GEMMs (csrc/gemm_bf16.hip) instead of the LDS stack kernel
+# (FP_GEMM_BF16_MIN_ROWS -> tuning.Tuning.fp_gemm_bf16_min_rows)
+# (FP_WIDE_TABLE -> tuning.Tuning.fp_wide_table) wide FP levels with skip features: known-feature columns pre-contracted, interpolation added in the GEMM's epilogue
 
 
 def fp_table_layer(fp, C1, C2, head):
@@ -841,7 +842,7 @@ def fp_table_layer(fp, C1, C2, head):
     (no skip features), or None: a caller that produces this level's known features with another chain launch can append it there as one
     more layer (fp_forward(..., also_table=...)) and hand the result back as table=."""
     layers = pack_conv_stack(fp.mlp)
-    if not (FP_TABLE and C1 == 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN):
+    if not (_T().fp_table and C1 == 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and _T().use_chain):
         return None
     rest = layers[1:] + (pack_conv_stack(head) if head is not None else [])
     if not rest or not _lib.lib().g4d_mlp_chain_supported(len(rest), (ctypes.c_int * len(rest))(*[L.Cout for L in rest])):
@@ -876,8 +877,8 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
     # earlier SA level, if any
     # cell-ordered route (csrc/mlp_chain.hip, g4d_mlp_chain_table_cells_f32): search results stay in the cell order of the unknown cloud's
     # ball grid and the table launch walks the points in that order (neighbouring rows share their nearest known points: L1 hits)
-    cells = (FP_CELLS and FP_TABLE and NN_CELLS and nn is None and unknown_grid is not None and C1 == 0 and n >= 4096 and 256 <= m < THREE_NN_GRID_MIN_M
-             and B > 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN)
+    cells = (_T().fp_cells and _T().fp_table and _T().nn_cells and nn is None and unknown_grid is not None and C1 == 0 and n >= 4096 and 256 <= m < _T().three_nn_grid_min_m
+             and B > 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and _T().use_chain)
     if cells:
         rest_ = layers[1:] + (pack_conv_stack(head) if head is not None else [])
         cells = bool(rest_) and bool(_lib.lib().g4d_mlp_chain_supported(len(rest_), (ctypes.c_int * len(rest_))(*[L.Cout for L in rest_])))
@@ -893,7 +894,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
                   dist2.data_ptr(), nn_idx.data_ptr(), L.Kpad, L.Cout, L.W.data_ptr(), L.scale.data_ptr(),
                   L.shift.data_ptr(), L.relu, o.data_ptr(), o.shape[-1], c0, stream)
 
-    if (FP_TABLE and C1 == 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN
+    if (_T().fp_table and C1 == 0 and C2 % 16 == 0 and layers[0].relu and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and _T().use_chain
             and B * m < B * n):
         # No skip features: conv(sum_i w_i f_i) = sum_i w_i conv(f_i), so the first layer's contraction runs over the m KNOWN rows
         # (table) instead of the n interpolated ones, and the layer itself becomes relu(interp(table) * scale + shift) in the loader.
@@ -918,7 +919,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
                       ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p),
                       final.view(B * n, -1).data_ptr(), final.shape[-1], 0, tap_layer, _ptr(tap_t), 0 if tap_t is None else tap_t.shape[-1], stream)
             return (out, final) if head is not None else out
-    if (FP_TABLE and C1 > 0 and head is None and len(layers) >= 2 and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and USE_CHAIN
+    if (_T().fp_table and C1 > 0 and head is None and len(layers) >= 2 and layers[0].Cout % 16 == 0 and current_precision() == "fp32" and _T().use_chain
             and m < n and chain_fits(layers, 0, 1, 2)):
         # Skip features: W [interp(f) ; s] = interp(Wa f) + Wb s -- the known-feature columns of the first layer are contracted over the
         # m KNOWN rows (table), the first layer's accumulators start from the interpolated table and the matrix pipe adds the skip columns.
@@ -954,12 +955,12 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
         # FP stack + FC head in one launch; the FP output is tapped to HBM (it is returned to the caller too)
         hl = pack_conv_stack(head)
         allL = layers + hl
-        if USE_STACK and stack_fits(allL, 0, 1, rows=B * n):
+        if _T().use_stack and stack_fits(allL, 0, 1, rows=B * n):
             logits = torch.empty((B, n, hl[-1].Cout), dtype=torch.float32, device=unknown.device)
             mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
                       tap=(len(layers) - 1, out.view(B * n, -1)), cells_grid=None if unknown_grid is None else unknown_grid[0])
             return out, logits
-    if (FP_GEMM_BF16 and current_precision() == "bf16" and len(layers) == 2 and B * n >= FP_GEMM_BF16_MIN_ROWS and C2 % 8 == 0 and USE_STACK
+    if (_T().fp_gemm_bf16 and current_precision() == "bf16" and len(layers) == 2 and B * n >= _T().fp_gemm_bf16_min_rows and C2 % 8 == 0 and _T().use_stack
             and stack_fits(layers, 0, 1, rows=B * n) and not chain_fits(layers, 0, 1, 2) and all(L.Kpad % 64 == 0 and L.W.shape[0] % 128 == 0 for L in layers)
             and layers[0].W.shape[0] >= layers[1].Kpad >= layers[0].Cout):
         # wide FP level with bf16 operands, large launch: interpolation pre-pass + two tiled bf16 GEMMs (csrc/gemm_bf16.hip) instead of the LDS stack
@@ -975,9 +976,9 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
                   h16.data_ptr(), L1.Kpad, 0, 0, 0, stream)
         _lib.call("g4d_gemm_frag_bf16", rows, L1.Kpad, h16.data_ptr(), L1.Wf16.data_ptr(), L1.scale.data_ptr(), L1.shift.data_ptr(), L1.relu, L1.Cout,
                   0, 0, out.data_ptr(), out.shape[-1], 0, stream)
-    elif USE_STACK and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
+    elif _T().use_stack and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
-    elif (layers[0].Cout > 64 and FP_WIDE_TABLE and C1 > 0 and C1 % 4 == 0 and m < n and current_precision() == "fp32"):
+    elif (layers[0].Cout > 64 and _T().fp_wide_table and C1 > 0 and C1 % 4 == 0 and m < n and current_precision() == "fp32"):
         # wide FP level (FP level 3 of the encoder: [384 + 192 -> 512 -> 256] over 256 points per cloud).  Split first layer:
         #   W [interp(f) ; s] = interp(Wa f) + Wb s
         # -- the known-feature columns are contracted over the m KNOWN rows (a quarter of the n rows: half of the level's flops gone), the skip
@@ -1002,7 +1003,7 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
                   table.shape[-1], dist2.data_ptr(), nn_idx.data_ptr(), Lb.scale.data_ptr(), Lb.shift.data_ptr(), Lb.relu, h.data_ptr(), h.shape[-1], 0, stream)
         for i, L in enumerate(layers[1:], 1):
             h = linear(h, L, out=out.view(B * n, -1) if i == len(layers) - 1 else None)
-    elif layers[0].Cout > 64 and not FP_WIDE_FUSED:
+    elif layers[0].Cout > 64 and not _T().fp_wide_fused:
         # wide FP level without skip features / other precisions: every 64-channel tile of the first layer would redo the interpolation ->
         # materialise the interpolated + concatenated rows once (a few MB), then plain DIRECT layers.
         x = torch.empty((B * n, C2 + C1), dtype=torch.float32, device=unknown.device)
@@ -1023,10 +1024,23 @@ def conv_stack_forward(stack, x_pm):
     B, N, C = x_pm.shape
     h = _chk(x_pm).view(B * N, C)
     layers = pack_conv_stack(stack)
-    if USE_STACK and stack_fits(layers, 0, 1, rows=B * N):
+    if _T().use_stack and stack_fits(layers, 0, 1, rows=B * N):
         out = torch.empty((B * N, layers[-1].Cout), dtype=torch.float32, device=x_pm.device)
         mlp_stack(0, B * N, C, layers, out, X=h, ldx=C)
         return out.view(B, N, -1)
     for L in layers:
         h = linear(h, L)
     return h.view(B, N, -1)
+
+
+
+_LEGACY_SWITCHES = {'USE_WAVE': 'use_wave', 'USE_STACK': 'use_stack', 'STREAM_GEMM': 'stream_gemm', 'USE_CHAIN': 'use_chain', 'OVERLAP_SAMPLING': 'overlap_sampling', 'LANES_SORT': 'lanes_sort', 'COHERENT_LANES': 'coherent_lanes', 'GRID_MIN_N': 'grid_min_n', 'FPS_PAIR': 'fps_pair', 'BQ_MULTI': 'bq_multi', 'SEARCH_MULTI': 'search_multi', 'SA_XYZ_PAIR': 'sa_xyz_pair', 'USE_SA_XYZ': 'use_sa_xyz', 'SA_XYZ_TABLE': 'sa_xyz_table', 'SA_TABLE': 'sa_table', 'THREE_NN_GRID_MIN_M': 'three_nn_grid_min_m', 'NN_CELLS': 'nn_cells', 'NN_MULTI': 'nn_multi', 'FP_WIDE_FUSED': 'fp_wide_fused', 'FP_CELLS': 'fp_cells', 'FP_TABLE': 'fp_table', 'FP_GEMM_BF16_MIN_ROWS': 'fp_gemm_bf16_min_rows', 'FP_GEMM_BF16': 'fp_gemm_bf16', 'FP_WIDE_TABLE': 'fp_wide_table'}
+
+
+def __getattr__(name):
+    """Round <= 4 module-level switches (fused.FP_CELLS, ...) as a READ-ONLY view of the Tuning in force (garment4d_amd/tuning.py); to change one,
+    `with tuning.use(tuning.current().replace(fp_cells=False)): ...` -- assigning to the module attribute no longer has any effect on dispatch."""
+    f = _LEGACY_SWITCHES.get(name)
+    if f is None:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+    return getattr(_T(), f)

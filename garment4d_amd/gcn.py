@@ -24,6 +24,7 @@ import torch
 from torch.nn.parameter import Parameter
 
 from . import _lib
+from .tuning import current as _T
 from .fused import PackedLayer, linear
 
 _csr_cache = {}
@@ -178,7 +179,7 @@ class GraphConvolution(torch.nn.Module):
         return f"{self.__class__.__name__} ({self.in_features} -> {self.out_features})"
 
 
-FUSE_STACK = os.environ.get("G4D_GCN_FUSED", "1") != "0"
+# (FUSE_STACK -> tuning.Tuning.gcn_fuse_stack)
 
 
 def gcn_stack_forward(layers, x, adj, relu_last=False, keep=(), in_width=None):
@@ -200,7 +201,7 @@ def gcn_stack_forward(layers, x, adj, relu_last=False, keep=(), in_width=None):
         raise NotImplementedError("gcn_stack_forward is forward-only: call it under torch.no_grad()")
 
     def fusable(i):   # aggregation of layer i + contraction of layer i + 1
-        return (FUSE_STACK and i + 1 < n and layers[i].out_features == 128
+        return (_T().gcn_fuse_stack and i + 1 < n and layers[i].out_features == 128
                 and (layers[i + 1].out_features == 128 or layers[i + 1].out_features <= 16))
 
     if in_width is not None:

@@ -11,6 +11,7 @@ that remain available in the reference's own lbs.py).
 import torch
 
 from . import _lib
+from .tuning import current as _T
 
 _parents_cache = {}
 
@@ -34,16 +35,16 @@ def _parents_i32(parents, device):
 
 import os
 
-USE_FUSED_LBS = True   # lbs() on the fused kernels; False: the five-step path that follows lbs.py line by line
-USE_ONE_LAUNCH = os.environ.get("G4D_LBS_ONE", "1") != "0"   # fused route: one launch (g4d_lbs_one_f32) instead of three (g4d_lbs_fused_f32)
+# (USE_FUSED_LBS -> tuning.Tuning.lbs_fused) lbs() on the fused kernels; False: the five-step path that follows lbs.py line by line
+# (USE_ONE_LAUNCH -> tuning.Tuning.lbs_one_launch) fused route: one launch (g4d_lbs_one_f32) instead of three (g4d_lbs_fused_f32)
 # ... for any number of frames: the kernel walks the 8-frame groups with the blend rows of its 64 vertices in registers (round 4; before, every
 # group was a workgroup of its own that re-read the 17.9 MB of blend rows and the three-launch route took over above 16 frames -- with a
 # DIFFERENT partition of the blend sum, so a frame's vertices depended on the batch it was in; now they do not:
 # tests/test_pipeline_gpu.py).  G4D_LBS_ONE_MAX_B restores a limit (the three-launch route beyond it).
-ONE_LAUNCH_MAX_B = int(os.environ.get("G4D_LBS_ONE_MAX_B", str(1 << 30)))
+# (ONE_LAUNCH_MAX_B -> tuning.Tuning.lbs_one_launch_max_b)
 # round 5: the pose / shape blend and the transform blend as fp32-MFMA GEMMs behind a once-per-frame rigid-chain launch (g4d_lbs_mfma_f32);
 # taken at EVERY batch size (a frame's bits must not depend on the batch: tests/test_pipeline_gpu.py).  G4D_LBS_MFMA=0: round 4's one-launch kernel.
-USE_MFMA = os.environ.get("G4D_LBS_MFMA", "1") != "0"
+# (USE_MFMA -> tuning.Tuning.lbs_mfma)
 _const_cache = {}
 
 
@@ -182,7 +183,7 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     posed = torch.empty((B, J, 3), dtype=torch.float32, device=dev)
     A = torch.empty((B, J, 4, 4), dtype=torch.float32, device=dev)
     verts = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
-    if USE_FUSED_LBS and USE_MFMA and V > 0 and _lib.lib().g4d_lbs_mfma_supported(J, NB):
+    if _T().lbs_fused and _T().lbs_mfma and V > 0 and _lib.lib().g4d_lbs_mfma_supported(J, NB):
         blend_dirs, Jt, Js = _model_constants(v_template, shapedirs, posedirs, J_regressor)
         nws = int(_lib.lib().g4d_lbs_mfma_ws_bytes(B, J))
         ws = torch.empty((max(nws, 16) + 3) // 4, dtype=torch.float32, device=dev)   # the GEMMs' B operands (2.4 KB per frame); the allocator's blocks are 512-byte aligned
@@ -190,7 +191,7 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
                   v_template.data_ptr(), blend_dirs.data_ptr(), Jt.data_ptr(), Js.data_ptr(), _parents_i32(parents, dev).data_ptr(),
                   lbs_weights.data_ptr(), A.data_ptr(), posed.data_ptr(), verts.data_ptr(), ws.data_ptr(), nws, stream)
         return verts, posed
-    if USE_FUSED_LBS and USE_ONE_LAUNCH and V > 0 and B <= ONE_LAUNCH_MAX_B and _lib.lib().g4d_lbs_one_supported(J, NB):
+    if _T().lbs_fused and _T().lbs_one_launch and V > 0 and B <= _T().lbs_one_launch_max_b and _lib.lib().g4d_lbs_one_supported(J, NB):
         # one launch: blend rows requested up front, per-frame rigid chain computed by every workgroup while they are in flight
         blend_dirs, Jt, Js = _model_constants(v_template, shapedirs, posedirs, J_regressor)
         _lib.call("g4d_lbs_one_f32", B, V, J, NB, int(bool(pose2rot)), betas.data_ptr(), NB if betas.shape[0] == B else 0, pose.data_ptr(),
@@ -198,7 +199,7 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
                   lbs_weights.data_ptr(), A.data_ptr(), posed.data_ptr(), verts.data_ptr(), stream)
         return verts, posed
     v_posed = torch.empty((B, V, 3), dtype=torch.float32, device=dev)
-    if USE_FUSED_LBS and NB <= 64:
+    if _T().lbs_fused and NB <= 64:
         # three launches: the joints follow from betas through two model constants (J_regressor is linear), the shape blend rides
         # in the pose-blend kernel as NB extra coefficients
         blend_dirs, Jt, Js = _model_constants(v_template, shapedirs, posedirs, J_regressor)

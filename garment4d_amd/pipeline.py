@@ -30,6 +30,7 @@ import torch
 
 from . import _lib
 from . import lbs as G
+from . import tuning as _tuning
 
 
 class StepFuture:
@@ -64,10 +65,13 @@ class _Slot:
 
 class StepPipeline:
     def __init__(self, model, smpl=None, clouds_per_step=8, n_points=8192, coalesce=8, streams=2, precision="fp32", pose2rot=True,
-                 device=None, use_graph=True):
+                 device=None, use_graph=True, tuning=None):
         """model: a Pointnet2MSGSEG in eval mode (its forward_fused is what runs); smpl: dict with v_template, shapedirs, posedirs,
-        J_regressor, parents, lbs_weights (HIP tensors) or None for the encoder alone."""
+        J_regressor, parents, lbs_weights (HIP tensors) or None for the encoder alone.  tuning: the garment4d_amd.tuning.Tuning this
+        executor runs under (default: the one in force where it is constructed) -- held for its lifetime, applied around every call it
+        launches or captures; two executors in one process can carry different ones."""
         assert coalesce >= 1 and streams >= 1 and not model.training
+        self.tuning = tuning if tuning is not None else _tuning.current()
         self.model, self.smpl, self.B, self.N, self.k = model, smpl, int(clouds_per_step), int(n_points), int(coalesce)
         self.precision, self.pose2rot, self.use_graph = precision, pose2rot, use_graph
         dev = torch.device(device) if device is not None else next(model.parameters()).device
@@ -90,6 +94,10 @@ class StepPipeline:
 
     # ---- one call = the hot path on a slot's 8 * coalesce clouds
     def _call(self, s):
+        with _tuning.use(self.tuning):
+            return self._call_tuned(s)
+
+    def _call_tuned(self, s):
         out = self.model.forward_fused(s.cloud, precision=self.precision)
         v = j = None
         if self.smpl is not None:

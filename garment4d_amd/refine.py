@@ -15,10 +15,11 @@ import torch.nn as nn
 from . import _lib
 from . import dist as gdist
 from . import fused
+from .tuning import current as _T
 from .gcn import GraphConvolution, gcn_stack_forward
 
 
-USE_PE_KERNEL = True   # tests flip this to cover the generic fused-stack route
+# (USE_PE_KERNEL -> tuning.Tuning.use_pe_kernel) tests flip this to cover the generic fused-stack route
 
 
 def _pack_linear_mlp(seq):
@@ -108,7 +109,7 @@ def positional_encoding(mlp, radius, nsample, xyz, new_xyz, feats_pm, out, col0,
     Vg = new_xyz.shape[1]
     C = feats_pm.shape[2]
     n_extra = 0 if table is not None else C
-    w = _pe_kernel_weights(mlp, 3 + n_extra) if (USE_PE_KERNEL and nsample in (4, 8, 16, 32, 64) and n_extra <= 5) else None
+    w = _pe_kernel_weights(mlp, 3 + n_extra) if (_T().use_pe_kernel and nsample in (4, 8, 16, 32, 64) and n_extra <= 5) else None
     if w is not None:
         W1, b1, W2f, b2 = w
         _lib.call("g4d_pos_encode_f32", F_, N, Vg, nsample, n_extra, xyz.data_ptr(), new_xyz.data_ptr(),

@@ -342,10 +342,15 @@ int g4d_linear_interp_add_f32(long long rows, int n, int m, int K, int Kpad, int
                               int tab_ld, const float *dist2, const int *nn_idx, const float *scale, const float *shift, int relu, float *out, int ldo,
                               int col0, g4d_stream_t stream);
 
-/* Run-time tuning switch of the large-launch kernels: keys "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "fp_table_persistent",
- * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "gemm_tile", "gemm_tile_min_rows" (each also an environment variable G4D_<KEY IN UPPER CASE>, read on first use).
- * Process-wide; for A/B measurements and tests -- every setting computes the same bits. */
+/* Run-time tuning switches of the large-launch kernels.  Keys: "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "fp_table_persistent",
+ * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "sa_group_bf16_persistent",
+ * "sa_group_bf16_min_rows", "gemm_tile", "gemm_tile_min_rows", "gemm_tile_min_cout", "gemm_tile_min_kpad".  Resolution order, per launch, on the
+ * launching host thread: the thread's override (g4d_tuning_set_thread) > the process-wide value (g4d_tuning_set) > the environment variable
+ * G4D_<KEY IN UPPER CASE> (read once, on first use) > the built-in default.  For A/B measurements, tests and executors that carry their own
+ * tuning (garment4d_amd/tuning.py) -- every setting computes the same bits.  g4d_tuning_set_thread(key, value, set): set != 0 installs the
+ * override for launches made by the calling thread, set == 0 removes it. */
 int g4d_tuning_set(const char *key, long long value);
+int g4d_tuning_set_thread(const char *key, long long value, int set);
 
 /* Up to 4 contiguous device-to-device copies (dst[i][0 .. nfloats[i]) = src[i][...]) in one launch -- the executor of
  * garment4d_amd/pipeline.py hands a step's cloud, betas and pose over with it (the reference moves them with three .cuda() copies per

@@ -47,7 +47,7 @@ S0 = s0.cuda_stream
 
 units, cur = [], None
 for name, args in rec:
-    if name == "g4d_tuning_set":
+    if name in ("g4d_tuning_set", "g4d_tuning_set_thread"):
         continue
     if name == "g4d_launch_group_begin":
         cur = [(name, args)]

@@ -24,12 +24,12 @@ for qname, qarr in QUERIES.items():
     qq = torch.from_numpy(np.repeat(qarr[None], F_, 0)).cuda()
     res = {}
     for mode in ("scan", "boxes", "lanes", "lanes+sort"):
-        fused.COHERENT_LANES = mode.startswith("lanes")
-        fused.LANES_SORT = mode == "lanes+sort"
-        kw = dict(coherent=mode != "scan", grid=False if mode == "scan" else None)
-        for _ in range(2): o = fused.ball_query_msg(radii, ns, body, qq, **kw)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(5): o = fused.ball_query_msg(radii, ns, body, qq, **kw)
-        torch.cuda.synchronize(); res[mode] = ((time.perf_counter() - t0) / 5, o)
+        from garment4d_amd import tuning
+        with tuning.use(tuning.current().replace(coherent_lanes=mode.startswith("lanes"), lanes_sort=mode == "lanes+sort")):
+            kw = dict(coherent=mode != "scan", grid=False if mode == "scan" else None)
+            for _ in range(2): o = fused.ball_query_msg(radii, ns, body, qq, **kw)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5): o = fused.ball_query_msg(radii, ns, body, qq, **kw)
+            torch.cuda.synchronize(); res[mode] = ((time.perf_counter() - t0) / 5, o)
     same = all(all(torch.equal(res["scan"][1][i], res[k][1][i]) for k in res) for i in range(3))
     print(f"{qname:28s} {name:14s}: " + " | ".join(f"{k} {v[0]*1e6:7.1f} us" for k, v in res.items()) + f" | identical={same}")

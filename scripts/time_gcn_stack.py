@@ -26,6 +26,7 @@ def timeit(fn, it=5):
 
 with torch.no_grad():
     for fused in (False, True):
-        G.FUSE_STACK = fused
-        t = timeit(lambda: G.gcn_stack_forward(layers, x, adj, keep=(2,)))
+        from garment4d_amd import tuning
+        with tuning.use(tuning.current().replace(gcn_fuse_stack=fused)):
+            t = timeit(lambda: G.gcn_stack_forward(layers, x, adj, keep=(2,)))
         print(f"fused={fused}: {t:.3f} ms per stack of 4 layers ({F_} frames x {Vg} vertices)")

@@ -16,7 +16,9 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 240]:
     wv, wj = LO.lbs(bn[fr], pn[fr], Pn["v_template"], Pn["shapedirs"], Pn["posedirs"], Pn["J_regressor"], Pn["parents"], Pn["lbs_weights"])
     line = [f"lbs() {B:4d} frames:"]
     for name, mf, one in (("mfma", True, True), ("one launch", False, True), ("three launches", False, False)):
-        L.USE_MFMA, L.USE_ONE_LAUNCH, L.ONE_LAUNCH_MAX_B = mf, one, 1 << 30
+        from garment4d_amd import tuning
+        ctx = tuning.use(tuning.current().replace(lbs_mfma=mf, lbs_one_launch=one, lbs_one_launch_max_b=1 << 30))
+        ctx.__enter__()
         out = L.lbs(*args); torch.cuda.synchronize()
         err = max(float(np.abs(out[0][fr].cpu().numpy() - wv).max()), float(np.abs(out[1][fr].cpu().numpy() - wj).max()))
         g = torch.cuda.CUDAGraph()
@@ -27,5 +29,6 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 240]:
         ts = []
         for _ in range(5):
             torch.cuda.synchronize(); t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 20 * 1e6)
+        ctx.__exit__(None, None, None)
         line.append(f"{name} {min(ts):7.1f} us (max err vs oracle {err:.1e})")
     print(" | ".join(line))

@@ -81,3 +81,18 @@ def golden_refine():
     case = syn.refine_golden_case()
     assert np.array_equal(syn.refine_golden_checksum(case), g["checksum"]), "synthetic.refine_golden_case drifted from refine.npz"
     return g, case
+
+
+@pytest.fixture
+def tune():
+    """tune(field=value, ...): run the REST of the test under a garment4d_amd.tuning.Tuning with these fields changed (native={"key": v} for the
+    library's tuning table); may be called repeatedly (each call builds on the one before); everything is restored when the test ends.
+    Replaces the monkeypatching of module-level switches of rounds 1-4: the kernel-selection state is one explicit object."""
+    import contextlib
+    from garment4d_amd import tuning
+    stack = contextlib.ExitStack()
+
+    def set_(**kw):
+        stack.enter_context(tuning.use(tuning.current().replace(**kw)))
+    yield set_
+    stack.close()

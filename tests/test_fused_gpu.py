@@ -111,12 +111,12 @@ def test_transpose_roundtrip():
 
 
 @pytest.mark.parametrize("use_stack,use_chain", [(True, True), (True, False), (False, False)])
-def test_stack_kernel_equals_per_layer_kernels(use_stack, use_chain, monkeypatch):
+def test_stack_kernel_equals_per_layer_kernels(use_stack, use_chain, tune):
     """mlp_stack.hip (whole stack per launch) and mlp.hip (one launch per layer) against the op-by-op path on every
     SA / FP / head shape of the cfg2 encoder (smaller clouds)."""
     from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
-    monkeypatch.setattr(fused, "USE_STACK", use_stack)
-    monkeypatch.setattr(fused, "USE_CHAIN", use_chain)
+    tune(use_stack=use_stack)
+    tune(use_chain=use_chain)
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=True), seed=5).cuda().eval()
     x = dev(syn.body_like_cloud(2, 3000, seed=11))
     with torch.no_grad():
@@ -160,7 +160,7 @@ def test_stack_pool_windows(S, widths, pool, precision, monkeypatch, request_fin
 @pytest.mark.parametrize("widths", [(3, 16, 16, 32), (3, 32, 32, 64), (99, 64, 64, 128), (195, 128, 128, 256), (67, 32, 32), (99, 128, 128), (40, 64),
                                     (128, 7)])
 @pytest.mark.parametrize("S,pool", [(16, 1), (32, 1), (64, 1), (8, 1), (4, 2), (64, 2), (1, 0)])
-def test_chain_kernel_equals_lds_kernels(widths, S, pool, monkeypatch):
+def test_chain_kernel_equals_lds_kernels(widths, S, pool, tune):
     """csrc/mlp_chain.hip (activations chained through the MFMA accumulators, no LDS) against the LDS-staged stack / wave
     kernels on the same grouped input: every supported tile combination, every pool window, ragged row counts."""
     g = torch.Generator().manual_seed(len(widths) * 100 + S)
@@ -180,7 +180,7 @@ def test_chain_kernel_equals_lds_kernels(widths, S, pool, monkeypatch):
     grp = (N, P, max(C, 0), 1, xyz, new_xyz, feats, idx)
     outs = {}
     for chain in (True, False):
-        monkeypatch.setattr(fused, "USE_CHAIN", chain)
+        tune(use_chain=chain)
         o = torch.full((rows // S_ if pool else rows, widths[-1] + 5), 3.0, device="cuda")
         fused.mlp_stack(1, rows, widths[0], layers, o, col0=2, pool=pool, S=S_, group=grp)
         outs[chain] = o
@@ -191,7 +191,7 @@ def test_chain_kernel_equals_lds_kernels(widths, S, pool, monkeypatch):
 
 @pytest.mark.parametrize("widths", [(3, 32, 32, 64), (195, 128, 128, 256), (99, 128, 128), (128, 7)])
 @pytest.mark.parametrize("S,pool", [(16, 1), (64, 1), (4, 2), (1, 0)])
-def test_chain_kernel_32_rows_per_wave(widths, S, pool, monkeypatch):
+def test_chain_kernel_32_rows_per_wave(widths, S, pool, tune):
     """Large launches take the 32-rows-per-wave instantiation of mlp_chain.hip (pool groups span 2 waves at S = 64)."""
     g = torch.Generator().manual_seed(S + len(widths))
     S_ = max(S, 1)
@@ -208,7 +208,7 @@ def test_chain_kernel_32_rows_per_wave(widths, S, pool, monkeypatch):
     assert rows >= 65536 and fused.chain_fits(layers, pool, S_, 1)
     outs = {}
     for chain in (True, False):
-        monkeypatch.setattr(fused, "USE_CHAIN", chain)
+        tune(use_chain=chain)
         o = torch.empty((rows // S_ if pool else rows, widths[-1]), device="cuda")
         fused.mlp_stack(1, rows, widths[0], layers, o, pool=pool, S=S_, group=(N, P, max(C, 0), 1, xyz, new_xyz, feats, idx))
         outs[chain] = o
@@ -319,7 +319,7 @@ def test_chain_bf16x3_kernel_is_fp32_accurate(widths, S, pool, monkeypatch, requ
 
 @pytest.mark.parametrize("rows,K,Cout,relu,col0,extra", [(65536, 128, 128, True, 0, 0), (70001, 128, 384, False, 0, 0), (65600, 96, 256, True, 5, 11),
                                                          (131072, 70, 128, False, 0, 0)])
-def test_row_streaming_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra, monkeypatch):
+def test_row_streaming_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra, tune):
     """csrc/gemm_stream.hip (tall un-pooled contractions, K <= 128, Cout a multiple of 128: config 4's qkv projection) against the
     LDS-tiled kernel it replaces there -- the same k order, so the results must be EQUAL -- and against float64: row counts that are
     not a multiple of the 128-row tile, ragged K, an output window inside a wider matrix."""
@@ -332,7 +332,7 @@ def test_row_streaming_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, e
     outs = [torch.full((rows, ldo), 7.0, device="cuda") for _ in range(2)]
 
     def run(stream_on, out):
-        monkeypatch.setattr(fused, "STREAM_GEMM", stream_on)
+        tune(stream_gemm=stream_on)
         if stream_on:
             fused.linear(x, L, out=out, col0=col0)
         else:   # below the row threshold the library always takes the LDS-tiled kernel: run it in 32768-row slabs
@@ -381,7 +381,7 @@ def test_shared_mlp_variants_run_op_by_op_and_are_refused_by_the_fused_path(vari
 
 @pytest.mark.parametrize("pool", ["max_pool", "avg_pool"])
 @pytest.mark.parametrize("B,N,P", [(1, 700, 33), (3, 2500, 257), (2, 6890, 512)])
-def test_sa_xyz_kernel_equals_chain_kernels_and_module(B, N, P, pool, monkeypatch):
+def test_sa_xyz_kernel_equals_chain_kernels_and_module(B, N, P, pool, tune):
     """csrc/sa_xyz.hip (xyz-only 3-layer SA stacks: weights in registers, layer 1 on the VALU, transposed middle layer) against the
     register-chain kernels on the same module, and against the op-by-op module: both supported stacks (16-16-32 at 16 samples,
     32-32-64 at 32), both pooling modes, row counts that are not a multiple of the 128-row workgroup pass, several frames."""
@@ -399,7 +399,7 @@ def test_sa_xyz_kernel_equals_chain_kernels_and_module(B, N, P, pool, monkeypatc
     with torch.no_grad():
         nx, want = sa(xyz, None)
         for on in (True, False):
-            monkeypatch.setattr(fused, "USE_SA_XYZ", on)
+            tune(use_sa_xyz=on)
             nx2, outs[on] = fused.sa_forward(sa, xyz, None)
             assert torch.equal(nx, nx2)
     scale = max(float(want.abs().max()), 1.0)
@@ -415,7 +415,7 @@ def test_sa_xyz_kernel_equals_chain_kernels_and_module(B, N, P, pool, monkeypatc
 @pytest.mark.parametrize("mlp,head_widths", [([128, 128], (64, 32, 7)), ([128, 128], None), ([64, 128, 64], (32,)), ([128, 128, 128, 64], None),
                                              ([96, 64], (64, 64))])
 @pytest.mark.parametrize("B,n,m", [(2, 3000, 333), (8, 8192, 1024), (1, 100, 7)])
-def test_fp_without_skip_on_the_pre_contracted_table(mlp, head_widths, B, n, m, monkeypatch):
+def test_fp_without_skip_on_the_pre_contracted_table(mlp, head_widths, B, n, m, tune):
     """FP levels without skip features run their first layer over the m KNOWN rows (conv(sum w_i f_i) = sum w_i conv(f_i)) and the
     register-chain kernel interpolates the table (g4d_mlp_chain_table_f32): against the op-by-op module, the fused path without the
     table, and the oracle -- with and without a head behind it, one or several FP layers, the benched size, row counts that are
@@ -442,7 +442,7 @@ def test_fp_without_skip_on_the_pre_contracted_table(mlp, head_widths, B, n, m, 
         want = fp(unknown, known, None, kf)
         want_head = head(want) if head is not None else None
         for table in (True, False):
-            monkeypatch.setattr(fused, "FP_TABLE", table)
+            tune(fp_table=table)
             outs[table] = fused.fp_forward(fp, unknown, known, None, fused.to_point_major(kf), head=head)
     got, ref = outs[True], outs[False]
     if head is None:
@@ -461,7 +461,7 @@ def test_fp_without_skip_on_the_pre_contracted_table(mlp, head_widths, B, n, m, 
     (3, 777, 129, 40, [[40, 64, 128], [40, 48, 64, 128]], [16, 64]),           # a 2-layer scale (table) next to one whose width is not a multiple of 16 (no table)
     (1, 300, 33, 7, [[7, 128, 128]], [8]),                                     # ragged feature width, single scale, window 8
 ])
-def test_sa_with_features_on_the_per_source_point_table(B, N, P, C, mlps, nsamples, pool, monkeypatch):
+def test_sa_with_features_on_the_per_source_point_table(B, N, P, C, mlps, nsamples, pool, tune):
     """SA levels with features run the feature part of their first layer once per SOURCE point (W [x_j - q ; f_j] = Wx (x_j - q) + Wf f_j,
     fused.sa_level_table) and the chain kernel's loader adds the xyz part (g4d_mlp_chain_group_table_f32): against the op-by-op module,
     the fused path without the table and -- on the smallest case -- the oracle; max and avg pooling, several scales sharing one table."""
@@ -482,7 +482,7 @@ def test_sa_with_features_on_the_per_source_point_table(B, N, P, C, mlps, nsampl
     with torch.no_grad():
         nx, want = sa(xyz, feats)
         for on in (True, False):
-            monkeypatch.setattr(fused, "SA_TABLE", on)
+            tune(sa_table=on)
             nx2, outs[on] = fused.sa_forward(sa, xyz, fpm)
             assert torch.equal(nx, nx2)
     np.testing.assert_allclose(outs[True].cpu().numpy(), outs[False].cpu().numpy(), rtol=1e-5, atol=1e-5)
@@ -496,7 +496,7 @@ def test_sa_with_features_on_the_per_source_point_table(B, N, P, C, mlps, nsampl
 
 @pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(8, 1024, 256, 256, 96, [352, 256, 128]), (2, 700, 99, 64, 35, [99, 128, 128]), (1, 300, 40, 32, 16, [48, 64, 64]),
                                              (3, 2000, 500, 128, 128, [256, 128, 64])])
-def test_fp_with_skip_features_on_the_interpolated_table(B, n, m, C2, C1, mlp, monkeypatch):
+def test_fp_with_skip_features_on_the_interpolated_table(B, n, m, C2, C1, mlp, tune):
     """FP levels WITH skip features whose stack fits the register-chain kernel: the known-feature columns of the first layer are contracted
     over the m known rows, the accumulators start from the interpolated table and the matrix pipe adds the skip columns
     (g4d_mlp_chain_interp_init_f32) -- against the op-by-op module, the fused path without the table and the oracle (smallest case)."""
@@ -513,7 +513,7 @@ def test_fp_with_skip_features_on_the_interpolated_table(B, n, m, C2, C1, mlp, m
     with torch.no_grad():
         want = fp(unknown, known, uf, kf)
         for table in (True, False):
-            monkeypatch.setattr(fused, "FP_TABLE", table)
+            tune(fp_table=table)
             outs[table] = fused.fp_forward(fp, unknown, known, fused.to_point_major(uf), fused.to_point_major(kf))
     np.testing.assert_allclose(outs[True].cpu().numpy(), outs[False].cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
@@ -601,7 +601,7 @@ def test_launch_group_state_errors():
 
 
 @pytest.mark.parametrize("B,n,m,mlp,head_widths", [(8, 8192, 1024, [128, 128, 64], [32, 7]), (2, 5000, 300, [64, 64], None), (1, 4096, 256, [32, 32, 32], [16])])
-def test_fp_over_cell_ordered_rows_is_bit_identical(B, n, m, mlp, head_widths, monkeypatch):
+def test_fp_over_cell_ordered_rows_is_bit_identical(B, n, m, mlp, head_widths, tune):
     """The last FP level with the unknown cloud's ball grid at hand: three_nn results stay in cell order and the table launch walks the
     points in that order (g4d_three_nn_cells_sorted_f32 + g4d_mlp_chain_table_cells_f32), writing every output to its original row --
     bit-identical to the un-sorted route, features and head outputs."""
@@ -626,7 +626,7 @@ def test_fp_over_cell_ordered_rows_is_bit_identical(B, n, m, mlp, head_widths, m
     outs = {}
     with torch.no_grad():
         for on in (True, False):
-            monkeypatch.setattr(fused, "FP_CELLS", on)
+            tune(fp_cells=on)
             outs[on] = fused.fp_forward(fp, unknown, known, None, kf, head=head, unknown_grid=grid)
     if head is not None:
         assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])

@@ -15,19 +15,11 @@ from garment4d_amd import _lib, fused, lbs as L, pointnet2_modules as PM, pytorc
 pytestmark = pytest.mark.gpu
 
 
-@contextlib.contextmanager
 def tuning(**kv):
-    """g4d_tuning_set for the duration of the block; restores the defaults of this file's keys afterwards."""
-    defaults = {"sa_table_persistent": 1, "sa_table_min_rows": 262144, "sa_table_128": 1, "fp_table_persistent": 1, "fp_table_min_rows": 262144,
-                "gemm_tile": 1, "gemm_tile_min_rows": 32768, "fp_init_persistent": 1, "fp_init_min_rows": 131072, "fp_head_bf16_persistent": 1, "fp_head_bf16_min_rows": 262144,
-                "sa_group_bf16_persistent": 1, "sa_group_bf16_min_rows": 262144}
-    try:
-        for k, v in kv.items():
-            _lib.call("g4d_tuning_set", k.encode(), int(v))
-        yield
-    finally:
-        for k in kv:
-            _lib.call("g4d_tuning_set", k.encode(), defaults[k])
+    """The library's tuning keys (include/g4d.h) for the duration of the block, through an explicit Tuning object (garment4d_amd/tuning.py:
+    per-thread overrides, removed on exit) -- no process-wide state is touched."""
+    from garment4d_amd import tuning as T
+    return T.use(T.current().replace(native=kv))
 
 
 def _seed_bn(mod):
@@ -60,7 +52,7 @@ def test_sa_table_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, mlps, 
 
 @pytest.mark.parametrize("cells", [True, False])
 @pytest.mark.parametrize("B,n,m", [(2, 8192, 1024), (3, 5000, 300), (1, 4100, 257)])
-def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, monkeypatch):
+def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, tune):
     """Last FP level + head (128 -> [128] -> 64 -> 32 -> 7) in place and over cell-ordered rows; n = 5000 / 4100: 16-row tiles straddle clouds."""
     torch.manual_seed(n)
     unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
@@ -69,7 +61,7 @@ def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, mo
     fp = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
     head = _seed_bn(torch.nn.Sequential(pt_utils.Conv1d(64, 32, bn=True), torch.nn.Dropout(), pt_utils.Conv1d(32, 7, activation=None)))
     grid = fused.build_ball_grid(unknown, 0.1)
-    monkeypatch.setattr(fused, "FP_CELLS", cells)
+    tune(fp_cells=cells)
     outs = {}
     with torch.no_grad():
         for on in (0, 1):
@@ -103,9 +95,10 @@ def test_tile_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra):
 
 
 @pytest.mark.parametrize("B", [1, 8, 9, 37, 240])
-def test_lbs_one_launch_does_not_depend_on_the_batch(B, monkeypatch):
-    """lbs_one_kernel walks the 8-frame groups of any batch; a frame's vertices must not depend on which batch it arrives in (the executor
-    coalesces steps) nor on how the groups are spread over workgroups."""
+def test_lbs_one_launch_does_not_depend_on_the_batch(B, tune):
+    """lbs() (round 5: the matrix-pipe route, one accumulator chain per output element over k ascending; round 4: lbs_one_kernel walking the
+    8-frame groups of any batch): a frame's vertices must not depend on which batch it arrives in (the executor coalesces steps) nor on how
+    the frame tiles are spread over waves / workgroups."""
     P = {k: torch.from_numpy(v).cuda() for k, v in syn.smpl_like_params(seed=3).items()}
     betas, pose = (torch.from_numpy(a).cuda() for a in syn.smpl_like_pose(B, seed=B))
     args = (P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"])
@@ -113,10 +106,17 @@ def test_lbs_one_launch_does_not_depend_on_the_batch(B, monkeypatch):
     for f in sorted({0, B // 2, B - 1}):
         v1, j1 = L.lbs(betas[f:f + 1].contiguous(), pose[f:f + 1].contiguous(), *args)
         assert torch.equal(v[f:f + 1], v1) and torch.equal(j[f:f + 1], j1), f"frame {f} of {B}"
-    monkeypatch.setattr(L, "ONE_LAUNCH_MAX_B", 0)     # the three-launch route partitions the blend sum differently: close, not equal
-    v3, j3 = L.lbs(betas, pose, *args)
-    torch.testing.assert_close(v, v3, rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(j, j3, rtol=1e-5, atol=1e-5)
+    # the other routes partition the blend sum differently: close, not equal
+    for other in (dict(lbs_mfma=False), dict(lbs_mfma=False, lbs_one_launch_max_b=0)):   # round 4's one-launch kernel; the three-launch route
+        tune(**other)
+        v3, j3 = L.lbs(betas, pose, *args)
+        torch.testing.assert_close(v, v3, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(j, j3, rtol=1e-5, atol=1e-5)
+    if B in (9, 240):   # round 4's kernel is batch-invariant too
+        tune(lbs_mfma=False, lbs_one_launch_max_b=1 << 30)
+        v4, _ = L.lbs(betas, pose, *args)
+        v41, _ = L.lbs(betas[B - 1:].contiguous(), pose[B - 1:].contiguous(), *args)
+        assert torch.equal(v4[B - 1:], v41)
 
 
 def test_copy_segments():
@@ -211,7 +211,7 @@ def test_sa_group_bf16_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, m
 
 
 @pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(40, 256, 64, 384, 192, [576, 512, 256]), (5, 1000, 100, 128, 60, [188, 512, 128]), (3, 333, 40, 96, 92, [188, 384, 256])])
-def test_wide_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n, m, C2, C1, mlp, monkeypatch):
+def test_wide_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n, m, C2, C1, mlp, tune):
     """Config 3's wide FP level: interpolation pre-pass + two tiled bf16 GEMMs in fragment order (csrc/gemm_bf16.hip) against the LDS stack kernel
     (g4d_mlp_stack_bf16), bit for bit; row counts that are not multiples of 128, 188 input columns (a ragged last k-step), 384 outputs
     feeding 384 of 384 columns of the next layer."""
@@ -224,8 +224,8 @@ def test_wide_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n
     outs = {}
     with torch.no_grad(), fused.precision("bf16"):
         for on in (False, True):
-            monkeypatch.setattr(fused, "FP_GEMM_BF16", on)
-            monkeypatch.setattr(fused, "FP_GEMM_BF16_MIN_ROWS", 0)
+            tune(fp_gemm_bf16=on)
+            tune(fp_gemm_bf16_min_rows=0)
             with _lib.timed_calls() as t:
                 outs[on] = fused.fp_forward(fp, unknown, known, skip, kf)
             names = [r[0] for r in t.results()]
@@ -237,7 +237,7 @@ def test_wide_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n
 
 
 @pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(3, 256, 64, 384, 192, [576, 512, 256]), (2, 1000, 100, 128, 64, [192, 256, 128]), (1, 333, 40, 96, 100, [196, 384])])
-def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, monkeypatch):
+def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, tune):
     """Wide FP levels with skip features (FP level 3 of the encoder): W [interp(f) ; s] = interp(Wa f) + Wb s -- table over the known rows, skip
     columns as a GEMM with the interpolated table added in its epilogue (g4d_linear_interp_add_f32).  Against the materialised route and the
     op-by-op module at 1e-5; the 128 x 128-tile kernel and the 64 x 64 one must agree bit for bit on it."""
@@ -250,7 +250,7 @@ def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, 
     outs = {}
     with torch.no_grad():
         for on in (False, True):
-            monkeypatch.setattr(fused, "FP_WIDE_TABLE", on)
+            tune(fp_wide_table=on)
             outs[on] = fused.fp_forward(fp, unknown, known, skip, kf)
         with tuning(gemm_tile=1, gemm_tile_min_rows=0):
             tiled = fused.fp_forward(fp, unknown, known, skip, kf)

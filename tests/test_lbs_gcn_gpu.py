@@ -144,7 +144,7 @@ def _regressor(first, seed):
 
 
 @pytest.mark.parametrize("rc,frames,numbering", [((64, 64), 3, "mesh"), ((20, 23), 2, "mesh"), ((20, 23), 2, "shuffled"), ((9, 7), 1, "mesh")])
-def test_gcn_stack_fused_vs_layer_by_layer_and_oracle(rc, frames, numbering, monkeypatch):
+def test_gcn_stack_fused_vs_layer_by_layer_and_oracle(rc, frames, numbering, tune):
     """gcn_stack_forward (aggregation of layer i + contraction of layer i+1 in one launch, csrc/gcn_fused.hip) against the chained
     GraphConvolution.forward and the numpy restatement: mesh numbering (LDS window), a shuffled numbering (window too wide: global
     gather), vertex counts that are not a multiple of the 128-row tile.  The kept activation (`keep`) is the SpMM's output bit for bit."""
@@ -159,7 +159,7 @@ def test_gcn_stack_fused_vs_layer_by_layer_and_oracle(rc, frames, numbering, mon
     layers = _regressor(195, Vg)
     with torch.no_grad():
         got = G.gcn_stack_forward(layers, dev(x), adj, keep=(2,))
-        monkeypatch.setattr(G, "FUSE_STACK", False)
+        tune(gcn_fuse_stack=False)
         ref = G.gcn_stack_forward(layers, dev(x), adj, keep=(2,))
     assert got[0] is None and got[1] is None and all(r is not None for r in ref)
     assert torch.equal(got[2], ref[2]) or float((got[2] - ref[2]).abs().max()) <= 1e-5 * max(1.0, float(ref[2].abs().max()))
@@ -190,12 +190,9 @@ def test_gcn_stack_fused_without_bias_and_with_long_rows():
     x = torch.randn(2, Vg, 40, generator=torch.Generator().manual_seed(4)).cuda()
     with torch.no_grad():
         got = G.gcn_stack_forward(layers, x, adj, keep=(0, 1))
-        prev = G.FUSE_STACK
-        G.FUSE_STACK = False
-        try:
+        from garment4d_amd import tuning
+        with tuning.use(tuning.current().replace(gcn_fuse_stack=False)):
             ref = G.gcn_stack_forward(layers, x, adj, keep=(0, 1))
-        finally:
-            G.FUSE_STACK = prev
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])                 # kept activations: the SpMM's arithmetic
     torch.testing.assert_close(got[2], ref[2], rtol=1e-5, atol=1e-5)
 
@@ -227,13 +224,12 @@ def test_gcn_agg_linear_tap_is_bit_identical_to_spmm():
                   0, L.Wf.data_ptr(), 128, out.data_ptr(), _lib.stream_ptr())
 
 
-@pytest.mark.parametrize("fused_path", ["one", "three", False])
-def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, monkeypatch):
-    """All lbs() routes -- the one-launch kernel, the three-launch one (both: joints from betas via J_regressor's linearity, shape
-    blend folded into the pose blend) and the five-step one that follows lbs.py line by line -- against the reference's outputs at
-    full SMPL size."""
-    monkeypatch.setattr(L, "USE_FUSED_LBS", bool(fused_path))
-    monkeypatch.setattr(L, "USE_ONE_LAUNCH", fused_path == "one")
+@pytest.mark.parametrize("fused_path", ["mfma", "one", "three", False])
+def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, tune):
+    """All lbs() routes -- the matrix-pipe one (round 5), the one-launch kernel, the three-launch one (all three: joints from betas via
+    J_regressor's linearity, shape blend folded into the pose blend) and the five-step one that follows lbs.py line by line -- against the
+    reference's outputs at full SMPL size."""
+    tune(lbs_fused=bool(fused_path), lbs_mfma=fused_path == "mfma", lbs_one_launch=fused_path == "one")
     g = golden_lbs
     P = syn.smpl_like_params(V=6890, J=24, num_betas=10, seed=40)
     betas, pose = syn.smpl_like_pose(2, seed=41)
@@ -280,7 +276,7 @@ def test_lbs_rejects_mismatched_shapes_before_touching_the_device():
 
 @pytest.mark.parametrize("B,V,J,NB,rot", [(1, 64, 24, 10, True), (8, 6890, 24, 10, True), (19, 1500, 24, 10, False), (9, 777, 25, 1, True),
                                           (3, 130, 5, 16, True), (17, 63, 23, 3, False)])
-def test_lbs_one_launch_kernel_vs_three_launch_route_and_oracle(B, V, J, NB, rot, monkeypatch):
+def test_lbs_one_launch_kernel_vs_three_launch_route_and_oracle(B, V, J, NB, rot, tune):
     """g4d_lbs_one_f32 against g4d_lbs_fused_f32 (same constants, different summation order of the blend) and the numpy oracle:
     frame counts that are not a multiple of the 8-frame group, vertex counts that are not a multiple of the 64-vertex tile, joint
     counts up to the kernel's 32, a weight row that is not 16-byte aligned (J = 5, 23), rotation-matrix input."""
@@ -290,11 +286,15 @@ def test_lbs_one_launch_kernel_vs_three_launch_route_and_oracle(B, V, J, NB, rot
     pose_in = pose if rot else lbs_oracle.batch_rodrigues(pose.reshape(-1, 3)).reshape(B, J, 3, 3)
     args = [dev(P[k]) for k in ("v_template", "shapedirs", "posedirs", "J_regressor")] + [torch.from_numpy(P["parents"]), dev(P["lbs_weights"])]
     outs = {}
-    monkeypatch.setattr(L, "ONE_LAUNCH_MAX_B", 1 << 30)
+    tune(lbs_one_launch_max_b=1 << 30, lbs_mfma=False)
     for one in (True, False):
-        monkeypatch.setattr(L, "USE_ONE_LAUNCH", one)
+        tune(lbs_one_launch=one)
         outs[one] = L.lbs(dev(betas), dev(np.ascontiguousarray(pose_in)), *args, pose2rot=rot)
-    assert L._lib.lib().g4d_lbs_one_supported(J, NB)
+    assert L._lib.lib().g4d_lbs_one_supported(J, NB) and L._lib.lib().g4d_lbs_mfma_supported(J, NB)
+    tune(lbs_mfma=True)                                       # round 5: the matrix-pipe route on the same ragged shapes (JS = 6 and 8, V % 32 != 0, B % 16 != 0)
+    mf = L.lbs(dev(betas), dev(np.ascontiguousarray(pose_in)), *args, pose2rot=rot)
+    np.testing.assert_allclose(host(mf[0]), host(outs[False][0]), rtol=2e-6, atol=2e-6)
+    assert torch.equal(mf[1], outs[False][1])                 # the rigid chain is the same code
     np.testing.assert_allclose(host(outs[True][0]), host(outs[False][0]), rtol=2e-6, atol=2e-6)
     assert torch.equal(outs[True][1], outs[False][1])        # the rigid chain is the same code
     wv, wj = lbs_oracle.lbs(betas, pose_in, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"],

@@ -321,7 +321,7 @@ def test_fps_bucketed_variant_is_index_exact():
 
 @pytest.mark.parametrize("order", ["mesh", "random"])
 @pytest.mark.parametrize("B,N,P", [(2, 6890, 1000), (1, 300, 64), (3, 1722, 130), (1, 64, 1)])
-def test_ball_query_lanes_kernel_equals_the_scan(B, N, P, order, monkeypatch):
+def test_ball_query_lanes_kernel_equals_the_scan(B, N, P, order, tune):
     """g4d_ball_query_lanes_f32 (one lane per query, block culling against the wave's query box) against the scan and the oracle:
     mesh-ordered and randomly ordered queries (the latter only slower), duplicate / zero-padded clouds, a NaN query, queries far
     away, P not a multiple of 64."""
@@ -340,9 +340,9 @@ def test_ball_query_lanes_kernel_equals_the_scan(B, N, P, order, monkeypatch):
         q[-1, 5] = 40.0
     radii, ns = [0.1, 0.2, 0.4], [8, 16, 32]
     scan = [t.cpu().numpy() for t in fused.ball_query_msg(radii, ns, dev(xyz), dev(q), coherent=False, grid=False)]
-    monkeypatch.setattr(fused, "COHERENT_LANES", True)
+    tune(coherent_lanes=True)
     for sort in (True, False):           # queries cell-sorted inside the call | taken in the caller's order
-        monkeypatch.setattr(fused, "LANES_SORT", sort)
+        tune(lanes_sort=sort)
         lanes = [t.cpu().numpy() for t in fused.ball_query_msg(radii, ns, dev(xyz), dev(q), coherent=True)]
         for a, b, r, n_ in zip(lanes, scan, radii, ns):
             assert np.array_equal(a, b), (order, sort, r)

@@ -59,9 +59,9 @@ def test_state_dict_keys_match_reference_names():
 
 @pytest.mark.parametrize("pe_kernel", [True, False])
 @pytest.mark.parametrize("garment", ["Tshirt", "Trousers"])
-def test_first_round_vs_oracle(garment, pe_kernel, monkeypatch):
+def test_first_round_vs_oracle(garment, pe_kernel, tune):
     from garment4d_amd import refine
-    monkeypatch.setattr(refine, "USE_PE_KERNEL", pe_kernel)   # dedicated positional-encoder kernel | generic fused stack
+    tune(use_pe_kernel=pe_kernel)   # dedicated positional-encoder kernel | generic fused stack
     nbatch, T = 2, 3
     head, sd, cur, body_v, body_vn, gv, gf, adj = _case(nbatch, T, seed=3, garment=garment)
     head.iteration = 1
