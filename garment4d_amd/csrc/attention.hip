@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) att_mix_kernel(int T, int vg, int C, cons
     const float *vp = qkv + (size_t)c * T * ld + (size_t)v * 3 * C + 2 * C + ch;
     f32x4 val[kAttMaxT];
 #pragma unroll
-    for (int u = 0; u < kAttMaxT; ++u) val[u] = u < T ? *reinterpret_cast<const f32x4 *>(vp + (size_t)u * ld) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < kAttMaxT; ++u) val[u] = u < T ? (f32x4)*reinterpret_cast<const f32x4u_att *>(vp + (size_t)u * ld) : (f32x4){0.f, 0.f, 0.f, 0.f};   // dword-aligned 16-byte loads: a qkv view at any 4-byte offset stays valid
     const float *a = att + (size_t)c * T * T;
     for (int t = 0; t < T; ++t) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -239,6 +239,9 @@ int g4d::fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const fl
     if (Cout[0] != D1 || Cout[1] != D2 || Cout[2] != D3 || Cout[3] > D4 || Cout[3] < 1 || Kpad[0] != D0 || Kpad[1] != D1 || Kpad[2] != D2 || Kpad[3] != D3) return -1;
     if (tap_out && (tap_layer != 1 || tap_ld % 4 != 0 || (reinterpret_cast<size_t>(tap_out) & 15) != 0)) return -1;
     if (n < 16 || m <= 0 || rows % n != 0 || (rows / n) * (long long)m * D0 >= (1ll << 32) || (reinterpret_cast<size_t>(known_feats) & 15) != 0) return -1;
+    G4D_REQUIRE(known_feats && dist2 && nn_idx && out && W[0] && W[1] && W[2] && W[3] && scale[0] && scale[1] && scale[2] && scale[3] && shift[0] && shift[1] && shift[2] && shift[3],
+                "g4d_mlp_chain_bf16: null pointer");
+    G4D_REQUIRE(ldo >= Cout[3] && (!tap_out || tap_ld >= Cout[1]), "g4d_mlp_chain_bf16: output row stride %d < %d channels or tap stride %d < %d", ldo, Cout[3], tap_ld, Cout[1]);
     FpHeadHArgs a;
     a.rows = (int)rows; a.n = n; a.m = m; a.feats = known_feats; a.dist2 = dist2; a.nn_idx = nn_idx;
     a.W1 = W[0]; a.W2 = W[1]; a.W3 = W[2]; a.W4 = W[3];

@@ -281,6 +281,10 @@ int g4d::fp_init_try(long long rows, int n, int m, int C1_, const float *skip, c
     if (Cout[0] != C1 || Cout[1] != C2 || Cout[2] != C3 || Kpad[0] != C0 || Kpad[1] != C1 || Kpad[2] != C2) return -1;
     if (tap_out && (tap_layer != 1 || tap_ld % 4 != 0 || (reinterpret_cast<size_t>(tap_out) & 15) != 0)) return -1;
     if (n < 16 || m <= 0 || rows % n != 0 || (rows / n) * (long long)m * tab_ld >= (1ll << 32) || tab_ld < C1 || (reinterpret_cast<size_t>(table) & 15) != 0) return -1;
+    G4D_REQUIRE(skip && table && dist2 && nn_idx && out && W[0] && W[1] && W[2] && scale[0] && scale[1] && scale[2] && shift[0] && shift[1] && shift[2],
+                "g4d_mlp_chain_interp_init_f32: null pointer");
+    G4D_REQUIRE(ldo >= Cout[2] && (!tap_out || tap_ld >= Cout[1]) && tab_ld % 4 == 0, "g4d_mlp_chain_interp_init_f32: output row stride %d < %d channels, tap stride %d < %d or table stride %d not a multiple of 4",
+                ldo, Cout[2], tap_ld, Cout[1], tab_ld);
     FpInitArgs a;
     a.rows = (int)rows; a.n = n; a.m = m; a.skip = skip; a.tab = table; a.tab_ld = tab_ld; a.dist2 = dist2; a.nn_idx = nn_idx;
     a.W1 = W[0]; a.sc1 = scale[0]; a.sh1 = shift[0]; a.W2 = W[1]; a.sc2 = scale[1]; a.sh2 = shift[1]; a.W3 = W[2]; a.sc3 = scale[2]; a.sh3 = shift[2];

@@ -206,6 +206,9 @@ int g4d::fp_table_try(long long rows, int n, int m, int C2, const float *table, 
     if (Cout[0] != kC2 || Cout[1] != kC3 || Cout[2] > kC4 || Cout[2] < 1 || Kpad[0] != kC1 || Kpad[1] != kC2 || Kpad[2] != kC3 || !relu[0] || !relu[1]) return -1;
     if (n < 16 || m <= 0 || rows % n != 0 || (rows / n) * (long long)m * kC1 >= (1ll << 32) || tap_ld % 4 != 0 || (reinterpret_cast<size_t>(tap_out) & 15) != 0 ||
         (reinterpret_cast<size_t>(table) & 15) != 0) return -1;
+    G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift && out && W[0] && W[1] && W[2] && scale[0] && scale[1] && scale[2] && shift[0] && shift[1] && shift[2],
+                "g4d_mlp_chain_table_f32: null pointer");
+    G4D_REQUIRE(ldo >= Cout[2] && tap_ld >= Cout[0], "g4d_mlp_chain_table_f32: output row stride %d < %d channels or tap stride %d < %d", ldo, Cout[2], tap_ld, Cout[0]);
     FpTabArgs a;
     a.rows = (int)rows; a.n = n; a.m = m; a.tab = table; a.dist2 = dist2; a.nn_idx = nn_idx;
     a.perm_rec = reinterpret_cast<const unsigned char *>(perm_rec); a.perm_stride = perm_stride;

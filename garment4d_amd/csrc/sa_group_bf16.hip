@@ -276,6 +276,9 @@ int g4d::sa_group_bf16_try(long long rows, int N, int P, int S, int C, int use_x
     const int T1 = Cout[0] / 16;
     if (Cout[0] % 16 != 0 || Kpad[0] != 32 * (C / 32 + 1) || C % 32 != 0 || Kpad[1] != 32 * ((T1 + 1) / 2) || Kpad[2] != Kpad[1]) return -1;
     if ((rows / S / P) * (long long)N * (C > 3 ? C : 3) >= (1ll << 32)) return -1;   // 32-bit element offsets
+    G4D_REQUIRE(out && W[0] && W[1] && W[2] && scale[0] && scale[1] && scale[2] && shift[0] && shift[1] && shift[2], "g4d_mlp_chain_bf16: null pointer");
+    G4D_REQUIRE(N > 0 && rows % ((long long)P * S) == 0 && ldo >= col0 + Cout[2] && col0 >= 0, "g4d_mlp_chain_bf16: rows must be clouds x P x S and the output window [%d, %d) must fit ldo = %d",
+                col0, col0 + Cout[2], ldo);
     SaGrpHArgs a;
     a.rows = (int)rows; a.N = N; a.P = P; a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
     a.W1 = W[0]; a.W2 = W[1]; a.W3 = W[2];

@@ -389,6 +389,11 @@ int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, con
     if (!on || pool != 1 || nlayers != 2 || rows < min_rows || rows >= (1ll << 31) - 64 || rows % S != 0) return -1;
     if (!(Kt == 32 || Kt == 64 || Kt == 128) || Cout[0] != Kt || Cout[1] != 2 * Kt || !relu[0] || !relu[1] || Kpad[0] != Kt || Kpad[1] != Kt) return -1;
     if ((long long)(rows / S / P) * N >= (1ll << 31)) return -1;
+    G4D_REQUIRE(xyz && new_xyz && idx && table && tab_wx && pre_scale && pre_shift && out && W[0] && W[1] && scale[0] && scale[1] && shift[0] && shift[1],
+                "g4d_mlp_chain_group_table_f32: null pointer");
+    G4D_REQUIRE(N > 0 && P > 0 && rows % ((long long)P * S) == 0 && ldo >= col0 + Cout[1] && col0 >= 0 && (tab_ld >= Kt || tab_ld == 0) && tab_ld % 4 == 0,
+                "g4d_mlp_chain_group_table_f32: rows must be clouds x P x S, the output window [%d, %d) must fit ldo = %d, the table stride %d must cover %d columns (or be 0)",
+                col0, col0 + Cout[1], ldo, tab_ld, Kt);
     SaTabArgs a;
     a.rows = (int)rows; a.N = N; a.P = P; a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.tab = table; a.tab_ld = tab_ld;
     a.wx = tab_wx; a.ps = pre_scale; a.pf = pre_shift;
