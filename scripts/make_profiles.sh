@@ -3,7 +3,7 @@
 #   gpurun -- 'bash scripts/make_profiles.sh r04').  Kernel traces and PMC passes are separate runs (a --pmc run never carries a trace
 # domain); everything lands in gpurun_out/profiles/ and is copied into profiles/ by hand.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p $OUT
@@ -45,6 +45,15 @@ python $ROOT/scripts/time_model.py 8 30 8192 3 > $OUT/${R}_cfg4_model_time.txt 2
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5 -o s -- python $ROOT/scripts/stress_cfg5.py > $OUT/cfg5.log 2>&1
 cp $OUT/cfg5/s_kernel_stats.csv $OUT/${R}_kernel_stats_cfg5_stress.csv
 python $ROOT/scripts/time_fps_big.py 2>&1 | grep -v amdgpu > $OUT/${R}_fps_large_clouds.txt
+# 6b. config 5's counters (BASELINE: "HBM-roofline run with rocprof counters"): HBM traffic and SQ counters of the stress launches
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc5_$C -o p -- python $ROOT/scripts/stress_cfg5.py > $OUT/pmc5_$C.log 2>&1
+done
+python $ROOT/scripts/pmc_to_profile.py $OUT/${R}_pmc_hbm_traffic_cfg5.csv $(find $OUT/pmc5_FETCH_SIZE $OUT/pmc5_WRITE_SIZE -name '*counter_collection.csv')
+PMC_SUFFIX=_cfg5 PMC_CMD="python $ROOT/scripts/stress_cfg5.py" bash $ROOT/scripts/make_pmc_sq.sh $R > $OUT/pmc_sq_cfg5.log 2>&1
+rm -rf $OUT/pmc5_FETCH_SIZE $OUT/pmc5_WRITE_SIZE
+# 6c. lbs() by batch size: the matrix-pipe route (round 5) against round 4's one-launch kernel and the three-launch route
+python $ROOT/scripts/time_lbs.py 1 8 16 30 240 2>&1 | grep "lbs()" > $OUT/${R}_lbs_by_batch.txt
 # 7. frames/s over (steps coalesced per call) x (calls in flight)
 cd $ROOT
 {
