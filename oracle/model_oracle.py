@@ -1,7 +1,10 @@
 """TEST INFRASTRUCTURE ONLY.  numpy restatement of the model around the hot path -- `PCAGarmentEncoderSeg.forward`
 (/root/reference/modules/mesh_encoder.py:127-169), `compute_vnorms` (utils/mesh_utils.py:116-134) and
 `PCALBSGarmentUseSegEncoderSeg.forward` (:412-487) -- composed from the pinned pointnet2 / lbs / gcn oracles.
-PARITY UNPINNED as a whole: mesh_encoder.py imports chamferdist / openmesh / torch_scatter, absent here."""
+Pinned in parts: compute_vnorms and the refinement loop + garment skinning (through refine_oracle) against the reference's own
+utils/mesh_utils.py and modules/mesh_encoder.py (tests/golden/refine.npz, make_golden_refine.py); the SA / FP / head stack against
+modules.npz.  NOT reference-run: PCAGarmentEncoderSeg.forward's wiring as a whole (its constructor needs the PCA pickle and the template
+OBJ, mesh_encoder.py:89-99) and calc_segmentation_results -- those follow the source text (:109-169)."""
 import numpy as np
 
 from . import modules_oracle as MO

@@ -1,9 +1,12 @@
 """numpy restatement of the garment-skinning / refinement code AROUND the hot path
 (/root/reference/modules/mesh_encoder.py:312-487).  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: modules/mesh_encoder.py cannot be imported here (needs chamferdist, openmesh, torch_scatter,
-dataset files), and `chamferdist.knn_points` itself is absent, so these follow the reference's source text and the
-published behaviour of pytorch3d's knn (squared L2, K smallest, ascending); tie order = lowest index first."""
+PINNED (round 5) against the reference's OWN modules/mesh_encoder.py, run in the build container with its absent third-party imports
+stubbed (tests/golden/make_golden_refine.py -> tests/golden/refine.npz; tests/test_oracle_golden.py checks lbs_garment_interpolation at
+K = 3 and 256, the adjacency of the constructor, and 1 / 3 refinement rounds to 1e-5).  What stays PARITY UNPINNED is `knn_points` alone:
+`chamferdist` (krrish94/chamferdist, unpinned in README.md:26) is absent from this image, so the K-nearest search follows the published
+behaviour of pytorch3d's knn (squared L2, K smallest, ascending) with tie order = lowest index first -- the same function is the stand-in
+inside the golden generator, i.e. the goldens pin everything AROUND the KNN, not the KNN."""
 import numpy as np
 
 F32 = np.float32
@@ -70,8 +73,8 @@ def lbs_garment_interpolation(garment_t, Tpose_vertices, Tpose_root_joints, zero
 
 # ---------------------------------------------------------------------------------------------------------------------
 # The refinement loop of PCALBSGarmentUseSegEncoderSeg.forward (/root/reference/modules/mesh_encoder.py:445-486),
-# restated with numpy on top of the pinned pointnet2 / gcn oracles.  PARITY UNPINNED as a whole (mesh_encoder.py imports
-# chamferdist / smplx and cannot be run here); its pieces (ball query, grouping, GCN layer) are the pinned ones.
+# restated with numpy on top of the pinned pointnet2 / gcn oracles; pinned as a whole by tests/golden/refine.npz (the reference's own
+# forward() run with a stub garment encoder: tests/golden/make_golden_refine.py).
 def _linear(x, w, b=None):
     y = x.astype(np.float32) @ w.T.astype(np.float32)
     return y if b is None else y + b.astype(np.float32)
