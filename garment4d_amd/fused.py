@@ -782,6 +782,21 @@ def sa_forward(sa, xyz, feats_pm=None, new_xyz=None, grid=None, idxs=None):
 # (NN_CELLS -> tuning.Tuning.nn_cells) three_nn scan over cell-ordered queries when the unknown cloud's ball grid exists
 
 
+# the block-pruned search pays from ~32 clouds of 8192 queries on (a pre-pass + 18 KB staged per 256 queries: 8 clouds 26 -> 59-77 us, 240 clouds
+# 380-390 -> 210-300 us); below, the plain scan over cell-ordered queries.  Identical output, so the threshold only moves time.
+_NN_PRUNE_MIN_QUERIES = 262144
+
+
+def three_nn_pruned(unknown, unknown_grid, known, dist2, nn_idx, sorted_out):
+    """g4d_three_nn_pruned_f32: exact block-pruned search (csrc/three_nn_prune.hip); unknown_grid = (workspace, rmax) or None."""
+    B, n = dist2.shape[0], dist2.shape[1]
+    m = known.shape[1]
+    nws = int(_lib.lib().g4d_three_nn_pruned_ws_bytes(B))
+    ws = torch.empty((max(nws, 16) + 3) // 4, dtype=torch.float32, device=known.device)   # sorted records + block boxes, 18 KB per cloud
+    _lib.call("g4d_three_nn_pruned_f32", B, n, m, _ptr(unknown), 0 if unknown_grid is None else unknown_grid[0].data_ptr(), known.data_ptr(),
+              dist2.data_ptr(), nn_idx.data_ptr(), int(bool(sorted_out)), ws.data_ptr(), nws, _lib.stream_ptr())
+
+
 def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=None):
     """Three nearest `known` (B,m,3) points of every `unknown` (B,n,3) point: (dist2 (B,n,3) squared, idx (B,n,3) int32).
     grid=None: the cell-grid search from m = Tuning.three_nn_grid_min_m on, the scan below; True / False force a route (identical output).
@@ -795,6 +810,9 @@ def three_nn(unknown, known, dist2=None, nn_idx=None, grid=None, unknown_grid=No
     if nn_idx is None:
         nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=dev)
     if _T().nn_cells and unknown_grid is not None and grid is None and n >= 4096 and 256 <= m < _T().three_nn_grid_min_m and B > 0:
+        if _T().nn_prune and _lib.lib().g4d_three_nn_pruned_supported(n, m) and B <= 65535 and B * n >= _NN_PRUNE_MIN_QUERIES:
+            three_nn_pruned(unknown, unknown_grid, known, dist2, nn_idx, sorted_out=False)
+            return dist2, nn_idx
         _lib.call("g4d_three_nn_cells_f32", B, n, m, unknown.data_ptr(), unknown_grid[0].data_ptr(), known.data_ptr(), dist2.data_ptr(),
                   nn_idx.data_ptr(), _lib.stream_ptr())
         return dist2, nn_idx
@@ -885,7 +903,10 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
     if cells:
         dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
         nn_idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
-        _lib.call("g4d_three_nn_cells_sorted_f32", B, n, m, unknown_grid[0].data_ptr(), known.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), stream)
+        if _T().nn_prune and _lib.lib().g4d_three_nn_pruned_supported(n, m) and B <= 65535 and B * n >= _NN_PRUNE_MIN_QUERIES:
+            three_nn_pruned(None, unknown_grid, known, dist2, nn_idx, sorted_out=True)
+        else:
+            _lib.call("g4d_three_nn_cells_sorted_f32", B, n, m, unknown_grid[0].data_ptr(), known.data_ptr(), dist2.data_ptr(), nn_idx.data_ptr(), stream)
     else:
         dist2, nn_idx = nn if nn is not None else three_nn(unknown, known, unknown_grid=unknown_grid)
 

@@ -57,6 +57,7 @@ class Tuning:
     three_nn_grid_min_m: int = 4096    # known sets at least this large search the cell grid
     nn_cells: bool = True              # three_nn scan over cell-ordered queries when the unknown cloud's ball grid exists
     nn_multi: bool = True              # the small three_nn searches of the inner FP levels in one launch
+    nn_prune: bool = True              # three_nn over <= 1024 known points: Morton blocks of 16 + exact box pruning (csrc/three_nn_prune.hip, round 5)
     # ---- set abstraction / feature propagation routes (fused.py)
     sa_xyz_pair: bool = True           # both xyz-only scales of a level in one launch
     use_sa_xyz: bool = True            # xyz-only 3-layer SA stacks on csrc/sa_xyz.hip
@@ -105,7 +106,7 @@ def from_environment() -> Tuning:
         lanes_sort=_env_flag("G4D_BQ_LANES_SORT", d.lanes_sort), coherent_lanes=_env_flag("G4D_BQ_LANES", d.coherent_lanes),
         grid_min_n=_env_int("G4D_BQ_GRID_MIN_N", d.grid_min_n), fps_pair=_env_flag("G4D_FPS_PAIR", d.fps_pair), bq_multi=_env_flag("G4D_BQ_MULTI", d.bq_multi),
         search_multi=_env_flag("G4D_SEARCH_MULTI", d.search_multi), three_nn_grid_min_m=_env_int("G4D_NN_GRID_MIN_M", d.three_nn_grid_min_m),
-        nn_cells=_env_flag("G4D_NN_CELLS", d.nn_cells), nn_multi=_env_flag("G4D_NN_MULTI", d.nn_multi), sa_xyz_pair=_env_flag("G4D_SA_XYZ_PAIR", d.sa_xyz_pair),
+        nn_cells=_env_flag("G4D_NN_CELLS", d.nn_cells), nn_multi=_env_flag("G4D_NN_MULTI", d.nn_multi), nn_prune=_env_flag("G4D_NN_PRUNE", d.nn_prune), sa_xyz_pair=_env_flag("G4D_SA_XYZ_PAIR", d.sa_xyz_pair),
         use_sa_xyz=_env_flag("G4D_SA_XYZ", d.use_sa_xyz), sa_xyz_table=_env_flag("G4D_SA_XYZ_TABLE", d.sa_xyz_table), sa_table=_env_flag("G4D_SA_TABLE", d.sa_table),
         fp_wide_fused=_env_flag("G4D_FP_WIDE_FUSED", d.fp_wide_fused), fp_cells=_env_flag("G4D_FP_CELLS", d.fp_cells), fp_table=_env_flag("G4D_FP_TABLE", d.fp_table),
         fp_gemm_bf16=_env_flag("G4D_FP_GEMM_BF16", d.fp_gemm_bf16), fp_gemm_bf16_min_rows=_env_int("G4D_FP_GEMM_BF16_MIN_ROWS", d.fp_gemm_bf16_min_rows),

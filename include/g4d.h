@@ -485,6 +485,18 @@ int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, const float 
  * are then spatial neighbours and the three table rows each of them gathers hit in L1 (interpolate_gpu.cu:77-117 + the first SharedMLP
  * layer of pointnet2_modules.py:127-156). */
 int g4d_three_nn_cells_sorted_f32(int b, int n, int m, const void *unknown_grid, const float *known, float *dist2, int *idx, g4d_stream_t stream);
+
+/* three_nn with exact block pruning (round 5; csrc/three_nn_prune.hip; replaces interpolate_gpu.cu:9-74 for well-spread known sets of up to
+ * 1024 points -- the last feature-propagation level).  A pre-pass Morton-sorts each cloud's known points into blocks of 16 with bounding
+ * boxes (workspace `ws`); a wave of 64 queries (cell order of `unknown_grid` when given, else index order of `unknown`) visits only the
+ * blocks whose box -- tested with the same fp32 distance expression, whose rounding is monotone -- can still hold one of some lane's three
+ * nearest, ties included; inserts order by (distance, original index).  Output identical to g4d_three_nn_f32 (sorted_out = 0) or to
+ * g4d_three_nn_cells_sorted_f32 (sorted_out != 0, needs unknown_grid) for any input.  16 <= m <= 1024, b <= 65535;
+ * ws >= g4d_three_nn_pruned_ws_bytes(b) bytes, 16-byte aligned, owned by the caller. */
+int g4d_three_nn_pruned_supported(int n, int m);
+long long g4d_three_nn_pruned_ws_bytes(int b);
+int g4d_three_nn_pruned_f32(int b, int n, int m, const float *unknown, const void *unknown_grid, const float *known, float *dist2, int *idx,
+                            int sorted_out, void *ws, long long ws_bytes, g4d_stream_t stream);
 int g4d_mlp_chain_table_cells_f32(long long rows, int n, int m, int C2, const float *table, const float *dist2, const int *nn_idx,
                                   const void *unknown_grid, const float *pre_scale, const float *pre_shift, float *in_tap, int in_tap_ld,
                                   int nlayers, const float *const *W, const float *const *scale, const float *const *shift, const int *Kpad,

@@ -1,33 +1,27 @@
-"""three_nn at the FP shapes of cfg2 and at config 4's interpenetration shape, scan vs cell grid, device time (hipGraph replay),
-on a volume cloud (unit_cloud) and a surface cloud (body_like_cloud, known = its FPS subset like the encoder's).
-python scripts/time_three_nn.py"""
+"""three_nn of the last FP level (B x 8192 <- 1024 FPS-selected known points): scan over cell-ordered queries vs the block-pruned search."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from garment4d_amd import _lib, fused, synthetic as syn, pointnet2_utils as PU
-def timeit(fn, n=20):
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        for _ in range(3): fn()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
-            for _ in range(n): fn()
-        g.replay(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-for name, B, n, m in (("unit", 8, 8192, 1024), ("body", 8, 8192, 1024), ("body", 8, 1024, 256), ("body", 30, 4096, 6890)):
-    gen = syn.unit_cloud if name == "unit" else (lambda B, N, seed: syn.body_like_cloud(B, N, seed=seed, dup_frac=0.0, zero_frac=0.0))
-    if m < n:
-        u = torch.from_numpy(gen(B, n, 1)).cuda()
-        k = PU.gather_operation(u.transpose(1, 2).contiguous(), PU.furthest_point_sample(u, m)).transpose(1, 2).contiguous()
-    else:
-        k = torch.from_numpy(gen(B, m, 1)).cuda(); u = (k[:, :n] * 1.02).contiguous()
-    d2 = torch.empty(B, n, 3, device="cuda"); ix = torch.empty(B, n, 3, dtype=torch.int32, device="cuda")
-    ws = torch.empty(_lib.lib().g4d_ball_grid_bytes(B, m), dtype=torch.uint8, device="cuda")
-    t0 = timeit(lambda: fused.three_nn(u, k, d2, ix, grid=False))
-    ref = (d2.clone(), ix.clone())
-    t1 = timeit(lambda: _lib.call("g4d_three_nn_grid_f32", B, n, m, u.data_ptr(), k.data_ptr(), d2.data_ptr(), ix.data_ptr(), ws.data_ptr(), _lib.stream_ptr()))
-    same = torch.equal(ref[0], d2) and torch.equal(ref[1], ix)
-    print(f"three_nn {name:5s} B={B:2d} {n}<-{m}: scan {t0:7.1f} us | grid (build + search) {t1:7.1f} us | identical={same}")
+import numpy as np, torch
+from garment4d_amd import fused, _lib, synthetic as syn, tuning
+
+def timeit(fn, it=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e3
+
+for B in [int(a) for a in sys.argv[1:]] or [8, 240]:
+    for kind in ("unit", "body"):
+        x = torch.from_numpy(syn.unit_cloud(B, 8192, seed=1) if kind == "unit" else syn.body_like_cloud(B, 8192, seed=1)).cuda()
+        known = fused.fps_gather(x, 1024)
+        grid = fused.build_ball_grid(x, 0.1)
+        res = {}
+        for prune in (False, True):
+            with tuning.use(tuning.current().replace(nn_prune=prune)):
+                t = timeit(lambda: fused.three_nn(x, known, unknown_grid=grid))
+                res[prune] = (t, fused.three_nn(x, known, unknown_grid=grid))
+        same = torch.equal(res[False][1][1], res[True][1][1]) and torch.equal(res[False][1][0], res[True][1][0])
+        print(f"B={B:4d} {kind:5s}: scan {res[False][0]:8.1f} us | pruned {res[True][0]:8.1f} us | identical={same}")

@@ -378,6 +378,56 @@ def test_three_nn_over_cell_ordered_queries_is_bit_exact(B, n, m, kind, contract
         np.testing.assert_array_equal(np.sqrt(host(d2)), wd)
 
 
+@pytest.mark.parametrize("B,n,m,kind", [(2, 8192, 1024, "fps"), (3, 5000, 1000, "rand"), (2, 4100, 333, "dup"), (2, 4500, 700, "nonfinite"), (2, 300, 16, "rand"),
+                                        (1, 8192, 1024, "body"), (2, 777, 17, "dup"), (1, 4096, 1024, "zeros")])
+def test_three_nn_block_pruned_search_is_bit_exact(B, n, m, kind, contraction_mode):
+    """g4d_three_nn_pruned_f32 (csrc/three_nn_prune.hip: Morton blocks of 16 known points, exact box pruning, (distance, index) inserts) against the
+    plain scan and the oracle, in index order, in the cell order of the unknown cloud's grid, and with the results left in cell order: FPS subsets
+    (the encoder's case), random sets, duplicates (ties everywhere: the index order must survive the spatial visiting order), non-finite coordinates,
+    a body-like cloud with zero padding, an all-zero known set, m not a multiple of 16."""
+    from garment4d_amd import fused, _lib
+    rng = np.random.default_rng(n + m)
+    u = syn.body_like_cloud(B, n, seed=n) if kind == "body" else syn.unit_cloud(B, n, seed=n)
+    if kind in ("fps", "body"):
+        k = np.stack([u[b][K.fps(u[b:b + 1], m)[0]] for b in range(B)])
+    elif kind == "dup":
+        k = np.repeat(u[:, :(m + 2) // 3], 3, axis=1)[:, :m].copy()
+    elif kind == "zeros":
+        k = np.zeros((B, m, 3), np.float32)
+    else:
+        k = rng.random((B, m, 3)).astype(np.float32)
+    if kind == "nonfinite":
+        u[0, 5] = np.nan; u[1, 7, 0] = np.inf; k[0, 3] = np.nan; k[1, 9, 2] = -np.inf; k[1, 200] = np.inf
+    ud, kd = dev(u), dev(np.ascontiguousarray(k))
+    assert _lib.lib().g4d_three_nn_pruned_supported(n, m)
+    nws = int(_lib.lib().g4d_three_nn_pruned_ws_bytes(B))
+    ws = torch.empty(nws // 4, dtype=torch.float32, device="cuda")
+    d2s, ixs = fused.three_nn(ud, kd, grid=False)                 # the plain scan (g4d_three_nn_f32)
+
+    def run(unknown, grid, sorted_out):
+        d2 = torch.full((B, n, 3), -7.0, device="cuda"); ix = torch.full((B, n, 3), -7, dtype=torch.int32, device="cuda")
+        _lib.call("g4d_three_nn_pruned_f32", B, n, m, 0 if unknown is None else unknown.data_ptr(), 0 if grid is None else grid[0].data_ptr(), kd.data_ptr(),
+                  d2.data_ptr(), ix.data_ptr(), int(sorted_out), ws.data_ptr(), nws, _lib.stream_ptr())
+        return d2, ix
+
+    def same(d2, ix, wd, wi):
+        assert torch.equal(ix, wi)
+        assert torch.equal(torch.nan_to_num(d2, nan=-1.0), torch.nan_to_num(wd, nan=-1.0))
+
+    same(*run(ud, None, 0), d2s, ixs)                             # queries in index order
+    if n >= 256:
+        grid = fused.build_ball_grid(ud, 0.2)
+        same(*run(ud, grid, 0), d2s, ixs)                         # queries in cell order, results scattered back
+        dc, ic = torch.full((B, n, 3), -7.0, device="cuda"), torch.full((B, n, 3), -7, dtype=torch.int32, device="cuda")
+        _lib.call("g4d_three_nn_cells_sorted_f32", B, n, m, grid[0].data_ptr(), kd.data_ptr(), dc.data_ptr(), ic.data_ptr(), _lib.stream_ptr())
+        same(*run(None, grid, 1), dc, ic)                         # results left in cell order
+    if kind != "nonfinite":
+        wd, wi = K.three_nn(u, np.ascontiguousarray(k))
+        assert np.array_equal(host(ixs), wi)
+    with pytest.raises(_lib.G4DError):
+        _lib.call("g4d_three_nn_pruned_f32", B, n, 2048, ud.data_ptr(), 0, kd.data_ptr(), d2s.data_ptr(), ixs.data_ptr(), 0, ws.data_ptr(), nws, _lib.stream_ptr())
+
+
 def test_three_nn_multi_equals_separate_searches(contraction_mode):
     """g4d_three_nn_multi_f32: several small problems of one batch in a single launch, each bit-identical to its own g4d_three_nn_f32."""
     from garment4d_amd import fused
