@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--coalesce", type=int, default=30, help="B = 8 steps gathered into one call of the executor (garment4d_amd/pipeline.py): 30 = the "
                                                               "reference's own fold of (8 clips, 30 frames) into one batch, modules/mesh_encoder.py:133")
-    ap.add_argument("--streams", type=int, default=4, help="calls in flight per GPU, each a captured hipGraph on its own stream (profiles/r04_coalesce_by_streams.txt)")
+    ap.add_argument("--streams", type=int, default=8, help="calls in flight per GPU, each a captured hipGraph on its own stream (profiles/r04_coalesce_by_streams.txt)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames per sample the CPU oracle is timed on with all cores")
