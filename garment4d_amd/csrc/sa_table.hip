@@ -373,7 +373,10 @@ static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
     constexpr int R = 16 * MT, G = S > R ? S / R : 1;
     const long long nunit = ((a.rows + R - 1) / R + G - 1) / G;
     const long long want = (nunit + 3) / 4;
-    const unsigned grid = (unsigned)(want < resident ? want : resident);
+    // (tuning key sa_table_oversub, default 1: more workgroups than fit an empty chip, each with fewer units -- the dispatcher then balances
+    //  them over whatever CUs other streams' launches leave free; A/B switch)
+    const long long cap = (long long)resident * (long long)tuning("sa_table_oversub", 1);
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL((sa_table_kernel<C, S, MT, WM>), dim3(grid), dim3(256), lds, st, a);
     return check_launch("g4d_sa_table");
 }

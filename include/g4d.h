@@ -342,7 +342,7 @@ int g4d_linear_interp_add_f32(long long rows, int n, int m, int K, int Kpad, int
                               int tab_ld, const float *dist2, const int *nn_idx, const float *scale, const float *shift, int relu, float *out, int ldo,
                               int col0, g4d_stream_t stream);
 
-/* Run-time tuning switches of the large-launch kernels.  Keys: "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "fp_table_persistent",
+/* Run-time tuning switches of the large-launch kernels.  Keys: "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "sa_table_oversub", "fp_table_persistent",
  * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "sa_group_bf16_persistent",
  * "sa_group_bf16_min_rows", "gemm_tile", "gemm_tile_min_rows", "gemm_tile_min_cout", "gemm_tile_min_kpad".  Resolution order, per launch, on the
  * launching host thread: the thread's override (g4d_tuning_set_thread) > the process-wide value (g4d_tuning_set) > the environment variable
