@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("G4D_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # (tests/test_golden_repro_cpu.py regenerates into a temp dir)
 
 from garment4d_amd import synthetic as syn  # noqa: E402
 from oracle import pointnet2_oracle as K  # noqa: E402
