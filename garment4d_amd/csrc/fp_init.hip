@@ -42,11 +42,17 @@ constexpr int K0 = C0 / 16, T1 = C1 / 16, T2 = C2 / 16, T3 = C3 / 16;   // 6 k-s
 constexpr int KSC = 2;                                                   // k-steps per staged chunk (one barrier per chunk)
 constexpr int STEPS = (K0 + T1 + T2) / KSC;                              // chunks of a tile: 3 (layer 1) + 8 (layer 2) + 4 (layer 3)
 constexpr int STAGE = KSC * 16 * 256;                                    // floats per stage buffer: the largest chunk (layer 1: 2 x 16 fragments)
+constexpr int kStageBytes = 2 * STAGE * (int)sizeof(float);               // the double buffer: dynamic shared memory (see the kernel)
 static_assert(K0 % KSC == 0 && T1 % KSC == 0 && T2 % KSC == 0, "whole chunks per layer");
 }
 
 __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_stage[2][STAGE];
+    // DYNAMIC shared memory on purpose (round 5): for a static __shared__ array the compiler knows that the L2 -> LDS copies and the fragment
+    // reads touch the same object and puts s_waitcnt vmcnt(0) between a chunk's copies and the first ds_read behind them -- the copy that was
+    // issued one chunk AHEAD was waited for at once, in every chunk (0.40 of the wave cycles parked).  The ordering that is needed is the
+    // explicit vmcnt(0) + barrier of stage_step().
+    extern __shared__ __attribute__((aligned(16))) float fp_init_smem[];
+    float (*s_stage)[STAGE] = reinterpret_cast<float (*)[STAGE]>(fp_init_smem);
     __shared__ __attribute__((aligned(16))) float s_sc1[C1], s_sh1[C1], s_sc2[C2], s_sh2[C2], s_sc3[C3], s_sh3[C3];
     const int tid = threadIdx.x;
     s_sc1[tid] = a.sc1[tid]; s_sh1[tid] = a.sh1[tid];
@@ -61,40 +67,59 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
     const int iters = (ntile - (int)blockIdx.x * 4 + nwaves - 1) / nwaves;   // the same for the four waves (barriers inside the loop)
     auto tile_of = [&](int it) { return min(wg + it * nwaves, ntile - 1); };
     auto live = [&](int it) { return wg + it * nwaves < ntile; };
-    unsigned lane16 = (unsigned)lane * 4u;   // opaque inside the tile loop: no hoisted copy-source addresses
+    const int lane16 = lane * 16;                    // byte offset of the lane's 16 bytes inside a 1 KB fragment
 
-    // a chunk's weight fragments (KSC k-steps x all channel tiles; fragment (kk, ct) at slot kk * nt + ct) into stage buffer chunk & 1:
+    // a chunk's weight fragments (KSC k-steps x all channel tiles; fragment (kk, ct) at slot kk * nt + ct) into one of the two stage buffers:
     // chunks 0..2 layer 1 (16 tiles), 3..10 layer 2 (8 tiles), 11..14 layer 3 (8 tiles).  One k-step per barrier measured no gain over the
     // register-chain kernel (449 vs 447 us): a 1k-cycle k-step does not cover the copy's L2 round trip, so every barrier waited for it.
-    auto stage_issue = [&](int abs_chunk) {          // abs_chunk counts the wave's chunks over all its tiles: STEPS is odd, the buffer parity flips per tile
-        float *dst = s_stage[abs_chunk & 1];
-        const int step = abs_chunk % STEPS;
+    //
+    // Round 5, three findings of reading the ISA (scripts/isa_events.py prints a kernel as runs of loads / waits / MFMAs):
+    //  * `step` (the chunk's index inside its tile) is now a compile-time constant at every call site and only the buffer parity is run-time
+    //    state.  With round 4's run-time `abs_chunk % STEPS` every chunk carried a dozen scalar selects and eight conditional branches around
+    //    its copies; the branches cut the tile loop into basic blocks, the compiler sank the blends of the next tile's first table rows into the
+    //    loop latch and kept the RAW rows alive instead -- 74 dwords of scratch, each spill store right behind its gather with s_waitcnt
+    //    vmcnt(0) in between: the gathers this kernel exists to hide were waited for one by one.
+    //  * the copies are MUBUF (buffer_load ... lds), not global_load_lds: a FLAT-encoded instruction with an LDS operand marks the wave's
+    //    counters "flat pending" in the compiler's scoreboard and EVERY later vmcnt wait becomes vmcnt(0) -- the table gathers could not stay
+    //    in flight past a copy.  With MUBUF copies the waits carry exact counts.
+    //  * the stage buffers are dynamic shared memory (see above).
+    const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W1), 0, C0 * C1 * 4, 0x00020000),
+                                 rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W2), 0, C1 * C2 * 4, 0x00020000),
+                                 rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W3), 0, C2 * C3 * 4, 0x00020000);
+    auto stage_issue = [&](int buf, int step) {
+        float *dst = s_stage[buf];
         constexpr int c1 = K0 / KSC, c2 = c1 + T1 / KSC;
-        const float *w = step < c1 ? a.W1 : (step < c2 ? a.W2 : a.W3);
         const int nt = step < c1 ? T1 : (step < c2 ? T2 : T3), kst = step < c1 ? K0 : (step < c2 ? T1 : T2);
         const int ks0 = (step < c1 ? step : (step < c2 ? step - c1 : step - c2)) * KSC;
-        unsigned l16 = lane16;
-        asm volatile("" : "+v"(l16));   // opaque HERE: otherwise the copy-source addresses of all chunks are formed at the top of the tile and kept
 #pragma unroll
         for (int j = 0; j < KSC * 4; ++j) {
-            const int slot = wave + 4 * j;           // this wave's fragments: slots wave, wave + 4, ...
-            if (slot < KSC * nt) {
+            if (j < KSC * nt / 4) {                  // this wave's fragments: slots wave, wave + 4, ...
+                const int slot = wave + 4 * j;
                 const int kk = slot / nt, ct = slot - kk * nt;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w + (ct * kst + ks0 + kk) * 256 + l16),
-                                                 (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, 0, 0);
+                const int soff = (ct * kst + ks0 + kk) * 1024;
+                __attribute__((address_space(3))) void *d = (__attribute__((address_space(3))) void *)(dst + slot * 256);
+                if (step < c1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, d, 16, lane16, soff, 0, 0);
+                else if (step < c2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, d, 16, lane16, soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW3, d, 16, lane16, soff, 0, 0);
             }
         }
     };
-    auto stage_step = [&](int step) {   // this wave's share has landed, everybody's has, nobody reads the other buffer any more; next copy goes out
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        stage_issue(step + 1);
+    int par0 = 0;                                    // stage buffer of the current tile's first chunk (STEPS is odd: it flips per tile)
+    static_assert(STEPS % 2 == 1, "buffer parity flips per tile");
+    // chunk c of the tile: this wave's share has landed, everybody's has, nobody reads the other buffer any more; chunk c + 1 (the next tile's
+    // first chunk after the last one) goes out.  `younger` = the vector-memory instructions this wave issued AFTER chunk c's copies (vmcnt
+    // counts in issue order on gfx9): they may stay in flight across the barrier.  Only the chunk boundaries INSIDE layer 2 use it -- there the
+    // only younger instructions are the unconditional table gathers of the last two k-steps.
+    auto stage_step = [&](int c, int younger) {
+        if (younger == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        stage_issue(par0 ^ ((c + 1) & 1), (c + 1) % STEPS);
     };
     // fragment (global k-step gks of the tile, channel tile ct) of a layer with nt tiles
-    int chunk0 = 0;                                  // abs_chunk of the current tile's first chunk
     auto sfrag = [&](int gks, int nt, int ct) -> f32x4 {
-        return *reinterpret_cast<const f32x4 *>(&s_stage[(chunk0 + gks / KSC) & 1][(((gks % KSC) * nt + ct) * 64 + lane) * 4]);
+        return *reinterpret_cast<const f32x4 *>(&s_stage[par0 ^ ((gks / KSC) & 1)][(((gks % KSC) * nt + ct) * 64 + lane) * 4]);
     };
-    auto stage_at = [&](int gks) { if (gks % KSC == 0) stage_step(chunk0 + gks / KSC); };
+    auto stage_at = [&](int gks, int younger = 0) { if (gks % KSC == 0) stage_step(gks / KSC, younger); };
 
     struct Raw { int i0, i1, i2; float d0, d1, d2; };
     auto load_raw = [&](int tile) {
@@ -144,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
     // ReLU or not as the floor of one v_max (no select per element): exact for every finite / infinite input
     float lo1 = a.relu1 ? 0.f : -__builtin_inff(), lo2 = a.relu2 ? 0.f : -__builtin_inff(), lo3 = a.relu3 ? 0.f : -__builtin_inff();
     asm volatile("" : "+v"(lo1), "+v"(lo2), "+v"(lo3));   // (opaque: the compiler otherwise turns each max back into max + select)
-    stage_issue(0);
+    stage_issue(0, 0);
     Raw rawn = load_raw(tile_of(0));
     Ctx cur = make(tile_of(0), rawn);
     Skip sk = load_skip(tile_of(0));
@@ -164,8 +189,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
     }
     for (int it = 0; it < iters; ++it) {
         const int tile = tile_of(it);
-        asm volatile("" : "+v"(lane16));
-        chunk0 = it * STEPS;
+        par0 = it & 1;
         const bool row_ok = tile * 16 + fi < a.rows && live(it);
         // ---- layer 1: the skip columns on the matrix pipe, transposed (A = weights, B = the skip row's 16 columns of the k-step)
         f32x4 sring[2];
@@ -198,17 +222,19 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
         Ctx nxt;
         Skip skn;
         f32x4 h1n[T1];
-        Item item;
+        Item item[2];                                // the table rows of k-steps ks - 2 / ks - 1: two k-steps (2k matrix-pipe cycles) of cover per gather
 #pragma unroll
         for (int ks = 0; ks < T1; ++ks) {
-            stage_at(K0 + ks);
-            if (ks == 0) {
+            if (ks == 0) {                           // (ahead of the barrier's copies: older than them in the wave's memory queue)
                 nxt = make(tile_of(it + 1), rawn);
                 rawn = load_raw(tile_of(it + 2));
-            } else {
-                h1n[ks - 1] = blend(nxt, item);
             }
-            item = load_item(nxt, ks);
+            stage_at(K0 + ks, ks >= 2 ? 6 : 0);
+            if (ks >= 2) {
+                h1n[ks - 2] = blend(nxt, item[ks & 1]);
+                asm volatile("" : "+v"(h1n[ks - 2]));   // the blend happens HERE (not sunk towards the loop latch with the raw rows kept alive)
+            }
+            item[ks & 1] = load_item(nxt, ks);
             sring[0] = sfrag(K0 + ks, T2, 0); sring[1] = sfrag(K0 + ks, T2, 1);
 #pragma unroll
             for (int ct = 0; ct < T2; ++ct) {
@@ -237,7 +263,11 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
 #pragma unroll
         for (int ks = 0; ks < T2; ++ks) {
             stage_at(K0 + T1 + ks);
-            if (ks == 0) { h1n[T1 - 1] = blend(nxt, item); skn = load_skip(tile_of(it + 1)); }
+            if (ks == 0) {
+                h1n[T1 - 2] = blend(nxt, item[0]); h1n[T1 - 1] = blend(nxt, item[1]);
+                asm volatile("" : "+v"(h1n[T1 - 2]), "+v"(h1n[T1 - 1]));
+                skn = load_skip(tile_of(it + 1));
+            }
             sring[0] = sfrag(K0 + T1 + ks, T3, 0); sring[1] = sfrag(K0 + T1 + ks, T3, 1);
 #pragma unroll
             for (int ct = 0; ct < T3; ++ct) {
@@ -290,14 +320,16 @@ int g4d::fp_init_try(long long rows, int n, int m, int C1_, const float *skip, c
     a.W1 = W[0]; a.sc1 = scale[0]; a.sh1 = shift[0]; a.W2 = W[1]; a.sc2 = scale[1]; a.sh2 = shift[1]; a.W3 = W[2]; a.sc3 = scale[2]; a.sh3 = shift[2];
     a.relu1 = relu[0]; a.relu2 = relu[1]; a.relu3 = relu[2];
     a.out = out; a.ldo = ldo; a.tap = tap_out; a.tap_ld = tap_ld;
+    static unsigned long long attr = 0;
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(fp_init_kernel), kStageBytes, attr, "g4d_fp_init")) return rc;
     static const int resident = [] {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fp_init_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fp_init_kernel, 256, kStageBytes) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return per_cu * 256;
         return per_cu * prop.multiProcessorCount;
     }();
     const long long want = ((rows + 15) / 16 + 3) / 4;
-    hipLaunchKernelGGL(fp_init_kernel, dim3((unsigned)(want < resident ? want : resident)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(fp_init_kernel, dim3((unsigned)(want < resident ? want : resident)), dim3(256), kStageBytes, st, a);
     return check_launch("g4d_fp_init");
 }

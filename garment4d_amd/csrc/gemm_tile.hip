@@ -14,9 +14,11 @@
 namespace g4d {
 
 namespace {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 128, TN = 128, TK = 32, TLD = TK + 4;   // LDS row stride 36 floats: ds_read_b128 fragment reads spread over all banks
 }
 
+template <bool FULLK>   // FULLK: K == Kpad (no zero-filled tail columns): the loads carry no predicate at all
 __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, int nrow_blk, int ncol_blk, int cpad) {
     extern __shared__ __attribute__((aligned(16))) float g_smem[];
     float *sA = g_smem;                         // [2][TM * TLD]
@@ -43,10 +45,17 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
     // K and ldx are multiples of 4 and X is 16-byte aligned (launcher): a lane's four columns are all inside the row or all past its end.
     // Branch-free on purpose: a load inside a conditional block makes the number of loads in flight unknown at the join and the compiler
     // then waits for the prefetch of the NEXT chunk (vmcnt(0)) in front of this chunk's MFMAs.
+    // (round 5: written as `in ? v : 0` the compiler turned the select into a load under an exec mask -- four conditional blocks per chunk,
+    //  each followed by s_waitcnt vmcnt(3): the eight prefetches of a chunk went out in three round trips instead of one.  The tail columns
+    //  are now cleared with a bit mask, and launches whose K is a whole number of chunks -- every GEMM of the benched path -- have no
+    //  predicate.)
     auto load_x = [&](int p, int k) -> f32x4 {
+        if constexpr (FULLK) return *reinterpret_cast<const f32x4 *>(xrow[p] + k);
         const bool in = k + lk < a.K;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow[p] + (in ? k : 0));
-        return in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(xrow[p] + (in ? k : 0));
+        const unsigned m = in ? 0xffffffffu : 0u;
+        const u32x4 r = {v[0] & m, v[1] & m, v[2] & m, v[3] & m};
+        return __builtin_bit_cast(f32x4, r);
     };
     f32x4 acc[4][4];
 #pragma unroll
@@ -146,14 +155,16 @@ bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
     if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < (a.tab ? 128 : min_kpad) || a.Cout < min_cout || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
     if (a.tab && ((a.tab_ld & 3) || (reinterpret_cast<size_t>(a.tab) & 15))) return false;
     const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
-    static unsigned long long attr = 0;
-    *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_tile_kernel), lds, attr, "g4d_linear_f32(tile)");
+    const bool fullk = a.K == a.Kpad;
+    static unsigned long long attr[2] = {0, 0};
+    *rc = ensure_dynamic_lds(fullk ? reinterpret_cast<const void *>(gemm_tile_kernel<true>) : reinterpret_cast<const void *>(gemm_tile_kernel<false>), lds, attr[fullk], "g4d_linear_f32(tile)");
     if (*rc) return true;
     const int cpad = (a.Cout + 63) / 64 * 64;   // the packed weight / scale / shift are padded to 64 channels
     const int nrow = (a.rows + TM - 1) / TM, ncol = (a.Cout + TN - 1) / TN;
     const long long blocks = (long long)((nrow + 7) / 8) * 8 * ncol;   // XCD-major numbering: row blocks rounded up to a multiple of 8
     if (blocks >= (1ll << 31)) return false;
-    hipLaunchKernelGGL(gemm_tile_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
+    if (fullk) hipLaunchKernelGGL(gemm_tile_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
+    else hipLaunchKernelGGL(gemm_tile_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
     *rc = check_launch("g4d_linear_f32(tile)");
     return true;
 }

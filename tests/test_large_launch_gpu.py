@@ -73,12 +73,16 @@ def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, tu
     np.testing.assert_allclose(fused.to_channel_major(outs[1][0]).cpu().numpy(), feats.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("rows,K,Cout,relu,col0,extra", [(4096, 576, 512, True, 0, 0), (5001, 512, 256, True, 0, 0), (4100, 256, 384, False, 3, 9), (3000, 260, 256, True, 0, 0)])
-def test_tile_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra):
+@pytest.mark.parametrize("rows,K,Cout,relu,col0,extra,xpad", [(4096, 576, 512, True, 0, 0, 0), (5001, 512, 256, True, 0, 0, 0), (4100, 256, 384, False, 3, 9, 0),
+                                                              (3000, 260, 256, True, 0, 0, 0), (3000, 260, 256, True, 0, 0, 40), (2500, 132, 128, False, 0, 0, 4)])
+def test_tile_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra, xpad):
     """csrc/gemm_tile.hip against linear_kernel: the same k order, so EQUAL; row counts that are not a multiple of 128, an output window inside
-    a wider matrix, K = 260 (Kpad = 288: the last chunk is mostly padding)."""
+    a wider matrix, K = 260 (Kpad = 288: the last chunk is mostly padding), and an input that is a window of a wider matrix whose other
+    columns hold NaN (the chunk tail must be cleared, not multiplied by zero weights)."""
     g = torch.Generator().manual_seed(rows % 97)
     x = torch.randn(rows, K, generator=g).cuda()
+    if xpad:
+        x = torch.cat([x, torch.full((rows, xpad), float("nan"), device="cuda")], dim=1)
     W = (torch.randn(Cout, K, generator=g) / K ** 0.5).cuda()
     sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
     layer = fused.PackedLayer(W, sc, sh, relu=relu)
@@ -89,7 +93,7 @@ def test_tile_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra):
             fused.linear(x, layer, out=outs[on], col0=col0)
     assert torch.equal(outs[0], outs[1])
     assert (outs[1][:, :col0] == 7.0).all() and (outs[1][:, col0 + Cout:] == 7.0).all()
-    ref = (x.double() @ W.double().T) * sc.double() + sh.double()
+    ref = (x[:, :K].double() @ W.double().T) * sc.double() + sh.double()
     ref = torch.relu(ref) if relu else ref
     torch.testing.assert_close(outs[1][:, col0:col0 + Cout].double(), ref, rtol=1e-5, atol=1e-5)
 
