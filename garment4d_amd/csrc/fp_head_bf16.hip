@@ -52,6 +52,9 @@ struct FpHeadHArgs {
     size_t perm_stride;                   // bytes per cloud
 };
 
+// PERM: cell-ordered launch.  A template flag (round 5): as a run-time branch around the record load the number of loads in flight was unknown
+// at the join and every tile started with s_waitcnt vmcnt(0) behind the loads it had just issued (see fp_table.hip).
+template <bool PERM>
 __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short s_w1[NW1], s_w2[NW2], s_w3[NW3], s_w4[NW4];
     __shared__ __attribute__((aligned(16))) float s_sc1[D1], s_sh1[D1], s_sc2[D2], s_sh2[D2], s_sc3[D3], s_sh3[D3], s_sc4[D4], s_sh4[D4];
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
     if (tid < D4) { s_sc4[tid] = a.sc4[tid]; s_sh4[tid] = a.sh4[tid]; }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: tile and cloud numbers on the scalar unit)
     const int fi = lane & 15, g = lane >> 4;
     const int ntile = (a.rows + 15) >> 4;
     const int nwaves = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(256) fp_head_bf16_kernel(const FpHeadHArgs a) 
     // Every row is computed from its own operands only, so the order changes no bit of any output.
     auto load_orow = [&](int tile) -> int {
         const int row = min(tile * 16 + fi, a.rows - 1);
-        if (!a.perm_rec) return row;
+        if constexpr (!PERM) return row;
         const int b = row / a.n;
         return b * a.n + reinterpret_cast<const int *>(a.perm_rec + (size_t)b * a.perm_stride)[4 * (row - b * a.n) + 3];
     };
@@ -249,14 +252,17 @@ int g4d::fp_head_bf16_try(long long rows, int n, int m, int C2, int C1, const fl
     a.relu1 = relu[0]; a.relu2 = relu[1]; a.relu3 = relu[2]; a.relu4 = relu[3]; a.cout4 = Cout[3];
     a.out = out; a.ldo = ldo; a.tap = tap_out; a.tap_ld = tap_ld;
     a.perm_rec = reinterpret_cast<const unsigned char *>(perm_rec); a.perm_stride = perm_stride;
-    static const int resident = [] {
+    typedef void (*Kern)(const FpHeadHArgs);
+    const Kern kern = perm_rec ? fp_head_bf16_kernel<true> : fp_head_bf16_kernel<false>;
+    static int resident[2] = {0, 0};
+    int &res = resident[perm_rec ? 1 : 0];
+    if (res == 0) {   // (benign race: every thread computes the same value)
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fp_head_bf16_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return per_cu * 256;
-        return per_cu * prop.multiProcessorCount;
-    }();
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        res = (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) ? per_cu * 256 : per_cu * prop.multiProcessorCount;
+    }
     const long long want = ((rows + 15) / 16 + 3) / 4;
-    hipLaunchKernelGGL(fp_head_bf16_kernel, dim3((unsigned)(want < resident ? want : resident)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(want < res ? want : res)), dim3(256), 0, st, a);
     return check_launch("g4d_fp_head_bf16");
 }

@@ -38,9 +38,13 @@ struct FpTabArgs {
 
 constexpr int kC1 = 128, kC2 = 64, kC3 = 32, kC4 = 16;
 constexpr int kT1 = kC1 / 16, kT2 = kC2 / 16, kT3 = kC3 / 16;
-constexpr int kD = 2;   // table k-steps in flight ahead of the one being contracted
-
-__global__ void __launch_bounds__(256) fp_table_head_kernel(const FpTabArgs a) {
+// kD: table k-steps in flight ahead of the one being contracted (a divisor of kT1: the ring runs across the tile boundary).
+// PERM: cell-ordered launch (the rows' original positions come from the grid records).  A template flag since round 5: as a run-time
+// branch around one load it made the number of loads in flight unknown at the join, and the compiler answered with s_waitcnt vmcnt(0) at the
+// top of EVERY tile -- behind the loads it had just issued, draining the whole ring.
+template <bool PERM, int kD>
+__global__ void __launch_bounds__(256, kD <= 4 ? 3 : 2) fp_table_head_kernel(const FpTabArgs a) {
+    static_assert(kT1 % kD == 0, "ring depth divides the k-steps of a tile");
     constexpr int NW2 = kC1 * kC2, NW3 = kC2 * kC3, NW4 = kC3 * kC4;
     __shared__ __attribute__((aligned(16))) float s_w2[NW2], s_w3[NW3], s_w4[NW4];
     __shared__ __attribute__((aligned(16))) float s_ps[kC1], s_pf[kC1], s_sc2[kC2], s_sh2[kC2], s_sc3[kC3], s_sh3[kC3], s_sc4[kC4], s_sh4[kC4];
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(256) fp_table_head_kernel(const FpTabArgs a) {
     if (tid < kC4) { s_sc4[tid] = a.sc4[tid]; s_sh4[tid] = a.sh4[tid]; }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: tile numbers, cloud numbers and their divisions run on the scalar unit)
     const int fi = lane & 15, fq = lane >> 4;
     const int ntile = (a.rows + 15) >> 4;
     const int nwaves = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(256) fp_table_head_kernel(const FpTabArgs a) {
         const int b0 = __builtin_amdgcn_readfirstlane((tile * 16) / a.n);   // a tile touches at most two clouds (n >= 16)
         const int b = b0 + (row >= (b0 + 1) * a.n ? 1 : 0);
         r.orow = row;
-        if (a.perm_rec) r.orow = b * a.n + reinterpret_cast<const int *>(a.perm_rec + (size_t)b * a.perm_stride)[4 * (row - b * a.n) + 3];
+        if constexpr (PERM) r.orow = b * a.n + reinterpret_cast<const int *>(a.perm_rec + (size_t)b * a.perm_stride)[4 * (row - b * a.n) + 3];
         return r;
     };
     // level 2: interpolation weights (pointnet2_utils.py:98 sqrt; pointnet2_modules.py:140-142) and the rows' offsets in the table
@@ -215,14 +219,18 @@ int g4d::fp_table_try(long long rows, int n, int m, int C2, const float *table, 
     a.ps = pre_scale; a.pf = pre_shift;
     a.W2 = W[0]; a.sc2 = scale[0]; a.sh2 = shift[0]; a.W3 = W[1]; a.sc3 = scale[1]; a.sh3 = shift[1]; a.W4 = W[2]; a.sc4 = scale[2]; a.sh4 = shift[2];
     a.cout4 = Cout[2]; a.relu4 = relu[2]; a.out = out; a.ldo = ldo; a.tap = tap_out; a.tap_ld = tap_ld;
-    static const int resident = [] {
+    // ring depth 2 (measured at 240 clouds, 1.97 M rows: 2 k-steps ahead 422 us, 4: 436-440, 8: 448 -- the deeper rings only add registers)
+    typedef void (*Kern)(const FpTabArgs);
+    const Kern kern = perm_rec ? fp_table_head_kernel<true, 2> : fp_table_head_kernel<false, 2>;
+    static int resident[2] = {0, 0};
+    int &res = resident[perm_rec ? 1 : 0];
+    if (res == 0) {   // (benign race: every thread computes the same value)
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fp_table_head_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return per_cu * 256;
-        return per_cu * prop.multiProcessorCount;
-    }();
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        res = (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) ? per_cu * 256 : per_cu * prop.multiProcessorCount;
+    }
     const long long want = ((rows + 15) / 16 + 3) / 4;
-    hipLaunchKernelGGL(fp_table_head_kernel, dim3((unsigned)(want < resident ? want : resident)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(want < res ? want : res)), dim3(256), 0, st, a);
     return check_launch("g4d_fp_table_head");
 }

@@ -18,7 +18,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 128, TN = 128, TK = 32, TLD = TK + 4;   // LDS row stride 36 floats: ds_read_b128 fragment reads spread over all banks
 }
 
-template <bool FULLK>   // FULLK: K == Kpad (no zero-filled tail columns): the loads carry no predicate at all
+// FULLK: K == Kpad (no zero-filled tail columns): the loads carry no predicate at all.  TAB: g4d_linear_interp_add_f32 -- the rows'
+// interpolation contexts (index / distance loads, three divisions) are formed BEFORE the contraction and only the table rows themselves are
+// fetched in the epilogue (round 5: with K = 192 the epilogue's dependent loads were a sixth of the launch).
+template <bool FULLK, bool TAB>
 __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, int nrow_blk, int ncol_blk, int cpad) {
     extern __shared__ __attribute__((aligned(16))) float g_smem[];
     float *sA = g_smem;                         // [2][TM * TLD]
@@ -62,6 +65,11 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    InterpRow ctx[4] = {};
+    if constexpr (TAB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ctx[i] = interp_row(a, min(row0 + (wave >> 1) * 64 + i * 16 + (lane & 15), a.rows - 1));
+    }
     const int nchunk = a.Kpad / TK;
     f32x4 ra[4], rb4[4];
 #pragma unroll
@@ -112,16 +120,14 @@ __global__ void __launch_bounds__(256, 2) gemm_tile_kernel(const LinearArgs a, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + wr * 64 + i * 16 + fi;
-        const int rowc = min(row, a.rows - 1);
-        InterpRow c = {};
-        if (a.tab) c = interp_row(a, rowc);   // + three_interpolate(tab) of the row (g4d_linear_interp_add_f32): as linear_kernel, added to the finished contraction
+        const InterpRow c = ctx[i];   // + three_interpolate(tab) of the row (g4d_linear_interp_add_f32): as linear_kernel, added to the finished contraction
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ch0 = n0 + wc * 64 + j * 16 + fq * 4;
             const int chc = min(ch0, cpad - 4);            // the packed scale / shift are padded to 64 channels
             const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + chc), sh = *reinterpret_cast<const f32x4 *>(a.shift + chc);
             f32x4 y = acc[i][j];
-            if (a.tab) {   // (the launcher guarantees Cout % 128 == 0, tab_ld % 4 == 0 and a 16-byte aligned table: whole 16-byte groups inside the row)
+            if constexpr (TAB) {   // (the launcher guarantees Cout % 128 == 0, tab_ld % 4 == 0 and a 16-byte aligned table: whole 16-byte groups inside the row)
                 const f32x4 t0 = *reinterpret_cast<const f32x4 *>(a.tab + c.k0 + ch0), t1 = *reinterpret_cast<const f32x4 *>(a.tab + c.k1 + ch0),
                             t2 = *reinterpret_cast<const f32x4 *>(a.tab + c.k2 + ch0);
 #pragma unroll
@@ -155,16 +161,17 @@ bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc) {
     if (!enabled || a.pool != 0 || a.rows < min_rows || a.Kpad < (a.tab ? 128 : min_kpad) || a.Cout < min_cout || a.Cout % TN != 0 || (a.K & 3) || (a.ldx & 3) || (reinterpret_cast<size_t>(a.X) & 15)) return false;
     if (a.tab && ((a.tab_ld & 3) || (reinterpret_cast<size_t>(a.tab) & 15))) return false;
     const int lds = 2 * (TM + TN) * TLD * (int)sizeof(float);   // 73728 bytes: two workgroups per CU
-    const bool fullk = a.K == a.Kpad;
-    static unsigned long long attr[2] = {0, 0};
-    *rc = ensure_dynamic_lds(fullk ? reinterpret_cast<const void *>(gemm_tile_kernel<true>) : reinterpret_cast<const void *>(gemm_tile_kernel<false>), lds, attr[fullk], "g4d_linear_f32(tile)");
+    typedef void (*Kern)(const LinearArgs, int, int, int);
+    static const Kern kerns[4] = {gemm_tile_kernel<false, false>, gemm_tile_kernel<false, true>, gemm_tile_kernel<true, false>, gemm_tile_kernel<true, true>};
+    const int which = (a.K == a.Kpad ? 2 : 0) + (a.tab ? 1 : 0);
+    static unsigned long long attr[4] = {0, 0, 0, 0};
+    *rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kerns[which]), lds, attr[which], "g4d_linear_f32(tile)");
     if (*rc) return true;
     const int cpad = (a.Cout + 63) / 64 * 64;   // the packed weight / scale / shift are padded to 64 channels
     const int nrow = (a.rows + TM - 1) / TM, ncol = (a.Cout + TN - 1) / TN;
     const long long blocks = (long long)((nrow + 7) / 8) * 8 * ncol;   // XCD-major numbering: row blocks rounded up to a multiple of 8
     if (blocks >= (1ll << 31)) return false;
-    if (fullk) hipLaunchKernelGGL(gemm_tile_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
-    else hipLaunchKernelGGL(gemm_tile_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
+    hipLaunchKernelGGL(kerns[which], dim3((unsigned)blocks), dim3(256), lds, s, a, nrow, ncol, cpad);
     *rc = check_launch("g4d_linear_f32(tile)");
     return true;
 }

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: block numbers, copy sources and destinations on the scalar unit)
     const int fi = lane & 15, fq = lane >> 4;
     const int nblk = (a.rows + R - 1) / R;           // 16 MT-row blocks of the launch
     const int nunit = (nblk + G - 1) / G;            // a wave's unit of work: G consecutive blocks = whole neighbourhoods
