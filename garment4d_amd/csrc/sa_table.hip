@@ -142,26 +142,29 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
     if (iters == 0) return;
     // kStageK k-steps' fragments (a chunk) into the stage buffer `chunk & 1`: chunks 0 .. T/kStageK-1 are layer 2's, the rest layer 3's; periodic
     // per block (an even number of chunks).  Fragment (kk, ct) of a chunk sits at slot kk * (tiles of the layer) + ct.
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W2), 0, C * C * 4, 0x00020000),
+                                 rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W3), 0, 2 * C * C * 4, 0x00020000);
     auto stage_issue = [&](int chunk) {
         if constexpr (WM == 2) {
             constexpr int NC2 = T / kStageK, NCH = 2 * NC2;
             chunk = chunk % NCH;
             float *dst = s_stage + (chunk & 1) * (kStageK * T3 * 256);
-            unsigned l16 = lane16;
-            asm volatile("" : "+v"(l16));   // opaque here: otherwise the copy-source addresses of every chunk are formed at the top of the block and kept
+            // MUBUF copies (round 5; fp_init.hip has the story): a FLAT-encoded global_load_lds marks the wave "flat pending" in the compiler's
+            // counter model and every later wait -- for a gathered row, for a ds_read -- becomes vmcnt(0) lgkmcnt(0), i.e. waits for the copy too.
+            const int l16b = lane * 16;
             if (chunk < NC2) {
 #pragma unroll
                 for (int j = 0; j < kStageK * T / 4; ++j) {
                     const int slot = wave + 4 * j, kk = slot / T, ct = slot % T;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W2 + (ct * T + chunk * kStageK + kk) * 256 + l16),
-                                                     (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, l16b,
+                                                             (ct * T + chunk * kStageK + kk) * 1024, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < kStageK * T3 / 4; ++j) {
                     const int slot = wave + 4 * j, kk = slot / T3, ct = slot % T3;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.W3 + (ct * T + (chunk - NC2) * kStageK + kk) * 256 + l16),
-                                                     (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW3, (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, l16b,
+                                                             (ct * T + (chunk - NC2) * kStageK + kk) * 1024, 0, 0);
                 }
             }
         }
