@@ -103,7 +103,6 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
     // the VALU / MFMA, the coordinates of pass k + 1 are in flight and so are the indices of pass k + 2.
     struct Rows { F3s px[2], pq[2]; };
     int ivn[2];
-    Rows cur, nxt;
     auto load_idx = [&](int pass, int (&v)[2]) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) v[mt] = a.idx[min(min(pass, npass - 1) * 32 + mt * 16 + fi, rows - 1)];   // unconditional (see load_rows)
@@ -122,13 +121,17 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
             rw.pq[mt] = ld3(a.new_xyz, (unsigned)qi * 3u);
         }
     };
-    int pass = first;
-    load_idx(pass, ivn);
-    load_rows(pass, ivn, cur);
-    load_idx(pass + stride, ivn);
-    for (; pass < npass; pass += stride) {
-        load_rows(pass + stride, ivn, nxt);       // level 2 of the next pass
+    // One pass: rows `use` (requested a pass ago) through the three layers while the next pass's rows arrive in `fill` and the indices of the
+    // one after in ivn.  Round 5: the loop below runs passes in PAIRS with the two row buffers swapping roles, instead of `cur = nxt` at the end
+    // of a pass -- the copy (and the register shuffles the allocator hung on it) needed the prefetched rows right behind the loads that
+    // fetched them, so every pass began by waiting for its own prefetch (s_waitcnt vmcnt(3) / vmcnt(2) five instructions after the loads).
+    // `alive` (uniform): false for the second pass of the last pair when the wave has an odd number of passes -- computed on clamped rows,
+    // nothing stored.
+    auto do_pass = [&](int pass, const Rows &cur, Rows &fill, bool alive) {
+        load_rows(pass + stride, ivn, fill);      // level 2 of the next pass
         load_idx(pass + 2 * stride, ivn);         // level 1 of the one after
+        // (without this fence the machine scheduler sinks both prefetches to the BOTTOM of the pass: ~15 MFMAs of cover)
+        __builtin_amdgcn_sched_barrier(0);
         const int row0 = pass * 32;
         // ---- layer 1 on the VALU, in operand layout
         f32x4 h1[2][T1];
@@ -143,7 +146,6 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
                     h1[mt][ks][e] = fmaxf(__builtin_fmaf(acc, s1[ks][e], h1s[ks][e]), 0.f);
                 }
         }
-        cur = nxt;
         // ---- layer 2, transposed: D[out channel 4 fq + r][row fi]
         f32x4 h2[2][T2];
 #pragma unroll
@@ -198,21 +200,22 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
                 for (int ct = 0; ct < T3; ++ct) x[ct] = fmaxf(v[0][ct], v[1][ct]);
                 float *o = a.out + (size_t)pass * a.ldo + a.col0;
                 if constexpr (T3 == 4) {
-                    o[lane] = fmaxf(pool4_rows_max(x[0], x[1], x[2], x[3]), 0.f);                       // lane = channel: one 256-byte store
+                    const float m = fmaxf(pool4_rows_max(x[0], x[1], x[2], x[3]), 0.f);
+                    if (alive) o[lane] = m;                                                             // lane = channel: one 256-byte store
                 } else {
                     const float m = fmaxf(pool4_rows_max(x[0], x[1], x[0], x[1]), 0.f);                 // rows: tile 0, tile 1, tile 0, tile 1
-                    if (lane < 32) o[lane] = m;
+                    if (lane < 32 && alive) o[lane] = m;
                 }
             } else {                   // S == 16: tile mt is neighbourhood 2 pass + mt
                 if constexpr (T3 == 2) {
                     const float m = fmaxf(pool4_rows_max(v[0][0], v[0][1], v[1][0], v[1][1]), 0.f);     // lanes 0..31: tile 0's 32 channels, 32..63: tile 1's
                     const int g = 2 * pass + (lane >> 5);
-                    if (g < nq) a.out[(size_t)g * a.ldo + a.col0 + (lane & 31)] = m;
+                    if (g < nq && alive) a.out[(size_t)g * a.ldo + a.col0 + (lane & 31)] = m;
                 } else {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const float m = fmaxf(pool4_rows_max(v[mt][0], v[mt][1], v[mt][2], v[mt][3]), 0.f);
-                        if (2 * pass + mt < nq) a.out[(size_t)(2 * pass + mt) * a.ldo + a.col0 + lane] = m;
+                        if (2 * pass + mt < nq && alive) a.out[(size_t)(2 * pass + mt) * a.ldo + a.col0 + lane] = m;
                     }
                 }
             }
@@ -237,14 +240,23 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
                             const int first_row = row0 + mt * 16;
-                            if (first_row < rows) a.out[(size_t)(first_row >> 4) * a.ldo + a.col0 + ch] = v[mt] * inv;
+                            if (first_row < rows && alive) a.out[(size_t)(first_row >> 4) * a.ldo + a.col0 + ch] = v[mt] * inv;
                         }
                     }
                 } else {
-                    if (lane < 16 && row0 < rows) a.out[(size_t)(row0 >> 5) * a.ldo + a.col0 + ch] = (v[0] + v[1]) * inv;
+                    if (lane < 16 && row0 < rows && alive) a.out[(size_t)(row0 >> 5) * a.ldo + a.col0 + ch] = (v[0] + v[1]) * inv;
                 }
             }
         }
+    };
+    int pass = first;
+    Rows ra, rb;
+    load_idx(pass, ivn);
+    load_rows(pass, ivn, ra);
+    load_idx(pass + stride, ivn);
+    for (; pass < npass; pass += 2 * stride) {
+        do_pass(pass, ra, rb, true);
+        do_pass(pass + stride, rb, ra, pass + stride < npass);
     }
 }
 
@@ -261,7 +273,7 @@ __device__ __forceinline__ void sa_xyz_dispatch(const SaXyzArgs &a, int first, i
 
 template <int C1, int C2, int C3>
 __global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
-    sa_xyz_dispatch<C1, C2, C3>(a, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4);
+    sa_xyz_dispatch<C1, C2, C3>(a, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), gridDim.x * 4);
 }
 
 // Both xyz-only scales of an MSG level (16-16-32 at 16 samples and 32-32-64 at 32, max pool) in ONE launch.  Every wave takes its share
@@ -270,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) sa_xyz_kernel(const SaXyzArgs a) {
 // resident waves per SIMD of 2, SQ counters at 240 clouds per launch.)
 template <bool MAXP>
 __global__ void __launch_bounds__(256, 2) sa_xyz_pair_kernel(const SaXyzArgs a0, const SaXyzArgs a1) {
-    const int first = blockIdx.x * 4 + (threadIdx.x >> 6), stride = gridDim.x * 4;
+    const int first = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), stride = gridDim.x * 4;   // (uniform: pass numbers, output rows and the loop test on the scalar unit)
     sa_xyz_body<32, 32, 64, 5, MAXP>(a1, first, stride);
     sa_xyz_body<16, 16, 32, 4, MAXP>(a0, first, stride);
 }
