@@ -161,28 +161,31 @@ __global__ void __launch_bounds__(kPrT) three_nn_prune_kernel(int n, int m, cons
     __shared__ unsigned scode[kPrNB];
     __shared__ float sgrid[4];
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63;
-    {
-        const unsigned char *cw = ws + (size_t)b * kPrCloudBytes;
-        const float4 *rec = reinterpret_cast<const float4 *>(cw);
-        for (int j = t; j < kPrM; j += kPrT) {
-            const float4 r = rec[j];
-            const int jj = (j >> 4) * LB + (j & 15);
-            skx[jj] = r.x; sky[jj] = r.y; skz[jj] = r.z; ski[jj] = __float_as_int(r.w);
-        }
-        const float *box = reinterpret_cast<const float *>(cw + kPrBoxOff);
-        for (int j = t; j < kPrNB * 8; j += kPrT) sbox[j] = box[j];
-        if (t < kPrNB) scode[t] = reinterpret_cast<const unsigned *>(cw + kPrCodeOff)[t];
-        if (t < 4) sgrid[t] = reinterpret_cast<const float *>(cw + kPrGridOff)[t];
-    }
+    // Every load of the prologue is issued before any of them is waited for (round 5: as separate guarded loops / ifs each load was followed by
+    // its own s_waitcnt vmcnt(0) -- five L2 round trips in a row at the start of every workgroup).  Indices past an array's end are clamped
+    // and the value dropped.
+    static_assert(kPrM == kPrT && kPrNB * 8 <= kPrT, "one record per thread");
+    const unsigned char *cw = ws + (size_t)b * kPrCloudBytes;
+    const float4 r = reinterpret_cast<const float4 *>(cw)[t];
+    const float boxv = reinterpret_cast<const float *>(cw + kPrBoxOff)[min(t, kPrNB * 8 - 1)];
+    const unsigned codev = reinterpret_cast<const unsigned *>(cw + kPrCodeOff)[min(t, kPrNB - 1)];
+    const float gridv = reinterpret_cast<const float *>(cw + kPrGridOff)[min(t, 3)];
     const int p = (int)blockIdx.x * kPrT + t;
     float ux, uy, uz;
     int orig = p;
     if (qrec) {
-        const float4 r = reinterpret_cast<const float4 *>(qrec + (size_t)b * qstride)[min(p, n - 1)];
-        ux = r.x; uy = r.y; uz = r.z; orig = sorted_out ? p : __float_as_int(r.w);
+        const float4 q = reinterpret_cast<const float4 *>(qrec + (size_t)b * qstride)[min(p, n - 1)];
+        ux = q.x; uy = q.y; uz = q.z; orig = sorted_out ? p : __float_as_int(q.w);
     } else {
         const float *u = unknown_all + ((size_t)b * n + min(p, n - 1)) * 3;
         ux = u[0]; uy = u[1]; uz = u[2];
+    }
+    {
+        const int jj = (t >> 4) * LB + (t & 15);
+        skx[jj] = r.x; sky[jj] = r.y; skz[jj] = r.z; ski[jj] = __float_as_int(r.w);
+        if (t < kPrNB * 8) sbox[t] = boxv;
+        if (t < kPrNB) scode[t] = codev;
+        if (t < 4) sgrid[t] = gridv;
     }
     __syncthreads();
     const float INF = __builtin_inff();
