@@ -34,15 +34,17 @@ constexpr int TM = 128, TN = 128, TK = G4D_TK, TLD = TK + 8;   // LDS row stride
 // fetched in the epilogue (round 5: with K = 192 the epilogue's dependent loads were a sixth of the launch).
 // WN: waves along the 128 channels of the tile (2: four waves of 64 x 64, 16 accumulator tiles each; 4: eight waves of 64 x 32).
 // D2: the global prefetch runs TWO k chunks ahead through a second register set (hipBLASLt's kernels for these shapes do: PGR2 in their names).
-//     An A/B switch, off by default: measured within 1 % of one chunk ahead.
-// What bounds this kernel (round 5; profiles/r05_gemm_tile_phases.txt = scripts/dbg_gemm_phases.py on a -DG4D_GEMM_DEBUG build): it sits at
-// 0.60-0.65 of the matrix pipe whatever is changed around the MFMAs -- persistent tiles, eight waves instead of four, one or two workgroups per
-// CU, a conflict-free LDS stride, unpredicated loads, two chunks of look-ahead, 64-deep chunks, the four k-steps of a fragment chained on one
-// accumulator: each within 2 %.  Cycle stamps say why: per 32-deep chunk a wave spends ~1.9k cycles ISSUING its 16 global loads (the
-// vector-memory issue path, not their latency), 1.1k staging the older chunk, 1.9k in the barrier and 5.0k in its 128 MFMAs (4.1k of pipe), and
-// a wave issues in order -- the two waves of a SIMD cannot cover 5.8k cycles of each other's non-MFMA time with 4.1k of MFMAs.  The lever that
-// is left is fewer memory instructions per MFMA: a 128 x 128 or 64 x 128 tile PER WAVE (256 accumulator registers, one wave per SIMD, loads
-// interleaved between the MFMAs by hand), which is what hipBLASLt's 0.79 kernels do (MT256x256x32 / MIWT8_8).  Not built.
+//     An A/B switch, off by default: measured equal to one chunk ahead, 40 registers more.
+// What bounded this kernel, and what fixed it (round 5; profiles/r05_gemm_tile_phases.txt = scripts/dbg_gemm_phases.py on a -DG4D_GEMM_DEBUG
+// build, scripts/exp_clock_gemm.py for the sustained rate): it sat at 0.72-0.74 of the matrix pipe sustained (0.60-0.65 in 7 ms bursts from an idle
+// chip) whatever was changed AROUND the MFMAs -- persistent tiles, eight waves instead of four, one or two workgroups per CU, a conflict-free LDS
+// stride, unpredicated loads, two chunks of look-ahead, 64-deep chunks, the four k-steps of a fragment chained on one accumulator: each within
+// 2 %.  Cycle stamps: per 32-deep chunk a wave spent ~2.0k cycles ISSUING its 16 global loads as one burst -- the eight waves of a CU queue at
+// its one 64 B / clk vector-memory path, 16 cycles per 1 KB wave-load -- 1.1k staging the older chunk, 1.8k in the barrier and 5.1k in its 128
+// MFMAs (4.1k of pipe); a wave issues in order, so it issued no MFMA while its loads queued, and two waves per SIMD cannot cover 5 k cycles of
+// each other's non-MFMA time with 4.1k of MFMAs.  Now the loads and the LDS stores sit BETWEEN the MFMA chains, one per two chains (8 MFMAs =
+// 256 cycles of pipe each): 313 -> 292 us at 61440 x 576 -> 512, 143 -> 132 us at 512 -> 256 sustained = 0.79 / 0.78 of the fp32 MFMA peak,
+// hipBLASLt's kernels (MT64x128x64 / MT256x256x32, PGR2) 291 / 128 us on the same box.
 template <bool FULLK, bool TAB, int WN, bool D2>
 __global__ void __launch_bounds__(128 * WN, WN) gemm_tile_kernel(const LinearArgs a, int nrow_blk, int ncol_blk, int cpad, int nblocks) {
     constexpr int NTH = 128 * WN, TPR = TK / 4, P = TM / (NTH / TPR), JT = TN / WN / 16;   // threads; threads per staged row; staging passes per operand; channel tiles per wave
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(128 * WN, WN) gemm_tile_kernel(const LinearArg
     f32x4 ax[P], aw[P], bx[D2 ? P : 1], bw[D2 ? P : 1];
     fetch(ax, aw);              // chunk 0
     stage(0, ax, aw);
-    fetch(ax, aw);              // chunk 1: staged during step 0
+    if constexpr (D2) fetch(ax, aw);   // chunk 1: staged during step 0 (one register set: requested AND staged during step 0)
     lds_barrier();
     const int fi = lane & 15, fq = lane >> 4;
     const int wr = wave / WN, wc = wave % WN;   // the wave's 64 x (128 / WN) part of the tile
@@ -194,10 +196,17 @@ __global__ void __launch_bounds__(128 * WN, WN) gemm_tile_kernel(const LinearArg
 #endif
     auto step = [&](f32x4 (&fill_x)[P], f32x4 (&fill_w)[P], const f32x4 (&drain_x)[P], const f32x4 (&drain_w)[P], bool same) {
         G4D_MSTAMP(7)   // (loop overhead / tile setup since the last stamp)
-        if (!same) fetch(fill_x, fill_w);
-        G4D_MSTAMP(0)   // prefetch issued
+        // The 2 P loads of chunk s + 2 (one register set: of chunk s + 1) and the 2 P LDS stores of chunk s + 1 are spread BETWEEN the chunk's MFMA
+        // chains (one per two chains: loads in the first half, stores in the second).  Issued as a burst at the top of the chunk they took the wave ~2k cycles -- eight waves
+        // queue at the CU's one 64 B / clk vector-memory path -- during which it issued no MFMA (profiles/r05_gemm_tile_phases.txt).
+        constexpr int NCH = (TK / 16) * 4 * JT;      // MFMA chains per chunk
+        static_assert(NCH >= 8 * P, "room for 2 P loads and 2 P stores between the chains");
+        const int kf = fc * TK;
+        (void)same;
+        G4D_MSTAMP(0)
         const float *cA = sA + cur * TM * TLD + (wr * 64 + fi) * TLD + fq * 4;
         const float *cB = sB + cur * TN * TLD + (wc * WCOLS + fi) * TLD + fq * 4;
+        float *dA = sA + (cur ^ 1) * TM * TLD + lr * TLD + lk, *dB = sB + (cur ^ 1) * TN * TLD + lr * TLD + lk;
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 16) {
             f32x4 af[4], bf[JT];
@@ -205,21 +214,34 @@ __global__ void __launch_bounds__(128 * WN, WN) gemm_tile_kernel(const LinearArg
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x4 *>(cA + i * 16 * TLD + kk);
 #pragma unroll
             for (int j = 0; j < JT; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(cB + j * 16 * TLD + kk);
-            // the four k-steps of a fragment pair back to back on ONE accumulator (A/B switch G4D order, measured below)
+            // the four k-steps of a fragment pair back to back on ONE accumulator
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
-                    __builtin_amdgcn_sched_barrier(0);   // (keeps the chain together: left alone the scheduler interleaves the accumulators again)
+                    __builtin_amdgcn_sched_barrier(0);   // (keeps the chain -- and the memory operation in front of it -- where it is written)
+                    {
+                        const int ch = (kk / 16) * 4 * JT + i * JT + j;
+                        if (ch % 2 == 0 && ch / 2 < 2 * P) {                      // request n of chunk s + 2
+                            constexpr int dummy = 0; (void)dummy;
+                            const int n = ch / 2;
+                            if (n < P) fill_x[n] = load_x(fx[n], kf);
+                            else fill_w[n - P] = *reinterpret_cast<const f32x4 *>(fw[n - P] + kf);
+                        }
+                        if (ch % 2 == 1 && ch >= NCH - 4 * P) {                  // LDS store n of chunk s + 1
+                            const int n = (ch - (NCH - 4 * P)) / 2;
+                            if (n < P) *reinterpret_cast<f32x4 *>(dA + RS * n * TLD) = drain_x[n];
+                            else *reinterpret_cast<f32x4 *>(dB + RS * (n - P) * TLD) = drain_w[n - P];
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // (weights as the A operand: see the epilogue)
                 }
         }
-        __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler stages `drain` ahead of the MFMAs: one chunk of cover for its loads instead of two)
-        G4D_MSTAMP(1)   // fragments read, MFMAs issued
-        stage(cur ^ 1, drain_x, drain_w);
-        if (same) fetch(fill_x, fill_w);   // one register set (depth 1): the next request goes out once the set has been staged
-        G4D_MSTAMP(2)   // the older prefetch has arrived and is staged
+        __builtin_amdgcn_sched_barrier(0);
+        G4D_MSTAMP(1)   // fragments read, MFMAs issued (D2: with the requests and the staging in between)
+        if (++fc == nchunk) { fc = 0; set_cursor(++fj); }   // the cursor moves on (fetch() does it for the burst form of the prologue)
+        G4D_MSTAMP(2)
         lds_barrier();
         G4D_MSTAMP(3)   // barrier
         cur ^= 1;
