@@ -47,6 +47,9 @@ __device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, 
 }
 
 constexpr int kStageK = 2;   // WM == 2: k-steps per staged chunk (one barrier per chunk)
+#ifndef G4D_SA_TABLE_SPREAD
+#define G4D_SA_TABLE_SPREAD 1
+#endif
 constexpr int kRing = 4;   // weight fragments requested ahead of their MFMAs (LDS: ~130 cycles; L2: see kRingG)
 constexpr int kRingG = 6;
 
@@ -108,20 +111,32 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) v[mt] = a.idx[min(blk * R + mt * 16 + fi, a.rows - 1)];
     };
-    auto load_rows = [&](int blk, const int (&v)[MT], Rows &rw) {
+    // The rows of a block: rows_begin() forms the table-row pointers and requests the coordinates (small loads); the T * MT 16-byte table loads --
+    // the expensive ones at the CU's 64 B / clk vector-memory path -- are requested ONE AT A TIME by rows_raw(q), which the block loop calls
+    // between its MFMA chains (round 5: as one burst of 14 loads they held the wave's in-order issue for ~2k cycles; load_rows() = all at once,
+    // for the start-up).
+    auto rows_begin = [&](int blk, const int (&v)[MT], Rows &rw, const float *(&tr)[MT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int q = __builtin_amdgcn_readfirstlane(min((blk * R + mt * 16) / S, nq - 1));   // S >= 16: a tile belongs to one neighbourhood
             const int b = q / a.P;
             const size_t pt = (size_t)b * a.N + v[mt];
-            const float *tr = a.tab + pt * a.tab_ld + fq * 4;
-#pragma unroll
-            for (int ks = 0; ks < T; ++ks) rw.raw[ks][mt] = *reinterpret_cast<const f32x4u *>(tr + ks * 16);
+            tr[mt] = a.tab + pt * a.tab_ld + fq * 4;
             const float *pp = a.xyz + pt * 3;
             rw.px[mt] = pp[0]; rw.py[mt] = pp[1]; rw.pz[mt] = pp[2];
             const float *cc = a.new_xyz + (size_t)q * 3;
             rw.cx[mt] = cc[0]; rw.cy[mt] = cc[1]; rw.cz[mt] = cc[2];
         }
+    };
+    auto rows_raw = [&](const float *const (&tr)[MT], Rows &rw, int q) {   // q = ks * MT + mt
+        const int ks = q / MT, mt = q % MT;
+        rw.raw[ks][mt] = *reinterpret_cast<const f32x4u *>(tr[mt] + ks * 16);
+    };
+    auto load_rows = [&](int blk, const int (&v)[MT], Rows &rw) {
+        const float *tr[MT];
+        rows_begin(blk, v, rw, tr);
+#pragma unroll
+        for (int q = 0; q < T * MT; ++q) rows_raw(tr, rw, q);
     };
     // a weight fragment = 1 KB, lane l takes bytes [16 l, 16 l + 16).  From L2 (WLDS false): uniform base (SGPRs, bumped per fragment by scalar
     // adds) + ONE lane offset register; written any other way the 192 fragment addresses of the 128-wide stack are loop invariants that the
@@ -144,6 +159,7 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
     // per block (an even number of chunks).  Fragment (kk, ct) of a chunk sits at slot kk * (tiles of the layer) + ct.
     const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W2), 0, C * C * 4, 0x00020000),
                                  rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W3), 0, 2 * C * C * 4, 0x00020000);
+    constexpr bool kSpread = G4D_SA_TABLE_SPREAD;   // the next chunk's copies between this chunk's MFMA chains (A/B: -DG4D_SA_TABLE_SPREAD=0)
     auto stage_issue = [&](int chunk) {
         if constexpr (WM == 2) {
             constexpr int NC2 = T / kStageK, NCH = 2 * NC2;
@@ -169,6 +185,30 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
             }
         }
     };
+    // ONE of a chunk's copies: number j of this wave's share (round 5: the copies of the next chunk go out between the MFMA chains of the current
+    // one, one per chain, instead of as a burst behind the barrier -- a wave issues in order, and while its 4-8 copies queued at the CU's
+    // vector-memory path, 16 cycles per 1 KB wave-copy and eight waves in line, it issued no MFMA; gemm_tile.hip has the measurement).
+    auto stage_issue_one = [&](int chunk, int j) {
+        if constexpr (WM == 2) {
+            constexpr int NC2 = T / kStageK, NCH = 2 * NC2;
+            chunk = chunk % NCH;
+            float *dst = s_stage + (chunk & 1) * (kStageK * T3 * 256);
+            const int l16b = lane * 16;
+            if (chunk < NC2) {
+                if (j < kStageK * T / 4) {
+                    const int slot = wave + 4 * j, kk = slot / T, ct = slot % T;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, l16b,
+                                                             (ct * T + chunk * kStageK + kk) * 1024, 0, 0);
+                }
+            } else {
+                if (j < kStageK * T3 / 4) {
+                    const int slot = wave + 4 * j, kk = slot / T3, ct = slot % T3;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW3, (__attribute__((address_space(3))) void *)(dst + slot * 256), 16, l16b,
+                                                             (ct * T + (chunk - NC2) * kStageK + kk) * 1024, 0, 0);
+                }
+            }
+        }
+    };
     // start of a chunk (k-step gks of the block, 0 .. 2T-1; acts on the first k-step of each chunk): this wave's share of the chunk's
     // fragments has landed (vmcnt), so has everybody else's and nobody reads the other buffer any more (barrier); then the next chunk's copy
     // goes out.  (One k-step per barrier: 805 us for the 128-wide stack; a 1k-cycle k-step barely covers the copy's L2 round trip.)
@@ -176,7 +216,7 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
         if constexpr (WM == 2) {
             if (gks % kStageK == 0) {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                stage_issue(gks / kStageK + 1);
+                if (!kSpread) stage_issue(gks / kStageK + 1);
             }
         }
     };
@@ -190,11 +230,13 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
     load_rows(block_of(0), ivn, cur);
     load_idx(block_of(1), ivn);
     float pm[T3];                                    // running maximum of the neighbourhood across its blocks (G > 1)
+    const float *trn[MT];                            // table-row pointers of the next block (rows_begin -> rows_raw)
     for (int it = 0; it < iters; ++it) {
         const int blk = block_of(it);
         if constexpr (WM != 1) asm volatile("" : "+v"(lane16));   // no hoisted fragment addresses
         if constexpr (WM != 2) {
-            load_rows(block_of(it + 1), ivn, nxt);   // level 2 of the next block
+            if constexpr (kSpread) rows_begin(block_of(it + 1), ivn, nxt, trn);   // level 2 of the next block: pointers + coordinates now, the table rows between layer 2's chains
+            else load_rows(block_of(it + 1), ivn, nxt);
             load_idx(block_of(it + 2), ivn);         // level 1 of the one after
         }
         // ---- first layer: relu(affine(table row + Wx (x_j - q))), the arithmetic of mlp_chain.hip's table loader, one k-step at a time
@@ -245,6 +287,8 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
                         if (f + RD < F) ring[f % RD] = wfrag(a.W2, s_w2, (f + RD) % T, (f + RD) / T);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (WM == 2 && kSpread) stage_issue_one(ks / kStageK + 1, (ks % kStageK) * T + ct);   // copy number (chain index) of the next chunk
+                    if constexpr (WM != 2 && kSpread) { if (f < T * MT) rows_raw(trn, nxt, f); }                     // one table row of the next block per chain
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -282,7 +326,8 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
                 if constexpr (WM == 2) {
                     if (ks == 0) {   // the next block's rows: requested here, behind a k-step barrier -- every barrier drains this wave's loads (vmcnt(0)),
                                      // so they get the 2k cycles of layer 3's first k-step instead of stalling the block's first one
-                        load_rows(block_of(it + 1), ivn, nxt);
+                        if constexpr (kSpread) rows_begin(block_of(it + 1), ivn, nxt, trn);   // (the table rows: between the chains below)
+                        else load_rows(block_of(it + 1), ivn, nxt);
                         load_idx(block_of(it + 2), ivn);
                     }
                 }
@@ -297,6 +342,11 @@ __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
                 if (f + RD < F3) ring3[f % RD] = wfrag(a.W3, s_w3, (f + RD) % T3, (f + RD) / T3);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (WM == 2 && kSpread) {
+                stage_issue_one((T + ks) / kStageK + 1, (ks % kStageK) * T3 + ct);
+                constexpr int ND = kStageK * T3 / 4;   // this wave's copies per layer-3 chunk: the next block's table rows follow them, one per chain
+                if (f >= ND && f - ND < T * MT) rows_raw(trn, nxt, f - ND);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
