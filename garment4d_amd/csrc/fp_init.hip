@@ -86,34 +86,43 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
     const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W1), 0, C0 * C1 * 4, 0x00020000),
                                  rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W2), 0, C1 * C2 * 4, 0x00020000),
                                  rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.W3), 0, C2 * C3 * 4, 0x00020000);
-    auto stage_issue = [&](int buf, int step) {
+    // copy number j of this wave's share of chunk `step` (fragments wave, wave + 4, ...).  Round 5: a chunk's copies go out ONE PER MFMA CHAIN of
+    // the chunk before it, not as a burst behind the barrier: a wave issues in order, and while its 4-8 copies queued at the CU's 64 B / clk
+    // vector-memory path (16 cycles per 1 KB wave-copy, eight waves in line) it issued no MFMA (gemm_tile.hip has the measurement).
+    auto stage_issue_one = [&](int buf, int step, int j) {
         float *dst = s_stage[buf];
         constexpr int c1 = K0 / KSC, c2 = c1 + T1 / KSC;
         const int nt = step < c1 ? T1 : (step < c2 ? T2 : T3), kst = step < c1 ? K0 : (step < c2 ? T1 : T2);
         const int ks0 = (step < c1 ? step : (step < c2 ? step - c1 : step - c2)) * KSC;
-#pragma unroll
-        for (int j = 0; j < KSC * 4; ++j) {
-            if (j < KSC * nt / 4) {                  // this wave's fragments: slots wave, wave + 4, ...
-                const int slot = wave + 4 * j;
-                const int kk = slot / nt, ct = slot - kk * nt;
-                const int soff = (ct * kst + ks0 + kk) * 1024;
-                __attribute__((address_space(3))) void *d = (__attribute__((address_space(3))) void *)(dst + slot * 256);
-                if (step < c1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, d, 16, lane16, soff, 0, 0);
-                else if (step < c2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, d, 16, lane16, soff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW3, d, 16, lane16, soff, 0, 0);
-            }
+        if (j < KSC * nt / 4) {
+            const int slot = wave + 4 * j;
+            const int kk = slot / nt, ct = slot - kk * nt;
+            const int soff = (ct * kst + ks0 + kk) * 1024;
+            __attribute__((address_space(3))) void *d = (__attribute__((address_space(3))) void *)(dst + slot * 256);
+            if (step < c1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, d, 16, lane16, soff, 0, 0);
+            else if (step < c2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, d, 16, lane16, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rW3, d, 16, lane16, soff, 0, 0);
         }
+    };
+    auto stage_issue = [&](int buf, int step) {      // all of them (the start-up)
+#pragma unroll
+        for (int j = 0; j < KSC * 4; ++j) stage_issue_one(buf, step, j);
     };
     int par0 = 0;                                    // stage buffer of the current tile's first chunk (STEPS is odd: it flips per tile)
     static_assert(STEPS % 2 == 1, "buffer parity flips per tile");
     // chunk c of the tile: this wave's share has landed, everybody's has, nobody reads the other buffer any more; chunk c + 1 (the next tile's
     // first chunk after the last one) goes out.  `younger` = the vector-memory instructions this wave issued AFTER chunk c's copies (vmcnt
     // counts in issue order on gfx9): they may stay in flight across the barrier.  Only the chunk boundaries INSIDE layer 2 use it -- there the
-    // only younger instructions are the unconditional table gathers of the last two k-steps.
+    // only younger instructions are the unconditional table gathers of the chunk's second k-step (its first k-step's were requested ahead of the
+    // copies, which follow them one per chain).
     auto stage_step = [&](int c, int younger) {
-        if (younger == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        if (younger == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        stage_issue(par0 ^ ((c + 1) & 1), (c + 1) % STEPS);
+    };
+    // in front of MFMA chain `ct` of k-step gks (a layer with nt channel tiles): the next chunk's copy number (chain index within the chunk)
+    auto copy_at = [&](int gks, int nt, int ct) {
+        const int c = gks / KSC;
+        stage_issue_one(par0 ^ ((c + 1) & 1), (c + 1) % STEPS, (gks % KSC) * nt + ct);
     };
     // fragment (global k-step gks of the tile, channel tile ct) of a layer with nt tiles
     auto sfrag = [&](int gks, int nt, int ct) -> f32x4 {
@@ -202,6 +211,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
                 const f32x4 w = sring[ct & 1];
                 if (ct + 2 < T1) sring[ct & 1] = sfrag(ks, T1, ct + 2);
                 __builtin_amdgcn_sched_barrier(0);
+                copy_at(ks, T1, ct);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], sk.s[ks][e], h1[ct], 0, 0, 0);
             }
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
                 nxt = make(tile_of(it + 1), rawn);
                 rawn = load_raw(tile_of(it + 2));
             }
-            stage_at(K0 + ks, ks >= 2 ? 6 : 0);
+            stage_at(K0 + ks, ks >= 2 ? 3 : 0);
             if (ks >= 2) {
                 h1n[ks - 2] = blend(nxt, item[ks & 1]);
                 asm volatile("" : "+v"(h1n[ks - 2]));   // the blend happens HERE (not sunk towards the loop latch with the raw rows kept alive)
@@ -241,6 +251,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
                 const f32x4 w = sring[ct & 1];
                 if (ct + 2 < T2) sring[ct & 1] = sfrag(K0 + ks, T2, ct + 2);
                 __builtin_amdgcn_sched_barrier(0);
+                copy_at(K0 + ks, T2, ct);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], h1[ks][e], h2[ct], 0, 0, 0);
             }
@@ -274,6 +285,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
                 const f32x4 w = sring[ct & 1];
                 if (ct + 2 < T3) sring[ct & 1] = sfrag(K0 + T1 + ks, T3, ct + 2);
                 __builtin_amdgcn_sched_barrier(0);
+                copy_at(K0 + T1 + ks, T3, ct);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[ks][e], w[e], o[ct], 0, 0, 0);
             }
