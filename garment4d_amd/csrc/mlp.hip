@@ -208,8 +208,10 @@ __global__ void __launch_bounds__(256) transpose_kernel(int R, int Cc, const flo
 static int launch_linear(int mode, const LinearArgs &a, hipStream_t s) {
     if (mode == LOAD_DIRECT) {
         int rc = G4D_OK;
-        if (gemm_stream_try(a, s, &rc)) return rc;   // tall, un-pooled, Cout a multiple of 128, K <= 128: the row-streaming GEMM
-        if (gemm_tile_try(a, s, &rc)) return rc;     // tall, un-pooled, deep: 128 x 128 tiles (gemm_tile.hip)
+        // (round 5: the tile kernel first -- since its loads sit between the MFMA chains it is level with the row-streaming kernel at
+        //  K = 128 -> 128 and 8 % ahead at 128 -> 384 (983k rows: 1128 vs 1230 us); the streaming kernel keeps the shapes the tile kernel declines)
+        if (gemm_tile_try(a, s, &rc)) return rc;     // tall, un-pooled, K >= 128, Cout a multiple of 128: 128 x 128 tiles (gemm_tile.hip)
+        if (gemm_stream_try(a, s, &rc)) return rc;   // tall, un-pooled, Cout a multiple of 128 after padding, K <= 128: the row-streaming GEMM
     }
     const int nb = (a.Cout + BN - 1) / BN;
     // 32-row tiles when 64-row tiles would not even give two workgroups per CU (and no fused pooling is asked for)
