@@ -10,7 +10,7 @@
 //     1.7-3.4 us of matrix work instead of one per 0.4 us;
 //   * wave w owns all 128 rows x channels [16 w, 16 w + 16): 8 accumulator tiles, A fragments by ds_read_b128 (4 consecutive k per
 //     lane feeding 4 MFMAs, same k permutation on both operands -- the LDS-tiled kernel's order, so results are bit-identical to it);
-//   * 2 x 128 x 68 floats of LDS = 70 KB: two workgroups per CU.
+//   * 2 x 128 x 72 floats of LDS = 74 KB: two workgroups per CU (row stride 72 since round 5: conflict-free fragment reads).
 // Measured at 983k rows (scripts/time_gemm_stream.py): 128 -> 128 491 -> 385-400 us (81-84 TFLOP/s), 128 -> 384 1510 -> 1210-1290 us;
 // with K = 195 / 323 (W re-streamed from L2 per tile and super-chunk, ragged tail) it LOSES to the register-chain kernel (842 / 1226 vs
 // 713 / 1093 us), so launch_linear takes this route only for Kpad <= 128.  What still separates it from the matrix pipe's 157: skipping
@@ -31,7 +31,7 @@
 namespace g4d {
 
 namespace {
-constexpr int GM = 128, GN = 128, GK = 64, GLD = GK + 4;
+constexpr int GM = 128, GN = 128, GK = 64, GLD = GK + 8;   // (72: conflict-free fragment reads; 68 was two-way -- gemm_tile.hip)
 constexpr int GT = 512;   // threads
 }  // namespace
 

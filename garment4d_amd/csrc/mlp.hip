@@ -25,7 +25,7 @@
 
 namespace g4d {
 
-constexpr int BN = 64, KC = 32, LDT = KC + 4;  // LDS row stride in floats
+constexpr int BN = 64, KC = 32, LDT = KC + 8;  // LDS row stride in floats: 40 (round 5; 36 put two of the 16-byte slots of a ds_read_b128 lane group on the same banks in 7 of 16 cases -- gemm_tile.hip has the derivation; SQ_LDS_BANK_CONFLICT 0.73 of the busy cycles)
 
 template <int MODE>
 __device__ __forceinline__ f32x4 load4(const LinearArgs &a, const RowCtx<MODE> &c, int row, int k) {

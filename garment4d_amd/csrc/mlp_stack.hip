@@ -266,8 +266,8 @@ extern "C" int g4d_mlp_stack_f32(int mode, long long rows, int K0,
         }
     }
     G4D_REQUIRE(Kpad[0] >= K0, "g4d_mlp_stack_f32: Kpad[0] < K0");
-    s.ld0 = w0 + 4;
-    s.ld1 = w1 + 4;
+    s.ld0 = w0 + 8;   // (+ 8, not + 4: conflict-free ds_read_b128 fragment reads for widths that are multiples of 16 -- gemm_tile.hip)
+    s.ld1 = w1 + 8;
     // 32-row workgroups (half the LDS, twice the workgroups) are available behind G4D_STACK_MT=1
     static const int mt_env = getenv("G4D_STACK_MT") ? atoi(getenv("G4D_STACK_MT")) : 0;  // tuning hook: 1 | 2 | 0 (auto)
     const size_t lds64 = sizeof(float) * 64 * (size_t)(s.ld0 + s.ld1);

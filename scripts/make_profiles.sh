@@ -70,6 +70,16 @@ print('k=%3d clouds/call=%4d calls in flight=%2d clouds in flight=%4d : %7.0f fr
 timeout 600 python scripts/exp_overlap.py 240 2>/dev/null > $OUT/${R}_overlap_pairs_240clouds.txt
 PAIRS="fps_gather_grid:mlp_chain_bf16,fps_gather_grid:three_nn" timeout 600 python scripts/exp_overlap.py 240 bf16 2>/dev/null > $OUT/${R}_launches_240clouds_bf16.txt
 python scripts/time_gemm.py 2>&1 | grep -v amdgpu > $OUT/${R}_gemm_shapes.txt
+# 8b. gemm_tile.hip: phase stamps (debug build) and the SUSTAINED rate next to hipBLASLt's, with the shader clock (time_gemm.py's 7 ms bursts from an
+#     idle chip read ~12 % lower than a launch inside a running call)
+{
+  echo "# gemm_tile.hip (g4d_linear_f32 at the wide FP level's shapes): where a workgroup's cycles go, and the sustained rate next to hipBLASLt's"
+  echo "# scripts/dbg_gemm_phases.py on garment4d_amd/lib/libg4d_hip_dbg.so (make dbg: -DG4D_GEMM_DEBUG, cycle stamps of wave 0 of every workgroup; the stamps cost ~10 % themselves),"
+  echo "# then scripts/exp_clock_gemm.py (one kernel back to back for 2 s, shader clock from scripts/micro/clockprobe.hip, board power from rocm-smi)"
+  G4D_LIB_PATH=$ROOT/garment4d_amd/lib/libg4d_hip_dbg.so python scripts/dbg_gemm_phases.py 2>&1 | grep -v amdgpu
+  G4D_LIB_PATH=$ROOT/garment4d_amd/lib/libg4d_hip_dbg.so python scripts/dbg_gemm_phases.py 61440 512 256 2>&1 | grep -v amdgpu
+  python scripts/exp_clock_gemm.py 2>&1 | grep -v amdgpu
+} > $OUT/${R}_gemm_tile_phases.txt
 python scripts/exp_clock.py 2>&1 | grep -v amdgpu > $OUT/${R}_clock_and_power_by_regime.txt
 rm -rf $OUT/bench $OUT/e240 $OUT/e240b $OUT/e8 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE $OUT/cfg4 $OUT/cfg5
 ls -la $OUT
