@@ -55,6 +55,9 @@ SIGNATURES = {
     "g4d_interp_concat_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_spmm_rows_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp],
     "g4d_gcn_agg_linear_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp],
+    "g4d_gcn_agg_linear_meta_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp, _vp],
+    "g4d_gcn_tile_meta_bytes": [_I],
+    "g4d_gcn_tile_meta_build": [_I, _vp, _vp, _vp, _vp, _vp],
     "g4d_knn_f32": [_I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_knn_blend_weights_f32": [_I, _I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp],
     "g4d_pos_encode_f32": [_I, _I, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp],
@@ -116,7 +119,7 @@ SIGNATURES = {
 _lib = None
 
 
-RESTYPES = {"g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_three_nn_pruned_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
+RESTYPES = {"g4d_gcn_tile_meta_bytes": ctypes.c_longlong, "g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_three_nn_pruned_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):

@@ -64,7 +64,14 @@ struct GcnFusedArgs {
     const float *Wp;         // next weight (Cout_pad x 128) in the fragment order of the LDS-resident MLP kernels: [16-channel tile][k-step of 16 (8)][lane = fq*16+fi][4 consecutive k]
     int cout;                // real output channels (<= 16 * NT)
     float *out;              // (frames, vg, cout)
+    const int *meta;         // per-tile metadata built once per mesh by g4d_gcn_tile_meta_build (NULL: every workgroup derives its own)
 };
+
+// Per-tile metadata (round 5): the window and the padded (column offset, weight) rows of a tile depend on the MESH only -- the same for all
+// frames of a launch, all four layers of a regressor, all three refinement rounds -- but every workgroup used to derive them from the CSR
+// arrays through three dependent round trips (row pointers -> column range -> atomics -> entries): ~25k of a tile's ~83k cycles.
+// Layout per tile, in ints: [0] lo, [1] hi, [2] longest row, [3] fast (window and valence fit), then TILE * kEll (offset, weight-bits) pairs.
+template <int TILE> constexpr int gcn_meta_ints() { return 4 + TILE * 8 * 2; }
 
 // NT = channel tiles of the next layer: 8 (Cout = 128: wave owns 2 channel tiles x 8 row tiles) or 1 (Cout <= 16: wave owns
 // 2 row tiles x the one channel tile).
@@ -97,6 +104,11 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
         maxlen = max(maxlen, len[p]);
     }
     if constexpr (FAST) {
+        if (a.meta) {   // the pairs were built once per mesh: one coalesced copy, no dependent loads
+            const int2 *src = reinterpret_cast<const int2 *>(a.meta + (size_t)(r0 / kTile) * gcn_meta_ints<TILE>() + 4);
+#pragma unroll
+            for (int k = 0; k < kTile * kEll / 256; ++k) ent[t + 256 * k] = src[t + 256 * k];
+        } else
         // the tile's CSR rows, padded to `ell` (column offset into `win`, weight) pairs each: the aggregation loop then has a
         // block-uniform trip count and no per-entry predicate.  A padded pair is (the ZERO row behind the window, weight 0): it adds
         // 0 * 0 whatever the activations hold -- pointing it at a real neighbour row would turn an inf / NaN there into NaN for rows
@@ -127,7 +139,9 @@ __device__ __forceinline__ void gcn_fused_tile(const GcnFusedArgs &a, int f, int
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int r = ar + 32 * i;
-            pre[i] = r < wrows ? *reinterpret_cast<const f32x4 *>(S + (size_t)(lo + r) * kC + ks * 32 + ac) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            // unconditional (rows past the window: its last row again, never stored): a load under a condition makes the number of loads in
+            // flight unknown where the branches join, and the wait for this slice's B fragments then drains the prefetch too
+            pre[i] = *reinterpret_cast<const f32x4 *>(S + (size_t)(lo + min(r, wrows - 1)) * kC + ks * 32 + ac);
         }
     };
     if constexpr (FAST) prefetch(0);
@@ -280,9 +294,17 @@ __global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(cons
     const int f = logical / a.tpf;
     const int r0 = (logical - f * a.tpf) * kTile;
     const int nrows = min(kTile, a.vg - r0);
+    if (t < kLdW) win[kWin * kLdW + t] = 0.f;
+    if (a.meta) {   // per-mesh metadata: window, longest row and fast-path flag of the tile, read (uniformly) instead of derived
+        const int *hd = a.meta + (size_t)(r0 / kTile) * gcn_meta_ints<TILE>();
+        const int lo = hd[0], hi = hd[1], ell = hd[2], fast = hd[3];
+        lds_barrier();   // (the zero row)
+        if (fast) gcn_fused_tile<NT, TILE, true>(a, f, r0, win, asl, ent, lo, hi - lo, 0, ell);
+        else gcn_fused_tile<NT, TILE, false>(a, f, r0, win, asl, ent, 0, 0, a.rowptr[r0], ell);
+        return;
+    }
     // window of the tile: [lo, hi) over the column indices of its rows (a contiguous CSR range)
     if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; s_lohi[2] = 0; }
-    if (t < kLdW) win[kWin * kLdW + t] = 0.f;
     lds_barrier();
     const int e0 = a.rowptr[r0], e1 = a.rowptr[r0 + nrows];
     {
@@ -312,22 +334,106 @@ __global__ void __launch_bounds__(256, TILE == 64 ? 3 : 2) gcn_fused_kernel(cons
         gcn_fused_tile<NT, TILE, false>(a, f, r0, win, asl, ent, 0, 0, e0, ell);
 }
 
+// One workgroup per tile of the mesh: what gcn_fused_kernel's prologue derives, written once (layout: gcn_meta_ints above).
+template <int TILE>
+__global__ void __launch_bounds__(256) gcn_meta_kernel(int vg, const int *rowptr, const int *colidx, const float *vals, int *meta) {
+    constexpr int kTile = TILE, kWin = Geo<TILE>::kWin;
+    __shared__ int s_lohi[3];
+    const int t = threadIdx.x, lane = t & 63;
+    const int r0 = (int)blockIdx.x * kTile;
+    const int nrows = min(kTile, vg - r0);
+    if (t == 0) { s_lohi[0] = 0x7fffffff; s_lohi[1] = -1; s_lohi[2] = 0; }
+    __syncthreads();
+    const int e0 = rowptr[r0], e1 = rowptr[r0 + nrows];
+    int lo = 0x7fffffff, hi = -1;
+    for (int e = e0 + t; e < e1; e += 256) {
+        const int c = colidx[e];
+        lo = min(lo, c);
+        hi = max(hi, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if (lane == 0 && hi >= 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
+    int rl = t < nrows ? rowptr[r0 + t + 1] - rowptr[r0 + t] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rl = max(rl, __shfl_xor(rl, o));
+    if (lane == 0) atomicMax(&s_lohi[2], rl);
+    __syncthreads();
+    const int wlo = s_lohi[0], whi = s_lohi[1] + 1, ell = s_lohi[2];
+    const bool fast = ell <= kEll && whi - wlo <= kWin && whi > wlo;
+    int *hd = meta + (size_t)blockIdx.x * gcn_meta_ints<TILE>();
+    if (t == 0) { hd[0] = wlo; hd[1] = whi; hd[2] = ell; hd[3] = fast ? 1 : 0; }
+    int2 *pairs = reinterpret_cast<int2 *>(hd + 4);
+    for (int k = t; k < kTile * kEll; k += 256) {   // (the pairs of gcn_fused_tile<FAST>: same rule, same padding)
+        const int r = k / kEll, j = k - r * kEll;
+        int off = kWin * kLdW;
+        float w = 0.f;
+        if (fast && r < nrows) {
+            const int b = rowptr[r0 + r], n = rowptr[r0 + r + 1] - b;
+            if (j < n) {
+                off = (colidx[b + j] - wlo) * kLdW;
+                w = vals[b + j];
+            }
+        }
+        pairs[k] = make_int2(off, __float_as_int(w));
+    }
+}
+
 }  // namespace g4d
 
 using namespace g4d;
 
+static int gcn_tile_rows() {
+    static const int tile = [] { const char *e = getenv("G4D_GCN_TILE"); return e && atoi(e) == 64 ? 64 : 128; }();   // measured: 2.12 ms (128) vs 2.20 ms (64) per 4-layer stack at 240 x 4096 rows
+    return tile;
+}
+
+extern "C" long long g4d_gcn_tile_meta_bytes(int vg) {
+    const int tile = gcn_tile_rows();
+    const long long tiles = (vg + tile - 1) / tile;
+    return tiles * (tile == 128 ? gcn_meta_ints<128>() : gcn_meta_ints<64>()) * (long long)sizeof(int);
+}
+
+extern "C" int g4d_gcn_tile_meta_build(int vg, const int *rowptr, const int *colidx, const float *vals, void *meta, g4d_stream_t stream) {
+    G4D_REQUIRE(vg >= 0, "g4d_gcn_tile_meta_build: bad size");
+    if (vg == 0) return G4D_OK;
+    G4D_REQUIRE(rowptr && colidx && vals && meta, "g4d_gcn_tile_meta_build: null pointer");
+    const int tile = gcn_tile_rows();
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (tile == 128) hipLaunchKernelGGL(gcn_meta_kernel<128>, dim3((vg + 127) / 128), dim3(256), 0, st, vg, rowptr, colidx, vals, static_cast<int *>(meta));
+    else hipLaunchKernelGGL(gcn_meta_kernel<64>, dim3((vg + 63) / 64), dim3(256), 0, st, vg, rowptr, colidx, vals, static_cast<int *>(meta));
+    return check_launch("g4d_gcn_tile_meta_build");
+}
+
+static int gcn_agg_linear(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals, const float *bias, int relu,
+                          float *tap, const float *Wp, int cout, float *out, const void *meta, g4d_stream_t stream);
+
 extern "C" int g4d_gcn_agg_linear_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
                                       const float *bias, int relu, float *tap, const float *Wp, int cout, float *out,
                                       g4d_stream_t stream) {
+    return gcn_agg_linear(frames, vg, c, S, rowptr, colidx, vals, bias, relu, tap, Wp, cout, out, nullptr, stream);
+}
+
+extern "C" int g4d_gcn_agg_linear_meta_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
+                                           const float *bias, int relu, float *tap, const float *Wp, int cout, float *out, const void *meta,
+                                           g4d_stream_t stream) {
+    return gcn_agg_linear(frames, vg, c, S, rowptr, colidx, vals, bias, relu, tap, Wp, cout, out, meta, stream);
+}
+
+static int gcn_agg_linear(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals, const float *bias, int relu,
+                          float *tap, const float *Wp, int cout, float *out, const void *meta, g4d_stream_t stream) {
     G4D_REQUIRE(frames >= 0 && vg >= 0, "g4d_gcn_agg_linear_f32: bad sizes");
     G4D_REQUIRE(c == kC, "g4d_gcn_agg_linear_f32: the support width must be %d (got %d)", kC, c);
     G4D_REQUIRE(cout == 128 || (cout >= 1 && cout <= 16), "g4d_gcn_agg_linear_f32: Cout must be 128 or <= 16 (got %d)", cout);
     if (frames == 0 || vg == 0) return G4D_OK;
     G4D_REQUIRE(S && rowptr && colidx && vals && Wp && out, "g4d_gcn_agg_linear_f32: null pointer");
-    static const int tile = [] { const char *e = getenv("G4D_GCN_TILE"); return e && atoi(e) == 64 ? 64 : 128; }();   // measured: 2.12 ms (128) vs 2.20 ms (64) per 4-layer stack at 240 x 4096 rows
+    const int tile = gcn_tile_rows();
     const int tpf = (vg + tile - 1) / tile;
     G4D_REQUIRE((long long)tpf * frames < (1ll << 30), "g4d_gcn_agg_linear_f32: too many tiles");
-    GcnFusedArgs a = {vg, frames, tpf, S, rowptr, colidx, vals, bias, relu, tap, Wp, cout, out};
+    GcnFusedArgs a = {vg, frames, tpf, S, rowptr, colidx, vals, bias, relu, tap, Wp, cout, out, static_cast<const int *>(meta)};
     const int per_xcd = (tpf * frames + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -95,6 +95,26 @@ def _to_csr(adj, device):
     return csr
 
 
+_meta_cache = {}
+_GCN_META = os.environ.get("G4D_GCN_META", "1") != "0"   # A/B switch: per-mesh tile metadata for the fused GCN launches
+
+
+def _tile_meta(rowptr, colidx, vals, nv):
+    """Per-mesh tile metadata of the fused GCN kernel (g4d_gcn_tile_meta_build: windows and padded CSR rows of every 128-vertex tile), built
+    once per adjacency -- keyed by the cached CSR tensors -- on the calling stream.  The adjacency of the refinement model is built in its
+    constructor and never changes (modules/mesh_encoder.py:288-307): every layer, frame and round reuses it."""
+    key = (rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), nv)
+    hit = _meta_cache.get(key)
+    if hit is not None and hit[0] is rowptr:
+        return hit[1]
+    if len(_meta_cache) > 32:
+        _meta_cache.clear()
+    meta = torch.empty(max(int(_lib.lib().g4d_gcn_tile_meta_bytes(nv)), 16), dtype=torch.uint8, device=rowptr.device)
+    _lib.call("g4d_gcn_tile_meta_build", nv, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), meta.data_ptr(), _lib.stream_ptr())
+    _meta_cache[key] = (rowptr, meta)
+    return meta
+
+
 class GraphConvolution(torch.nn.Module):
     """Simple GCN layer (Kipf & Welling): same parameters (`weight` (in,out), `bias` (out)) and init as the reference."""
 
@@ -222,6 +242,7 @@ def gcn_stack_forward(layers, x, adj, relu_last=False, keep=(), in_width=None):
     rowptr, colidx, vals, nv = _to_csr(adj, xb.device)
     assert nv == N, "adjacency size does not match the number of vertices"
     stream = _lib.stream_ptr()
+    meta = _tile_meta(rowptr, colidx, vals, nv) if _GCN_META else None
     h, S = xb, None    # S = support of the CURRENT layer (h W_i), when the previous launch already contracted it
     for i, m in enumerate(layers):
         L_support, _, bias = m._packed()
@@ -235,9 +256,9 @@ def gcn_stack_forward(layers, x, adj, relu_last=False, keep=(), in_width=None):
             Ln = nxt._packed()[0]
             tap = torch.empty((B, N, 128), dtype=torch.float32, device=xb.device) if i in keep else None
             S_next = torch.empty((B, N, nxt.out_features), dtype=torch.float32, device=xb.device)
-            _lib.call("g4d_gcn_agg_linear_f32", B, N, 128, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(),
+            _lib.call("g4d_gcn_agg_linear_meta_f32", B, N, 128, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(),
                       0 if bias is None else bias.data_ptr(), int(relu), 0 if tap is None else tap.data_ptr(), Ln.Wf.data_ptr(),
-                      nxt.out_features, S_next.data_ptr(), stream)                      # layers.py:46-55 of layer i, :42 of layer i+1
+                      nxt.out_features, S_next.data_ptr(), meta.data_ptr() if meta is not None else 0, stream)   # layers.py:46-55 of layer i, :42 of layer i+1
             outs[i] = tap if tap is None or not squeeze else tap[0]
             h, S = None, S_next
         else:

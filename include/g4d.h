@@ -315,6 +315,17 @@ int g4d_spmm_rows_f32(int frames, int vg, int c, const float *S, const int *rowp
 int g4d_gcn_agg_linear_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
                            const float *bias, int relu, float *tap, const float *Wp, int cout, float *out, g4d_stream_t stream);
 
+/* The same launch with per-MESH tile metadata (round 5): the window of neighbouring rows and the padded (column, weight) rows of every
+ * 128-vertex tile depend on the adjacency only -- the same for every frame, layer and refinement round -- so a caller that keeps the mesh
+ * builds them once (g4d_gcn_tile_meta_build into g4d_gcn_tile_meta_bytes(vg) bytes of device memory) and passes them here; the kernel's
+ * workgroups then skip three dependent round trips through the CSR arrays.  meta == NULL behaves as g4d_gcn_agg_linear_f32; results are
+ * identical either way.  (The adjacency of modules/mesh_encoder.py:288-307 is built in the model's constructor and never changes.) */
+long long g4d_gcn_tile_meta_bytes(int vg);
+int g4d_gcn_tile_meta_build(int vg, const int *rowptr, const int *colidx, const float *vals, void *meta, g4d_stream_t stream);
+int g4d_gcn_agg_linear_meta_f32(int frames, int vg, int c, const float *S, const int *rowptr, const int *colidx, const float *vals,
+                                const float *bias, int relu, float *tap, const float *Wp, int cout, float *out, const void *meta,
+                                g4d_stream_t stream);
+
 /* max (is_max=1) / mean over S consecutive rows, any S: in (groups*S, ldi) -> out (groups, ldo) at col0. */
 int g4d_pool_rows_f32(int groups, int s, int c, const float *in, int ldi, float *out, int ldo, int col0, int is_max,
                       g4d_stream_t stream);
