@@ -74,11 +74,13 @@ def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, tu
 
 
 @pytest.mark.parametrize("rows,K,Cout,relu,col0,extra,xpad", [(4096, 576, 512, True, 0, 0, 0), (5001, 512, 256, True, 0, 0, 0), (4100, 256, 384, False, 3, 9, 0),
-                                                              (3000, 260, 256, True, 0, 0, 0), (3000, 260, 256, True, 0, 0, 40), (2500, 132, 128, False, 0, 0, 4)])
+                                                              (3000, 260, 256, True, 0, 0, 0), (3000, 260, 256, True, 0, 0, 40), (2500, 132, 128, False, 0, 0, 4),
+                                                              (20000, 512, 512, True, 0, 0, 0), (70000, 128, 384, False, 0, 0, 0)])
 def test_tile_gemm_equals_lds_tiled_kernel(rows, K, Cout, relu, col0, extra, xpad):
     """csrc/gemm_tile.hip against linear_kernel: the same k order, so EQUAL; row counts that are not a multiple of 128, an output window inside
     a wider matrix, K = 260 (Kpad = 288: the last chunk is mostly padding), and an input that is a window of a wider matrix whose other
-    columns hold NaN (the chunk tail must be cleared, not multiplied by zero weights)."""
+    columns hold NaN (the chunk tail must be cleared, not multiplied by zero weights); more 128 x 128 tiles than resident workgroups (the
+    persistent kernel walks several tiles per workgroup, the block numbering has holes: 157 row blocks), K = 128 (four chunks per tile)."""
     g = torch.Generator().manual_seed(rows % 97)
     x = torch.randn(rows, K, generator=g).cuda()
     if xpad:

@@ -224,6 +224,36 @@ def test_gcn_agg_linear_tap_is_bit_identical_to_spmm():
                   0, L.Wf.data_ptr(), 128, out.data_ptr(), _lib.stream_ptr())
 
 
+@pytest.mark.parametrize("rc,numbering,cout", [((64, 64), "mesh", 128), ((20, 23), "mesh", 3), ((20, 23), "shuffled", 128), ((9, 7), "mesh", 128)])
+def test_gcn_agg_linear_with_and_without_tile_metadata(rc, numbering, cout):
+    """g4d_gcn_agg_linear_meta_f32 (windows and padded CSR rows of every tile built once per mesh by g4d_gcn_tile_meta_build) against
+    g4d_gcn_agg_linear_f32 (every workgroup derives its own): EQUAL outputs and taps -- mesh numbering (LDS window), a shuffled numbering
+    (tiles marked slow in the metadata: global gather), a vertex count that is not a multiple of the tile, a narrow next layer."""
+    from garment4d_amd import _lib, fused
+    verts, faces = syn.quad_cylinder(*rc)
+    Vg = verts.shape[0]
+    if numbering == "shuffled":
+        faces = np.random.default_rng(5).permutation(Vg)[faces]
+    adj = gcn_oracle.adjacency_from_faces(faces, Vg)
+    rowptr, colidx, vals, _ = G._to_csr(adj, torch.device("cuda"))
+    g = torch.Generator().manual_seed(Vg + cout)
+    S = torch.randn(3, Vg, 128, generator=g).cuda()
+    bias = torch.randn(128, generator=g).cuda()
+    Wn = (torch.randn(128, cout, generator=g) * 0.1).cuda()
+    L = fused.PackedLayer(Wn.t().contiguous(), torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda"), relu=False)
+    meta = torch.empty(int(_lib.lib().g4d_gcn_tile_meta_bytes(Vg)), dtype=torch.uint8, device="cuda")
+    _lib.call("g4d_gcn_tile_meta_build", Vg, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), meta.data_ptr(), _lib.stream_ptr())
+    outs = []
+    for m in (0, meta.data_ptr()):
+        tap = torch.full_like(S, float("nan"))
+        out = torch.full((3, Vg, cout), float("nan"), device="cuda")
+        _lib.call("g4d_gcn_agg_linear_meta_f32", 3, Vg, 128, S.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), bias.data_ptr(), 1,
+                  tap.data_ptr(), L.Wf.data_ptr(), cout, out.data_ptr(), m, _lib.stream_ptr())
+        outs.append((tap, out))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][1]).all()
+
+
 @pytest.mark.parametrize("fused_path", ["mfma", "one", "three", False])
 def test_lbs_fused_and_stepwise_paths_golden(golden_lbs, fused_path, tune):
     """All lbs() routes -- the matrix-pipe one (round 5), the one-launch kernel, the three-launch one (all three: joints from betas via
