@@ -7,14 +7,15 @@
 // Why: 295 KB of weights per 16-row tile.  The register-chain kernel streams them from L2 per wave: at 16 rows per wave the vector-memory
 // path is the bound (64 B / cycle / CU), at 32 rows per wave the 348 registers leave one wave per SIMD and every latency is exposed; both
 // run at 0.53 of the matrix pipe (447 us per 240-cloud call for 231 us of MFMA).  Here the four waves of a workgroup walk their 16-row tiles
-// in lock step and two k-steps' weight fragments at a time are copied L2 -> LDS once per workgroup (global_load_lds, double buffer, one
+// in lock step and two k-steps' weight fragments at a time are copied L2 -> LDS once per workgroup (buffer_load ... lds since round 5, double buffer, one
 // chunk ahead, one barrier per chunk), as in sa_table.hip; per-layer constants sit in LDS; (index, distance) of tile t + 2, the
 // interpolation weights / offsets and skip rows of tile t + 1 are prepared while tile t computes, and tile t + 1's starting accumulators
 // (the interpolated table) are built during tile t's middle layer, one channel tile per k-step.  Arithmetic and k order are the chain
-// kernel's: bit-identical results.  Measured: 432 us (one k-step per barrier: 449) -- a small gain only.  What still bounds it is open; ruled
-// out by A/B builds on the same box: stores in front of the chunk barriers (issued behind them instead: 444 us), the weight traffic itself
-// (8 waves per workgroup sharing a copy: 484 us -- one lock-stepped workgroup per CU has no partner to interleave with), L2 locality of the
-// table gathers (XCD-contiguous tile ranges: 450 us).
+// kernel's: bit-identical results.  Round 4 measured 432 us (one k-step per barrier: 449) and could not say what bounded it -- ruled out by
+// A/B builds: stores in front of the chunk barriers (behind them: 444 us), the weight traffic itself (8 waves sharing a copy: 484 us), L2
+// locality of the table gathers (XCD-contiguous tile ranges: 450 us).  Round 5 read the ISA (the comment at stage_issue_one below): scratch
+// spills behind every early gather, vmcnt(0) between a copy and the next ds_read, vmcnt(0) after every FLAT lds copy -- 428 -> 324 us, the
+// matrix pipe 0.52 -> 0.72 busy.
 #include <cstdlib>
 
 #include "mlp_common.h"

@@ -60,7 +60,7 @@ constexpr int kRingG = 6;
 //      of matrix pipe: 8 waves per CU ask the vector-memory path for 64 bytes per cycle, all it has -- the 128-wide stack (192 KB of
 //      weights) ran at 0.70 of the matrix pipe this way, the same as the register-chain kernel with 32 rows per wave and half the waves;
 //   2  the four waves of a workgroup walk their blocks in lock step and SHARE every fragment: a k-step's fragments (8 or 16 KB) are copied
-//      L2 -> LDS once per workgroup (global_load_lds, each wave a quarter) into a double buffer, one k-step ahead, one barrier per k-step;
+//      L2 -> LDS once per workgroup (buffer_load ... lds since round 5, each wave a quarter) into a double buffer, one k-step ahead, one barrier per k-step;
 //      the waves read them with ds_read_b128.  L2 traffic for weights drops 4x.
 template <int C, int S, int MT, int WM>
 __global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
