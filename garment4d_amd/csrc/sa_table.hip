@@ -47,6 +47,9 @@ __device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, 
 }
 
 constexpr int kStageK = 2;   // WM == 2: k-steps per staged chunk (one barrier per chunk)
+#ifndef G4D_SA64_OCC3
+#define G4D_SA64_OCC3 0   // experiment: the 64-wide, 32-sample stack (52 KB of LDS) at three workgroups per CU (<= 168 registers, 12 bytes of scratch): within 1 % on one box, off
+#endif
 #ifndef G4D_SA_TABLE_SPREAD
 #define G4D_SA_TABLE_SPREAD 1
 #endif
@@ -63,7 +66,7 @@ constexpr int kRingG = 6;
 //      L2 -> LDS once per workgroup (buffer_load ... lds since round 5, each wave a quarter) into a double buffer, one k-step ahead, one barrier per k-step;
 //      the waves read them with ds_read_b128.  L2 traffic for weights drops 4x.
 template <int C, int S, int MT, int WM>
-__global__ void __launch_bounds__(256, 2) sa_table_kernel(const SaTabArgs a) {
+__global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA64_OCC3) ? 3 : 2) sa_table_kernel(const SaTabArgs a) {
     constexpr bool WLDS = WM == 1;
     constexpr int T = C / 16, T3 = 2 * T;
     constexpr int R = 16 * MT;                       // rows per block
