@@ -24,6 +24,13 @@ namespace g4d {
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+#ifdef G4D_FPINIT_DEBUG
+__device__ long long g_fpinit_dbg[8 * 1024];   // per workgroup (first 1024), wave 0: cycles per phase summed over its tiles (scripts/dbg_fp_init_phases.py)
+#define G4D_FSTAMP(i) { if (threadIdx.x == 0 && blockIdx.x < 1024) { const long long now_ = (long long)__builtin_readcyclecounter(); g_fpinit_dbg[blockIdx.x * 8 + (i)] += now_ - dbg_last; dbg_last = now_; } }
+#else
+#define G4D_FSTAMP(i)
+#endif
+
 struct FpInitArgs {
     int rows, n, m;
     const float *skip;                    // (rows, C1 = 96)
@@ -116,9 +123,16 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
     // counts in issue order on gfx9): they may stay in flight across the barrier.  Only the chunk boundaries INSIDE layer 2 use it -- there the
     // only younger instructions are the unconditional table gathers of the chunk's second k-step (its first k-step's were requested ahead of the
     // copies, which follow them one per chain).
+#ifdef G4D_FPINIT_DEBUG
+    long long dbg_last = (long long)__builtin_readcyclecounter();
+#endif
     auto stage_step = [&](int c, int younger) {
-        if (younger == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        G4D_FSTAMP(0)   // compute since the last stamp
+        if (younger == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G4D_FSTAMP(1)   // own loads / copies landed
+        asm volatile("s_barrier" ::: "memory");
+        G4D_FSTAMP(2)   // barrier
     };
     // in front of MFMA chain `ct` of k-step gks (a layer with nt channel tiles): the next chunk's copy number (chain index within the chunk)
     auto copy_at = [&](int gks, int nt, int ct) {
@@ -198,6 +212,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
         }
     }
     for (int it = 0; it < iters; ++it) {
+        G4D_FSTAMP(3)   // tile epilogue (last layer's stores) + loop
         const int tile = tile_of(it);
         par0 = it & 1;
         const bool row_ok = tile * 16 + fi < a.rows && live(it);
@@ -268,7 +283,10 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
             }
             if (a.tap && row_ok) *reinterpret_cast<f32x4 *>(a.tap + orow * a.tap_ld + ct * 16 + fq * 4) = h2[ct];
         }
-        // ---- layer 3 (128 -> 128), normal orientation: lane (fi, fq) holds rows 4 fq + r of channel 16 ct + fi
+        // ---- layer 3 (128 -> 128), transposed like the two before it (round 5; the same products in the same k order as the normal orientation
+        //      of round 4, i.e. the same bits): lane (fi, fq) ends with channels 16 ct + 4 fq + r of row fi = ONE 16-byte store per channel
+        //      tile.  In the normal orientation the tile left through 32 dword stores per lane -- 12.6k of a tile's 110k cycles by the phase
+        //      stamps (scripts/dbg_fp_init_phases.py), the wave issuing nothing else meanwhile.
         f32x4 o[T3];
 #pragma unroll
         for (int ct = 0; ct < T3; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -288,20 +306,19 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 copy_at(K0 + T1 + ks, T3, ct);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[ks][e], w[e], o[ct], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], h2[ks][e], o[ct], 0, 0, 0);
             }
         }
         const bool tile_live = live(it);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ct = 0; ct < T3; ++ct) {
-            const float sc = s_sc3[ct * 16 + fi], sh = s_sh3[ct * 16 + fi];
+            if ((ct & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(s_sc3 + ct * 16 + fq * 4), sh = *reinterpret_cast<const f32x4 *>(s_sh3 + ct * 16 + fq * 4);
+            f32x4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y = fmaxf(__builtin_fmaf(o[ct][r], sc, sh), lo3);
-                const int row = tile * 16 + fq * 4 + r;
-                if (tile_live && row < a.rows) a.out[(size_t)row * a.ldo + ct * 16 + fi] = y;
-            }
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(__builtin_fmaf(o[ct][r], sc[r], sh[r]), lo3);
+            if (tile_live && row_ok) *reinterpret_cast<f32x4 *>(a.out + orow * a.ldo + ct * 16 + fq * 4) = y;   // (16-byte aligned: checked by the launcher)
         }
         cur = nxt;
         sk = skn;
@@ -311,6 +328,14 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
 }
 
 }  // namespace g4d
+
+#ifdef G4D_FPINIT_DEBUG
+extern "C" int g4d_fpinit_debug_read(long long *host_out, int clear) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g4d::g_fpinit_dbg), sizeof(long long) * 8 * 1024);
+    if (clear) { static long long z[8 * 1024]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g4d::g_fpinit_dbg), z, sizeof(z)); }
+    return rc;
+}
+#endif
 
 using namespace g4d;
 
@@ -326,6 +351,7 @@ int g4d::fp_init_try(long long rows, int n, int m, int C1_, const float *skip, c
     if (n < 16 || m <= 0 || rows % n != 0 || (rows / n) * (long long)m * tab_ld >= (1ll << 32) || tab_ld < C1 || (reinterpret_cast<size_t>(table) & 15) != 0) return -1;
     G4D_REQUIRE(skip && table && dist2 && nn_idx && out && W[0] && W[1] && W[2] && scale[0] && scale[1] && scale[2] && shift[0] && shift[1] && shift[2],
                 "g4d_mlp_chain_interp_init_f32: null pointer");
+    if (ldo % 4 != 0 || (reinterpret_cast<size_t>(out) & 15) != 0) return -1;   // (the last layer leaves through 16-byte stores)
     G4D_REQUIRE(ldo >= Cout[2] && (!tap_out || tap_ld >= Cout[1]) && tab_ld % 4 == 0, "g4d_mlp_chain_interp_init_f32: output row stride %d < %d channels, tap stride %d < %d or table stride %d not a multiple of 4",
                 ldo, Cout[2], tap_ld, Cout[1], tab_ld);
     FpInitArgs a;
