@@ -121,14 +121,13 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
     // chunk c of the tile: this wave's share has landed, everybody's has, nobody reads the other buffer any more; chunk c + 1 (the next tile's
     // first chunk after the last one) goes out.  `younger` = the vector-memory instructions this wave issued AFTER chunk c's copies (vmcnt
     // counts in issue order on gfx9): they may stay in flight across the barrier.  Only the chunk boundaries INSIDE layer 2 use it -- there the
-    // only younger instructions are the unconditional table gathers of the chunk's second k-step (its first k-step's were requested ahead of the
-    // copies, which follow them one per chain).
+    // only younger instructions are the unconditional table gathers of its two k-steps (requested BEHIND the wave's four copies of the chunk).
 #ifdef G4D_FPINIT_DEBUG
     long long dbg_last = (long long)__builtin_readcyclecounter();
 #endif
     auto stage_step = [&](int c, int younger) {
         G4D_FSTAMP(0)   // compute since the last stamp
-        if (younger == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (younger == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G4D_FSTAMP(1)   // own loads / copies landed
         asm volatile("s_barrier" ::: "memory");
@@ -248,19 +247,21 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
         Ctx nxt;
         Skip skn;
         f32x4 h1n[T1];
-        Item item[2];                                // the table rows of k-steps ks - 2 / ks - 1: two k-steps (2k matrix-pipe cycles) of cover per gather
+        constexpr int RING = 3;                      // the table rows of k-steps ks - 3 .. ks - 1 are in flight: a gather is consumed three k-steps after its request
+        Item item[RING];
 #pragma unroll
         for (int ks = 0; ks < T1; ++ks) {
             if (ks == 0) {                           // (ahead of the barrier's copies: older than them in the wave's memory queue)
                 nxt = make(tile_of(it + 1), rawn);
                 rawn = load_raw(tile_of(it + 2));
             }
-            stage_at(K0 + ks, ks >= 2 ? 3 : 0);
-            if (ks >= 2) {
-                h1n[ks - 2] = blend(nxt, item[ks & 1]);
-                asm volatile("" : "+v"(h1n[ks - 2]));   // the blend happens HERE (not sunk towards the loop latch with the raw rows kept alive)
+            // inner barriers (ks = 2, 4, ..): the copies of this chunk went out in chains 0..3 of k-step ks - 2; YOUNGER than them in the wave's
+            // memory queue are only the gathers of k-steps ks - 2 (requested in chain 4, behind the copies) and ks - 1: vmcnt(6)
+            stage_at(K0 + ks, ks >= 2 ? 6 : 0);
+            if (ks >= RING) {
+                h1n[ks - RING] = blend(nxt, item[ks % RING]);
+                asm volatile("" : "+v"(h1n[ks - RING]));   // the blend happens HERE (not sunk towards the loop latch with the raw rows kept alive)
             }
-            item[ks & 1] = load_item(nxt, ks);
             sring[0] = sfrag(K0 + ks, T2, 0); sring[1] = sfrag(K0 + ks, T2, 1);
 #pragma unroll
             for (int ct = 0; ct < T2; ++ct) {
@@ -268,6 +269,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
                 if (ct + 2 < T2) sring[ct & 1] = sfrag(K0 + ks, T2, ct + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 copy_at(K0 + ks, T2, ct);
+                if (ct == KSC * T2 / 4) item[ks % RING] = load_item(nxt, ks);   // behind this wave's copies of the chunk (chains 0 .. 3 of its first k-step)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], h1[ks][e], h2[ct], 0, 0, 0);
             }
@@ -293,9 +295,9 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
 #pragma unroll
         for (int ks = 0; ks < T2; ++ks) {
             stage_at(K0 + T1 + ks);
-            if (ks == 0) {
-                h1n[T1 - 2] = blend(nxt, item[0]); h1n[T1 - 1] = blend(nxt, item[1]);
-                asm volatile("" : "+v"(h1n[T1 - 2]), "+v"(h1n[T1 - 1]));
+            if (ks == 0) {                            // the last RING gathers of layer 2 (complete: the barrier above waited for everything)
+#pragma unroll
+                for (int q = T1 - RING; q < T1; ++q) { h1n[q] = blend(nxt, item[q % RING]); asm volatile("" : "+v"(h1n[q])); }
                 skn = load_skip(tile_of(it + 1));
             }
             sring[0] = sfrag(K0 + T1 + ks, T3, 0); sring[1] = sfrag(K0 + T1 + ks, T3, 1);
