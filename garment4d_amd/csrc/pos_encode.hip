@@ -50,8 +50,11 @@ __device__ __forceinline__ f32x4 ldf4(const float *base, unsigned elem) {
 // -- exactly the A-operand layout layer 2 wants (above), and the same k-ascending FMA chain as the VALU form (bit-identical).  A lane then loads only
 // the ONE input component per k-step it feeds (4 bytes instead of three 12-byte rows), holds 4 weight registers instead of 8 KX, and the layer costs
 // 8-16 MFMAs + 32 v_max per 64 rows instead of 32 (KX + 2) VALU instructions (VALU work is ADDED to the matrix pipe's time on this chip).
+#ifndef G4D_PE_PIPE_OCC4
+#define G4D_PE_PIPE_OCC4 1
+#endif
 template <int E, bool TABLE, bool SBIG, bool PIPE, bool L1M>  // PIPE: software-pipelined gathers (pays for the table rows, costs occupancy otherwise); SBIG: nsample >= 16, a 16-row tile belongs to ONE query -> its centre is wave-uniform
-__global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
+__global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC4) ? 4 : 2) pos_encode_kernel(const PeArgs a) {
     constexpr int KX = 3 + E;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fi = lane & 15, fq = lane >> 4;
@@ -262,8 +265,11 @@ __global__ void __launch_bounds__(256, 2) pos_encode_kernel(const PeArgs a) {
 template <bool TABLE, bool SBIG>
 static void launch_pe(int E, dim3 grid, hipStream_t st, const PeArgs &a) {
     static const int pipe_env = getenv("G4D_PE_PIPE") ? atoi(getenv("G4D_PE_PIPE")) : -1;  // tuning hook: 0 | 1, default by variant
-    const bool pipe = pipe_env >= 0 ? pipe_env != 0 : (TABLE && E == 0);                 // measured: +10 % with a table, -17 % without
     static const int l1m_env = getenv("G4D_PE_L1_MFMA") ? atoi(getenv("G4D_PE_L1_MFMA")) : 1;   // A/B switch: layer 1 on the matrix pipe (round 5)
+    // round 4 measured the pipelined gathers at +10 % with a table and -17 % without (157 registers: three waves per SIMD instead of four).
+    // With layer 1 on the matrix pipe the pipelined form without a table fits 128 registers (launch bounds: four waves per SIMD) and wins
+    // there too: body encoders 901 / 446 / 241 -> 852 / 422 / 230 us at 240 frames x 4096 garment vertices, S = 32 / 16 / 8.
+    const bool pipe = pipe_env >= 0 ? pipe_env != 0 : (l1m_env ? true : (TABLE && E == 0));
 #define G4D_PE_LAUNCH(EE, PP, LL) hipLaunchKernelGGL((pos_encode_kernel<EE, TABLE, SBIG, PP, LL>), grid, dim3(256), 0, st, a)
 #define G4D_PE_CASE(EE)                                                                                     \
     case EE:                                                                                                \
