@@ -102,25 +102,26 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) iv[mt] = a.idx[row0 + min(mt * 16 + fi, rows - 1 - row0)];
     };
-    auto load_rows = [&](int chunk, const int (&iv)[4], Raw &rw) {
+    // The rows of a chunk, one 16-row tile (mt) at a time: the pipelined form requests tile mt of the NEXT chunk between the MFMA groups of
+    // layer 2's column steps (round 5: issued as one burst of up to 24 loads at the top of a chunk they held the wave's in-order issue while the
+    // 12-16 waves of a CU queued at its vector-memory path; gemm_tile.hip has the measurement).
+    auto load_rows_mt = [&](int chunk, const int (&iv)[4], Raw &rw, int mt) {
         const int row0 = __builtin_amdgcn_readfirstlane(min(chunk, nchunks - 1) << 6);
         const int q0 = row0 >> a.logS;                // first query of the chunk (uniform)
         const int f0 = q0 / a.p;                      // its frame: one scalar division per chunk
         const int qnext = (f0 + 1) * a.p;             // first query of the next frame (a chunk touches <= 2 frames, see launcher)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int r = min(mt * 16 + fi, rows - 1 - row0);  // clamp the tail chunk onto the last valid row
-            int qi = (row0 + r) >> a.logS;
-            if (SBIG) qi = __builtin_amdgcn_readfirstlane(qi);
-            const int f = f0 + (qi >= qnext ? 1 : 0);
-            const unsigned src = (unsigned)(f * a.n + iv[mt]);
-            if constexpr (L1M) {
-                const unsigned fq2 = (unsigned)min(fq, 2);
-                rw.c0[mt] = ldf(a.xyz, src * 3 + fq2);               // in[4 kk + fq]: kk = 0 -> dx | dy | dz | extra 0
-                rw.q0[mt] = ldf(a.new_xyz, (unsigned)qi * 3 + fq2);
-                if (E > 0) rw.e0[mt] = ldf(a.extra, src * E);
-                if (E > 1) rw.c1[mt] = ldf(a.extra, src * E + (unsigned)min(1 + fq, E - 1));   // kk = 1 -> extra 1 + fq (0 beyond E)
-            } else {
+        const int r = min(mt * 16 + fi, rows - 1 - row0);  // clamp the tail chunk onto the last valid row
+        int qi = (row0 + r) >> a.logS;
+        if (SBIG) qi = __builtin_amdgcn_readfirstlane(qi);
+        const int f = f0 + (qi >= qnext ? 1 : 0);
+        const unsigned src = (unsigned)(f * a.n + iv[mt]);
+        if constexpr (L1M) {
+            const unsigned fq2 = (unsigned)min(fq, 2);
+            rw.c0[mt] = ldf(a.xyz, src * 3 + fq2);               // in[4 kk + fq]: kk = 0 -> dx | dy | dz | extra 0
+            rw.q0[mt] = ldf(a.new_xyz, (unsigned)qi * 3 + fq2);
+            if (E > 0) rw.e0[mt] = ldf(a.extra, src * E);
+            if (E > 1) rw.c1[mt] = ldf(a.extra, src * E + (unsigned)min(1 + fq, E - 1));   // kk = 1 -> extra 1 + fq (0 beyond E)
+        } else {
             rw.px[mt] = ldf3(a.xyz, src * 3);
             rw.pq[mt] = ldf3(a.new_xyz, (unsigned)qi * 3);
             if (E == 3) rw.pe[mt] = ldf3(a.extra, src * 3);
@@ -128,12 +129,15 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
 #pragma unroll
                 for (int e = 0; e < E; ++e) rw.ex[mt][e] = ldf(a.extra, src * E + e);
             }
-            }
-            if (TABLE) {
-                rw.t[mt][0] = ldf4(a.table, src * 32 + fq * 4);
-                rw.t[mt][1] = ldf4(a.table, src * 32 + 16 + fq * 4);
-            }
         }
+        if (TABLE) {
+            rw.t[mt][0] = ldf4(a.table, src * 32 + fq * 4);
+            rw.t[mt][1] = ldf4(a.table, src * 32 + 16 + fq * 4);
+        }
+    };
+    auto load_rows = [&](int chunk, const int (&iv)[4], Raw &rw) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) load_rows_mt(chunk, iv, rw, mt);
     };
     int chunk = blockIdx.x * 4 + wave;
     int iv_next[4];
@@ -145,10 +149,9 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
     }
     for (; chunk < nchunks; chunk += stride) {
         const int row0 = __builtin_amdgcn_readfirstlane(chunk << 6);
+        int iv_nn[4];                                      // PIPE: indices of chunk + 2 (requested at the last column step; iv_next is still being read until then)
         if (PIPE) {
-            load_rows(chunk + stride, iv_next, nxt);       // level 2 of the next chunk
-            load_idx(chunk + 2 * stride, iv_next);         // level 1 of the one after
-            __builtin_amdgcn_sched_barrier(0);             // (left alone the scheduler sinks these requests below the chunk's MFMAs, right in front of their use)
+            // (level 2 of the next chunk and level 1 of the one after go out between the column steps below)
         } else {
             load_idx(chunk, iv_next);
             load_rows(chunk, iv_next, cur);
@@ -207,6 +210,12 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
         // k ascending per accumulator (ks, e) as before; eight independent accumulators between two MFMAs on the same one
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
+            if constexpr (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if ((c8 & 1) == 0) load_rows_mt(chunk + stride, iv_next, nxt, c8 >> 1);
+                if (c8 == 7) load_idx(chunk + 2 * stride, iv_nn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (c8 + 1 < 8) column(c8 + 1, afc[(c8 + 1) & 1]);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -221,7 +230,11 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
                 }
             }
         }
-        if (PIPE) cur = nxt;
+        if (PIPE) {
+            cur = nxt;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) iv_next[mt] = iv_nn[mt];
+        }
         // max over the S rows of each query; acc[mt][ct][r] = row 16 mt + 4 fq + r, channel 16 ct + fi
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
