@@ -139,20 +139,22 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) load_rows_mt(chunk, iv, rw, mt);
     };
-    int chunk = blockIdx.x * 4 + wave;
-    int iv_next[4];
-    Raw cur, nxt;
+    int chunk0 = blockIdx.x * 4 + wave;
+    int iv_a[4], iv_b[4];
+    Raw ra, rb;
     if (PIPE) {
-        load_idx(chunk, iv_next);
-        load_rows(chunk, iv_next, cur);
-        load_idx(chunk + stride, iv_next);
+        load_idx(chunk0, iv_a);
+        load_rows(chunk0, iv_a, ra);
+        load_idx(chunk0 + stride, iv_a);
     }
-    for (; chunk < nchunks; chunk += stride) {
+    // One chunk.  PIPE: rows `cur` (requested a chunk ago) through the layers while the next chunk's rows arrive in `nxt` (through the indices
+    // iv_next, requested two chunks ago) and the indices of the chunk after that in iv_nn.  The loop below runs chunks in PAIRS with the two row
+    // buffers and the two index arrays swapping roles (round 5: `cur = nxt` at the end of a chunk needed the prefetched rows a few hundred cycles
+    // after the last of them had been requested).  A chunk past the wave's last one computes on clamped rows and stores nothing (its first_row
+    // tests fail).
+    auto do_chunk = [&](int chunk, Raw &cur, Raw &nxt, int (&iv_next)[4], int (&iv_nn)[4]) {
         const int row0 = __builtin_amdgcn_readfirstlane(chunk << 6);
-        int iv_nn[4];                                      // PIPE: indices of chunk + 2 (requested at the last column step; iv_next is still being read until then)
-        if (PIPE) {
-            // (level 2 of the next chunk and level 1 of the one after go out between the column steps below)
-        } else {
+        if (!PIPE) {
             load_idx(chunk, iv_next);
             load_rows(chunk, iv_next, cur);
         }
@@ -230,11 +232,7 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
                 }
             }
         }
-        if (PIPE) {
-            cur = nxt;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) iv_next[mt] = iv_nn[mt];
-        }
+
         // max over the S rows of each query; acc[mt][ct][r] = row 16 mt + 4 fq + r, channel 16 ct + fi
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -272,6 +270,14 @@ __global__ void __launch_bounds__(256, (PIPE && !TABLE && L1M && G4D_PE_PIPE_OCC
                 }
             }
         }
+    };
+    if constexpr (PIPE) {
+        for (int chunk = chunk0; chunk < nchunks; chunk += 2 * stride) {
+            do_chunk(chunk, ra, rb, iv_a, iv_b);                 // iv_a: indices of chunk + stride; iv_b <- indices of chunk + 2 stride
+            do_chunk(chunk + stride, rb, ra, iv_b, iv_a);        // (past the wave's last chunk: nothing stored)
+        }
+    } else {
+        for (int chunk = chunk0; chunk < nchunks; chunk += stride) do_chunk(chunk, ra, rb, iv_a, iv_b);
     }
 }
 
