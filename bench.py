@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--input-pool-mb", type=float, default=320.0, help="distinct input clouds rotated through, in MB (0 = replay the "
                                                                        "same resident batches: MALL-warm inputs)")
     ap.add_argument("--no-lbs", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin` leg (the reference's operator-API call forms through the same executor)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="bf16 = BASELINE config 3: shared-MLP operands in bf16 (fp32 accumulate); default fp32 = config 2")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for "
@@ -587,6 +588,62 @@ def main():
             lat = alone(one, 1)
             lat_call = alone(pipe, kco)                  # one coalesced call alone (includes its kco input copies)
             del one
+        # The drop-in route (north_star: "keeping the pointnet2_utils / PointnetSAModule / PointnetFPModule operator API so
+        # modules/pointnet2encoder.py ... load it as a drop-in"): the same executor, the same inputs, but each call is the REFERENCE'S call form
+        #   (a) model(pc)  -- Pointnet2MSGSEG.forward, which in eval() + no_grad dispatches to the fused call graph and converts every returned
+        #       feature tensor to the reference's (B, C, N) layout, and
+        #   (b) the reference's own loop over SA_modules / FP_modules / FC_layer (pointnet2encoder.py:127-141), every module dispatching on its
+        #       own (no cross-level launch sharing), twins carrying the point-major layout between modules.
+        dropin = None
+        if rank == 0 and world == 1 and not args.no_dropin:
+            from garment4d_amd import tuning as _tuning
+
+            def dropin_rate(tun, seconds):
+                pp = StepPipeline(model, smpl, clouds_per_step=B_CLOUDS, n_points=N_POINTS, coalesce=kco, streams=ns, precision=args.precision,
+                                  device=dev, use_graph=not args.no_graph, tuning=tun, encoder_call=lambda m, pc: m(pc)[1])
+
+                def steps(n):
+                    for k in range(n):
+                        if pose_pool is None:
+                            pp.submit(pool[k % npool], inputs_ready=True)
+                        else:
+                            pp.submit(pool[k % npool], *pose_pool[k % len(pose_pool)], inputs_ready=True)
+                    pp.synchronize()
+                    torch.cuda.synchronize()
+                steps(kco * ns)                              # first replays
+                n = kco * ns
+                while True:
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    steps(n)
+                    d_ = time.perf_counter() - t0_
+                    if d_ >= seconds or n >= 1 << 22:
+                        break
+                    n = int(np.ceil(n * seconds / max(d_, 1e-6) * 1.15 / kco)) * kco
+                # one eager call alone on one stream, as a script that just calls model(pc) in a loop would see it
+                cl = pp.slots[0]
+                with _tuning.use(tun):
+                    ts = []
+                    for _ in range(5):
+                        torch.cuda.synchronize()
+                        t1_ = time.perf_counter()
+                        pp._call(cl)
+                        torch.cuda.synchronize()
+                        ts.append(time.perf_counter() - t1_)
+                del pp
+                return n * B_CLOUDS / d_, float(np.median(ts)) * 1e3
+            t_model = _tuning.current()
+            v_model, ms_model = dropin_rate(t_model, 1.5)
+            v_mods, ms_mods = dropin_rate(t_model.replace(dropin_whole_model=False), 1.5)
+            ex = args.steps * repeats * B_CLOUDS / dt
+            dropin = {"value": v_model, "unit": "frames/s", "ratio_to_executor": v_model / ex,
+                      "route": "middle, sem_logits, l_features, l_xyz = model(pc) in eval() + torch.no_grad() (the reference's forward contract: (B, C, N) features, "
+                               "pointnet2encoder.py:112-145) + lbs(); same executor settings, same inputs as `value`",
+                      "eager_one_stream_ms_per_call": ms_model,
+                      "modules_value": v_mods, "modules_ratio_to_executor": v_mods / ex, "modules_eager_one_stream_ms_per_call": ms_mods,
+                      "modules_route": "the reference's loop SA_modules[i](xyz, features) / FP_modules[i](...) / FC_layer(...) over this package's modules "
+                                       "(pointnet2encoder.py:127-141), each module dispatching to its fused kernels on its own, + lbs()",
+                      "clouds_per_call": B_CLOUDS * kco, "calls_in_flight": ns}
         table = roof = None
         if rank == 0:
             table, roof, call_us = launch_table(model, smpl, pose_pool, pool, kco, args.precision)
@@ -623,6 +680,7 @@ def main():
                                    ("torch.distributed.run" if world > 1 else "single process"),
                        "distance_contraction": __import__("garment4d_amd.numerics", fromlist=["x"]).get_distance_contraction(),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "dropin": dropin,
             "roofline": roof.get("roofline"), "roofline_mfma_all": roof.get("roofline_mfma_all"), "roofline_fps": roof.get("roofline_fps"),
             "roofline_hbm": roof.get("roofline_hbm"),
             "launches": {"clouds_per_call": B_CLOUDS * kco, "eager_one_stream_us": call_us, "note": "one coalesced call launched eagerly on one stream, HIP events around every "

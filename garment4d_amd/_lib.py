@@ -80,6 +80,7 @@ SIGNATURES = {
                            _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_group_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
+    "g4d_sa_table_supported": [ctypes.c_longlong, _I, _I, _I],
     "g4d_three_nn_cells_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_mlp_chain_interp_init_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_three_nn_multi_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

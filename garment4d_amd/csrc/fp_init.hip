@@ -125,9 +125,15 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
 #ifdef G4D_FPINIT_DEBUG
     long long dbg_last = (long long)__builtin_readcyclecounter();
 #endif
+    // The count is tied to the code that issues those gathers: load_item() is kItemLoads (= 3: one 16-byte gather per neighbour, struct Item) vector-
+    // memory instructions and kYoungerItems (= 2) of them are younger than the copies.  A change of Item's layout breaks the static_asserts below
+    // instead of silently shortening the wait; a compiler that merged or reordered these loads would be caught by the bit-identity test against
+    // fp_init_persistent = 0 (tests/test_large_launch_gpu.py), which runs for every build.
+    constexpr int kItemLoads = 3, kYoungerItems = 2, kYounger = kItemLoads * kYoungerItems;
+    static_assert(kYounger == 6, "stage_step's s_waitcnt immediate below is written for 6 younger gathers");
     auto stage_step = [&](int c, int younger) {
         G4D_FSTAMP(0)   // compute since the last stamp
-        if (younger == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (younger == kYounger) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G4D_FSTAMP(1)   // own loads / copies landed
         asm volatile("s_barrier" ::: "memory");
@@ -175,6 +181,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
         return k;
     };
     struct Item { f32x4 t0, t1, t2; };
+    static_assert(sizeof(Item) == kItemLoads * sizeof(f32x4), "one 16-byte gather per member: stage_step counts them (vmcnt)");
     auto load_item = [&](const Ctx &c, int ct) {
         Item x;
         x.t0 = *reinterpret_cast<const f32x4u *>(a.tab + c.k0 + ct * 16);
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) fp_init_kernel(const FpInitArgs a) {
             }
             // inner barriers (ks = 2, 4, ..): the copies of this chunk went out in chains 0..3 of k-step ks - 2; YOUNGER than them in the wave's
             // memory queue are only the gathers of k-steps ks - 2 (requested in chain 4, behind the copies) and ks - 1: vmcnt(6)
-            stage_at(K0 + ks, ks >= 2 ? 6 : 0);
+            stage_at(K0 + ks, ks >= 2 ? kYounger : 0);
             if (ks >= RING) {
                 h1n[ks - RING] = blend(nxt, item[ks % RING]);
                 asm volatile("" : "+v"(h1n[ks - RING]));   // the blend happens HERE (not sunk towards the loop latch with the raw rows kept alive)

@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64 * kOneKS) lbs_one_kernel(int B, int V, int 
                 for (int k = 0; k < 9; ++k) sC[(size_t)(NB + (l - 1) * 9 + k) * kFB + f] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
             }
         }
-        if (l < NB) sC[(size_t)l * kFB + f] = betas[(size_t)b * betas_bstride + l];
+        for (int i = l; i < NB; i += 64) sC[(size_t)i * kFB + f] = betas[(size_t)b * betas_bstride + i];   // (NB may exceed the 64 lanes: few joints, many betas)
         wave_sync_lds();
         if (l < J) {  // local transform [R | J - J_parent]  (lbs.py:390-396)
             const int p = parents[l];
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) lbs_frame_kernel(int B, int J, int NB, in
             for (int k = 0; k < 9; ++k) C_[NB + (l - 1) * 9 + k] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f);
         }
     }
-    if (l < NB) C_[l] = betas[(size_t)b * betas_bstride + l];
+    for (int i = l; i < NB; i += 64) C_[i] = betas[(size_t)b * betas_bstride + i];   // (NB may exceed the 64 lanes: few joints, many betas)
     wave_sync_lds();
     if (l < J) {  // local transform [R | J - J_parent]  (lbs.py:390-396)
         const int p = parents[l];

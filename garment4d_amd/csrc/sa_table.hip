@@ -437,16 +437,26 @@ static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
     return check_launch("g4d_sa_table");
 }
 
+// The ONE statement of which launches the persistent kernel takes: the instantiated (Kt, S) pairs below, max pooling, enough rows to pipeline,
+// and the calling thread's tuning state (A/B switches).  sa_table_try() and the host-side dispatch (fused.py: the xyz-only route hands over a
+// table with row stride 0, which only this kernel reads) both ask here, so they cannot disagree.
+extern "C" int g4d_sa_table_supported(long long rows, int Kt, int S, int pool) {
+    const int on = (int)g4d::tuning("sa_table_persistent", 1);                 // A/B switch
+    const long long min_rows = g4d::tuning("sa_table_min_rows", 262144);       // ~4 blocks of 32 rows per resident wave
+    if (!on || pool != 1 || S <= 0 || rows < min_rows || rows >= (1ll << 31) - 64 || rows % S != 0) return 0;
+    if ((Kt == 32 && (S == 16 || S == 32)) || (Kt == 64 && (S == 16 || S == 32 || S == 64))) return 1;
+    const int wide = (int)g4d::tuning("sa_table_128", 1);                      // the 128-wide stack (weights streamed from L2: 192 KB do not fit LDS)
+    return (wide && Kt == 128 && (S == 32 || S == 64)) ? 1 : 0;
+}
+
 // Takes the launch if it is one of the instantiated shapes and large enough to pipeline (several row blocks per resident wave);
 // returns -1 when it is not (the caller then runs the register-chain kernel), else the launch status.
 int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld,
                       int Kt, const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W,
                       const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
                       int ldo, int col0, hipStream_t st) {
-    const int on = (int)tuning("sa_table_persistent", 1);                 // A/B switch
-    const long long min_rows = tuning("sa_table_min_rows", 262144);       // ~4 blocks of 32 rows per resident wave
-    if (!on || pool != 1 || nlayers != 2 || rows < min_rows || rows >= (1ll << 31) - 64 || rows % S != 0) return -1;
-    if (!(Kt == 32 || Kt == 64 || Kt == 128) || Cout[0] != Kt || Cout[1] != 2 * Kt || !relu[0] || !relu[1] || Kpad[0] != Kt || Kpad[1] != Kt) return -1;
+    if (nlayers != 2 || !g4d_sa_table_supported(rows, Kt, S, pool)) return -1;
+    if (Cout[0] != Kt || Cout[1] != 2 * Kt || !relu[0] || !relu[1] || Kpad[0] != Kt || Kpad[1] != Kt) return -1;
     if ((long long)(rows / S / P) * N >= (1ll << 31)) return -1;
     G4D_REQUIRE(xyz && new_xyz && idx && table && tab_wx && pre_scale && pre_shift && out && W[0] && W[1] && scale[0] && scale[1] && shift[0] && shift[1],
                 "g4d_mlp_chain_group_table_f32: null pointer");

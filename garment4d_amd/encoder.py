@@ -4,9 +4,12 @@ the reference's `Pointnet2MSGSEG` (/root/reference/modules/pointnet2encoder.py:1
 config 2 quotes the metric on (`input_channels=0, global_feat=False`, as instantiated at
 modules/mesh_encoder.py:49).
 
-forward()        -- op-by-op path (HIP ops + torch SharedMLP): trainable, returns exactly what the reference's
-                    forward returns (middle_features, sem_logits, l_features, l_xyz), channel-major features.
-forward_fused()  -- eval-mode inference on the fused HIP kernels; activations stay point-major in HBM.
+forward()        -- the reference's signature and return contract (middle_features, sem_logits, l_features, l_xyz) with
+                    channel-major features.  In eval() mode under torch.no_grad() on fp32 HIP tensors it RUNS THE FUSED
+                    KERNELS (the same call graph as forward_fused, converted to (B, C, N) at the edge, each returned tensor
+                    carrying its point-major twin); in training mode / with autograd on it is the op-by-op path (HIP ops +
+                    torch SharedMLP), which is trainable.
+forward_fused()  -- eval-mode inference on the fused HIP kernels; activations stay point-major in HBM (no conversion).
 
 Unlike the reference module, importing this file has no side effects (the reference parses sys.argv and
 loads cfgs/*.yaml at import time through utils/config.py:129).
@@ -17,7 +20,7 @@ import torch.nn as nn
 from . import fused
 from . import pytorch_utils as pt_utils
 from .tuning import current as _T
-from .pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+from .pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG, fused_route
 
 CLASS_NUM = 7  # utils/dataloader.py:24
 
@@ -57,6 +60,12 @@ class Pointnet2MSGSEG(nn.Module):
 
     def forward(self, pointcloud: torch.Tensor):
         """pointcloud (B, N, 3 + input_channels) -> (middle_features, sem_logits (B,N,classes), l_features, l_xyz)."""
+        stacks = [m for sa in self.SA_modules for m in sa.mlps] + [fp.mlp for fp in self.FP_modules] + [self.FC_layer]
+        if self.global_feat:
+            stacks += list(self.Middle_modules.mlps)
+        if _T().dropin_whole_model and fused_route(self, stacks, pointcloud) and all(sa.pool_method in ("max_pool", "avg_pool") for sa in self.SA_modules):
+            # the drop-in route of north_star: same kernels and launches as forward_fused(); precision = the fused.precision() in force (fp32)
+            return self._forward_fused(pointcloud.contiguous(), channel_major=True)
         xyz, features = self._break_up_pc(pointcloud)
         l_xyz, l_features = [xyz], [features]
         for sa in self.SA_modules:
@@ -166,8 +175,8 @@ class Pointnet2MSGSEG(nn.Module):
         l_feats[0], sem_logits = fused.fp_forward(self.FP_modules[0], l_xyz[0], l_xyz[1], l_feats[0], l_feats[1],
                                                   head=self.FC_layer, unknown_grid=grid0, table=table0)  # logits (B, N, classes)
         if channel_major:
-            l_feats = [None if f is None else fused.to_channel_major(f) for f in l_feats]
-            middle = None if middle is None else fused.to_channel_major(middle)
+            l_feats = [None if f is None else fused.channel_major_with_twin(f) for f in l_feats]
+            middle = None if middle is None else fused.channel_major_with_twin(middle)
         return middle, sem_logits, l_feats, l_xyz
 
 

@@ -110,41 +110,58 @@ def _unwrap_bn(m):
     return m.bn if isinstance(m, nn.Sequential) and hasattr(m, "bn") else m
 
 
+def _pack_block(block):
+    """One pytorch_utils.Conv{1,2}d block -> PackedLayer (no caching)."""
+    conv = getattr(block, "conv", None)
+    names = [n for n, _ in block.named_children()]
+    act = getattr(block, "activation", None)
+    # pytorch_utils.py:35-101 also builds pre-activation blocks, instance norm and arbitrary activations; the reference's models
+    # (pointnet2encoder.py, mesh_encoder.py) never do.  Those variants run on the op-by-op path (module.forward(): HIP grouping /
+    # sampling ops + torch layers), which supports everything the constructors accept -- say so instead of computing something else.
+    if conv is None or conv.kernel_size not in ((1,), (1, 1)) or conv.stride not in ((1,), (1, 1)) or conv.padding not in ((0,), (0, 0)):
+        raise NotImplementedError("fused path: 1x1 convolution blocks only; call the module's own forward() for this stack")
+    if names[0] != "conv":
+        raise NotImplementedError("fused path: post-activation blocks only (preact=False); call the module's own forward()")
+    if "in" in names:
+        raise NotImplementedError("fused path: instance norm needs per-sample statistics; call the module's own forward()")
+    if not (act is None or isinstance(act, nn.ReLU)):
+        raise NotImplementedError(f"fused path: ReLU or no activation only (got {type(act).__name__}); call the module's own forward()")
+    bn = _unwrap_bn(block.bn) if "bn" in names else None
+    scale, shift = _fold(conv, bn)
+    w2 = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
+    return PackedLayer(w2, scale, shift, relu=act is not None)
+
+
+def _param_key(m):
+    return tuple((p.data_ptr(), p._version) for p in list(m.parameters()) + list(m.buffers()))
+
+
 def pack_conv_stack(stack):
     """Pack an nn.Sequential of pytorch_utils.Conv{1,2}d blocks (SharedMLP, FC head).  Dropout is an
     eval-mode no-op.  Cached on the module, keyed by the parameters' version counters."""
-    key = tuple((p.data_ptr(), p._version) for p in list(stack.parameters()) + list(stack.buffers()))
+    key = _param_key(stack)
     cached = getattr(stack, "_g4d_packed", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    layers = []
     with torch.no_grad():
-        for block in stack.children():
-            if isinstance(block, nn.Dropout):
-                continue
-            conv = getattr(block, "conv", None)
-            names = [n for n, _ in block.named_children()]
-            act = getattr(block, "activation", None)
-            # pytorch_utils.py:35-101 also builds pre-activation blocks, instance norm and arbitrary activations; the reference's models
-            # (pointnet2encoder.py, mesh_encoder.py) never do.  Those variants run on the op-by-op path (module.forward(): HIP grouping /
-            # sampling ops + torch layers), which supports everything the constructors accept -- say so instead of computing something else.
-            if conv is None or conv.kernel_size not in ((1,), (1, 1)):
-                raise NotImplementedError("fused path: 1x1 convolution blocks only; call the module's own forward() for this stack")
-            if names[0] != "conv":
-                raise NotImplementedError("fused path: post-activation blocks only (preact=False); call the module's own forward()")
-            if "in" in names:
-                raise NotImplementedError("fused path: instance norm needs per-sample statistics; call the module's own forward()")
-            if not (act is None or isinstance(act, nn.ReLU)):
-                raise NotImplementedError(f"fused path: ReLU or no activation only (got {type(act).__name__}); call the module's own forward()")
-            bn = _unwrap_bn(block.bn) if "bn" in names else None
-            scale, shift = _fold(conv, bn)
-            w2 = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
-            layers.append(PackedLayer(w2, scale, shift, relu=act is not None))
+        layers = [_pack_block(block) for block in stack.children() if not isinstance(block, nn.Dropout)]
     stack._g4d_packed = (key, layers)
     return layers
 
 
-_CACHE_ATTRS = ("_g4d_packed", "_g4d_split", "_g4d_pe", "_g4d_table", "_g4d_sa_table", "_g4d_fp_split")
+def pack_conv_block(block):
+    """One block packed and cached ON THE BLOCK (the drop-in forward of pytorch_utils.Conv1d): PackedLayer."""
+    key = _param_key(block)
+    cached = getattr(block, "_g4d_packed_block", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    with torch.no_grad():
+        layer = _pack_block(block)
+    block._g4d_packed_block = (key, layer)
+    return layer
+
+
+_CACHE_ATTRS = ("_g4d_packed", "_g4d_packed_block", "_g4d_split", "_g4d_pe", "_g4d_table", "_g4d_sa_table", "_g4d_fp_split")
 
 
 def invalidate(module):
@@ -177,6 +194,32 @@ def to_channel_major(x):
     out = torch.empty((B, C, N), dtype=torch.float32, device=x.device)
     _lib.call("g4d_transpose_f32", B, N, C, x.data_ptr(), out.data_ptr(), _lib.stream_ptr())
     return out
+
+
+def attach_twin(cm, pm):
+    """Remember on the channel-major tensor `cm` (B, C, N) -- what the reference's operator API returns -- the point-major tensor `pm`
+    (B, N, C) the kernels produced it from, so that the next drop-in module of a chain (pointnet2encoder.py:127-140 feeds level l's
+    output to level l+1 and to two FP levels) reads the kernels' own layout instead of transposing back.  Keyed on cm's version counter:
+    an in-place update of `cm` invalidates the twin; a view / slice / clone of `cm` is a new tensor object and carries none."""
+    cm._g4d_pm = (pm, cm._version)
+    return cm
+
+
+def point_major_of(cm):
+    """(B, C, N) features of the operator API -> (B, N, C) for the kernels: the attached twin when `cm` came out of a fused drop-in
+    module and has not been written since, else one transpose launch."""
+    tw = getattr(cm, "_g4d_pm", None)
+    if tw is not None and tw[1] == cm._version and tuple(tw[0].shape) == (cm.shape[0], cm.shape[2], cm.shape[1]):
+        return tw[0]
+    pm = to_point_major(cm.contiguous())
+    if cm.is_contiguous():
+        attach_twin(cm, pm)      # the same features usually come back (a level's output feeds the next SA level and two FP levels)
+    return pm
+
+
+def channel_major_with_twin(pm):
+    """(B, N, C) kernel output -> the (B, C, N) tensor the reference returns, carrying `pm` as its twin."""
+    return attach_twin(to_channel_major(pm), pm)
 
 
 # (STREAM_GEMM -> tuning.Tuning.stream_gemm) tall contractions (>= 65536 rows, K <= 128, Cout a multiple of 128) on the row-streaming GEMM
@@ -683,8 +726,9 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
                   L2.shift.data_ptr(), L3.Wf.data_ptr(), L3.Kpad, L3.scale.data_ptr(), L3.shift.data_ptr(), pool, out.data_ptr(),
                   out.shape[-1], col0, stream)
     elif (_T().sa_xyz_table and C == 0 and use_xyz and len(layers) == 3 and current_precision() == "fp32" and all(L.relu for L in layers) and pool == 1
-          and layers[0].Cout in (32, 64, 128) and layers[1].Cout == layers[0].Cout and layers[2].Cout == 2 * layers[0].Cout and S in (16, 32, 64)
-          and layers[1].Kpad == layers[0].Cout and layers[2].Kpad == layers[0].Cout and B * P * S >= 262144):
+          and layers[1].Cout == layers[0].Cout and layers[2].Cout == 2 * layers[0].Cout
+          and layers[1].Kpad == layers[0].Cout and layers[2].Kpad == layers[0].Cout
+          and _lib.lib().g4d_sa_table_supported(B * P * S, layers[0].Cout, S, pool)):   # (shape x tuning state: exactly what sa_table_try takes -- only it reads a stride-0 table)
         # a WIDE xyz-only stack (BASELINE config 5: [3, 64, 64, 128] over 64 samples): the persistent kernel of sa_table.hip with its weights in
         # LDS, fed a shared row of zeros as the "feature part" of the first layer (tab_ld = 0) -- 0 + Wx (x_j - q) is the layer itself
         L0 = layers[0]

@@ -107,10 +107,17 @@ def _tile_meta(rowptr, colidx, vals, nv):
     hit = _meta_cache.get(key)
     if hit is not None and hit[0] is rowptr:
         return hit[1]
-    if len(_meta_cache) > 32:
-        _meta_cache.clear()
     meta = torch.empty(max(int(_lib.lib().g4d_gcn_tile_meta_bytes(nv)), 16), dtype=torch.uint8, device=rowptr.device)
     _lib.call("g4d_gcn_tile_meta_build", nv, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), meta.data_ptr(), _lib.stream_ptr())
+    if torch.cuda.is_current_stream_capturing():
+        # under stream capture the build is only RECORDED into that graph: the buffer belongs to the graph's replays, not to the cache (an eager
+        # caller hitting the cache would read memory no kernel has written yet)
+        return meta
+    # the build ran on the calling stream; a later call may sit on ANOTHER stream (the executor's slots): finish it here, once per mesh, so
+    # that a cache hit needs no event bookkeeping
+    torch.cuda.current_stream(rowptr.device).synchronize()
+    if len(_meta_cache) > 32:
+        _meta_cache.clear()
     _meta_cache[key] = (rowptr, meta)
     return meta
 

@@ -65,15 +65,17 @@ class _Slot:
 
 class StepPipeline:
     def __init__(self, model, smpl=None, clouds_per_step=8, n_points=8192, coalesce=8, streams=2, precision="fp32", pose2rot=True,
-                 device=None, use_graph=True, tuning=None):
-        """model: a Pointnet2MSGSEG in eval mode (its forward_fused is what runs); smpl: dict with v_template, shapedirs, posedirs,
+                 device=None, use_graph=True, tuning=None, encoder_call=None):
+        """model: a Pointnet2MSGSEG in eval mode (its forward_fused is what runs -- or `encoder_call(model, clouds) -> sem_logits`, e.g.
+        `lambda m, pc: m(pc)[1]`, the reference's own call form, which in eval + no_grad dispatches to the same kernels and converts the
+        features to the reference's (B, C, N) layout); smpl: dict with v_template, shapedirs, posedirs,
         J_regressor, parents, lbs_weights (HIP tensors) or None for the encoder alone.  tuning: the garment4d_amd.tuning.Tuning this
         executor runs under (default: the one in force where it is constructed) -- held for its lifetime, applied around every call it
         launches or captures; two executors in one process can carry different ones."""
         assert coalesce >= 1 and streams >= 1 and not model.training
         self.tuning = tuning if tuning is not None else _tuning.current()
         self.model, self.smpl, self.B, self.N, self.k = model, smpl, int(clouds_per_step), int(n_points), int(coalesce)
-        self.precision, self.pose2rot, self.use_graph = precision, pose2rot, use_graph
+        self.precision, self.pose2rot, self.use_graph, self.encoder_call = precision, pose2rot, use_graph, encoder_call
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         self.device = dev
         nb = 0 if smpl is None else smpl["shapedirs"].shape[-1]
@@ -98,7 +100,13 @@ class StepPipeline:
             return self._call_tuned(s)
 
     def _call_tuned(self, s):
-        out = self.model.forward_fused(s.cloud, precision=self.precision)
+        if self.encoder_call is not None:
+            from . import fused
+            with fused.precision(self.precision):
+                logits = self.encoder_call(self.model, s.cloud)
+            out = (None, logits)
+        else:
+            out = self.model.forward_fused(s.cloud, precision=self.precision)
         v = j = None
         if self.smpl is not None:
             P = self.smpl

@@ -1,10 +1,18 @@
 """PointnetSAModuleMSG / PointnetSAModule / PointnetFPModule with the reference's constructor signatures,
 forward contracts and state-dict keys (/root/reference/modules/pointnet2/pointnet2/pointnet2_modules.py).
 
-forward() here is the op-by-op path (every op a HIP kernel through the drop-in boundary; SharedMLP through
-torch so that it is trainable, incl. train-mode BatchNorm).  Eval-mode inference can instead call
-`garment4d_amd.fused` which runs group+MLP+max / interpolate+MLP as single fused HIP kernels reading the
-same parameters.
+forward() has two routes behind the reference's one signature:
+
+  * eval() + torch.no_grad() on float32 HIP tensors whose shared MLPs are 1x1 conv(+BN)(+ReLU) blocks: the FUSED kernels
+    (`garment4d_amd.fused.sa_forward` / `fp_forward`: sampling, ball query, group + MLP + pool, three_nn + interpolate + MLP
+    as single launches).  The reference's return contract holds -- features are (B, C, N) -- and the returned tensor
+    carries its point-major twin (`fused.attach_twin`), so a chain of these modules, e.g. the reference's own
+    modules/pointnet2encoder.py:127-140 loop, transposes once per level output and never back.
+  * everything else (training mode, autograd enabled, CPU / non-fp32 tensors, pre-activation / instance-norm / non-ReLU
+    stacks, Tuning.dropin_fused = False): the op-by-op path -- every op a HIP kernel through the drop-in boundary,
+    SharedMLP through torch so that it is trainable, incl. train-mode BatchNorm.
+
+Both routes read the same parameters (same state-dict keys); they agree within fp32 rounding (tests/test_dropin_gpu.py).
 """
 from typing import List
 
@@ -14,6 +22,29 @@ import torch.nn.functional as F
 
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
+from .tuning import current as _T
+from . import tuning as _tuning
+
+
+def op_by_op():
+    """with op_by_op(): ...  -- module forward()s inside take the op-by-op route whatever the mode (A/B switch, reference for tests)."""
+    return _tuning.use(_tuning.current().replace(dropin_fused=False))
+
+
+def fused_route(module, stacks, *tensors):
+    """Does this forward() call go to the fused kernels?  eval mode, autograd off, fp32 HIP tensors, every stack packable."""
+    if module.training or torch.is_grad_enabled() or not _T().dropin_fused:
+        return False
+    for t in tensors:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32):
+            return False
+    from . import fused
+    try:
+        for st in stacks:
+            fused.pack_conv_stack(st)        # cached on the stack; raises for blocks the kernels do not cover
+    except NotImplementedError:
+        return False
+    return True
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -26,6 +57,12 @@ class _PointnetSAModuleBase(nn.Module):
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None):
         """xyz (B,N,3), features (B,C,N)|None -> (new_xyz (B,npoint,3)|None, new_features (B,sum Cout,npoint))."""
+        if (self.pool_method in ("max_pool", "avg_pool") and fused_route(self, self.mlps, xyz, features, new_xyz)
+                and all(int(g.use_xyz) or features is not None for g in self.groupers)):
+            from . import fused
+            nx, f_pm = fused.sa_forward(self, xyz.contiguous(), None if features is None else fused.point_major_of(features),
+                                        new_xyz=None if new_xyz is None else new_xyz.contiguous())
+            return (nx if nx is not None else new_xyz), fused.channel_major_with_twin(f_pm)
         if new_xyz is None and self.npoint is not None:
             sample_idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), sample_idx)
@@ -82,6 +119,11 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         """unknown (B,n,3), known (B,m,3)|None, unknow_feats (B,C1,n)|None, known_feats (B,C2,m) -> (B,Cout,n)."""
+        if fused_route(self, [self.mlp], unknown, known, unknow_feats, known_feats):
+            from . import fused
+            out_pm = fused.fp_forward(self, unknown.contiguous(), None if known is None else known.contiguous(),
+                                      None if unknow_feats is None else fused.point_major_of(unknow_feats), fused.point_major_of(known_feats))
+            return fused.channel_major_with_twin(out_pm)
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)

@@ -1,11 +1,14 @@
 """SharedMLP / Conv1d / Conv2d / FC / BatchNorm containers with the reference's constructor signatures and
 STATE-DICT KEYS (/root/reference/modules/pointnet2/pointnet2/pytorch_utils.py): e.g.
 `layer0.conv.weight (Cout,Cin,1,1)`, `layer0.bn.bn.{weight,bias,running_mean,running_var,num_batches_tracked}`,
-so reference checkpoints load unchanged.  This is the trainable (un-fused) path; eval-mode
-inference goes through the fused HIP kernels (garment4d_amd/fused.py), which read these modules' tensors.
+so reference checkpoints load unchanged.  These containers are the trainable (un-fused) path; eval-mode
+inference goes through the fused HIP kernels (garment4d_amd/fused.py), which read these modules' tensors -- the SA / FP
+modules dispatch there themselves (pointnet2_modules.py), and a `Conv1d` block called on its own in eval() + no_grad (the
+FC head of pointnet2encoder.py:141) runs as one HIP contraction on the input's point-major twin.
 """
 from typing import List, Tuple
 
+import torch
 import torch.nn as nn
 
 
@@ -65,6 +68,23 @@ class Conv1d(_ConvBase):
         super().__init__(in_size, out_size, kernel_size, stride, padding, activation, bn, init, conv=nn.Conv1d,
                          batch_norm=BatchNorm1d, bias=bias, preact=preact, name=name, instance_norm=instance_norm,
                          instance_norm_func=nn.InstanceNorm1d)
+
+    def forward(self, x):
+        """(B, Cin, N) -> (B, Cout, N).  eval() + no_grad on an fp32 HIP tensor: conv + BN + ReLU as ONE contraction launch
+        (fused.linear) on the point-major twin of `x`; otherwise torch's layers, as the reference (trainable)."""
+        if (not self.training) and (not torch.is_grad_enabled()) and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32:
+            from . import fused
+            from .tuning import current as _T
+            if _T().dropin_fused:
+                try:
+                    L = fused.pack_conv_block(self)
+                except NotImplementedError:
+                    L = None
+                if L is not None and x.shape[1] == L.K:
+                    pm = fused.point_major_of(x)
+                    B, N, C = pm.shape
+                    return fused.channel_major_with_twin(fused.linear(pm.view(B * N, C), L).view(B, N, L.Cout))
+        return super().forward(x)
 
 
 class Conv2d(_ConvBase):

@@ -11,6 +11,11 @@ another one for the duration of a block -- including its `native` entries, which
 it launches (and around the capture of its hipGraphs: kernel selection is frozen into the graph at capture time).  Environment variables
 only seed `DEFAULT` at import; nothing else reads them afterwards.
 
+Isolation, precisely: the Python switches live in a ContextVar (per thread AND per asyncio task / copied context); the `native` keys live
+in a per-OS-THREAD table of the library.  `use()` therefore must not span an `await` or hand its context to another thread
+(asyncio.to_thread, copy_context().run): the other thread would see the Python switches but not the native keys, and two tasks
+interleaving on one thread inside `use()` blocks would see each other's native overrides.  One `use()` block = one thread, no awaits inside.
+
 Every setting computes the same values (bit-identical between kernel variants unless a field's comment says otherwise): the object
 chooses HOW a call runs, never WHAT it returns.
 
@@ -69,6 +74,10 @@ class Tuning:
     fp_gemm_bf16: bool = True          # wide FP level, bf16 operands, large launches: tiled GEMMs (csrc/gemm_bf16.hip)
     fp_gemm_bf16_min_rows: int = 8192
     fp_wide_table: bool = True         # wide FP levels with skip features: known-feature columns pre-contracted
+    # ---- the operator API (pointnet2_modules.py / encoder.py / pytorch_utils.py)
+    dropin_fused: bool = True          # eval() + no_grad: module forward()s dispatch to the fused kernels (False: always the op-by-op route)
+    dropin_whole_model: bool = True    # Pointnet2MSGSEG.forward as ONE fused call graph (cross-level launches shared); False: the reference's loop over its
+                                       #  SA / FP modules, each dispatching on its own -- what modules/pointnet2encoder.py runs over this package's modules
     # ---- callers around the path
     use_pe_kernel: bool = True         # refine.py: dedicated positional-encoder kernel (False: the generic fused stack)
     gcn_fuse_stack: bool = True        # gcn.py: fused GCN stack launches
@@ -111,7 +120,7 @@ def from_environment() -> Tuning:
         fp_wide_fused=_env_flag("G4D_FP_WIDE_FUSED", d.fp_wide_fused), fp_cells=_env_flag("G4D_FP_CELLS", d.fp_cells), fp_table=_env_flag("G4D_FP_TABLE", d.fp_table),
         fp_gemm_bf16=_env_flag("G4D_FP_GEMM_BF16", d.fp_gemm_bf16), fp_gemm_bf16_min_rows=_env_int("G4D_FP_GEMM_BF16_MIN_ROWS", d.fp_gemm_bf16_min_rows),
         fp_wide_table=_env_flag("G4D_FP_WIDE_TABLE", d.fp_wide_table), gcn_fuse_stack=_env_flag("G4D_GCN_FUSED", d.gcn_fuse_stack),
-        lbs_mfma=_env_flag("G4D_LBS_MFMA", d.lbs_mfma), lbs_one_launch=_env_flag("G4D_LBS_ONE", d.lbs_one_launch),
+        dropin_fused=_env_flag("G4D_DROPIN_FUSED", d.dropin_fused), dropin_whole_model=_env_flag("G4D_DROPIN_WHOLE", d.dropin_whole_model), lbs_mfma=_env_flag("G4D_LBS_MFMA", d.lbs_mfma), lbs_one_launch=_env_flag("G4D_LBS_ONE", d.lbs_one_launch),
         lbs_one_launch_max_b=_env_int("G4D_LBS_ONE_MAX_B", d.lbs_one_launch_max_b))
 
 

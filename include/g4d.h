@@ -431,6 +431,10 @@ int g4d_mlp_chain_table_f32(long long rows, int n, int m, int C2, const float *t
  * Wx transposed.  The layer itself becomes relu((table[j] + Wx (x_j - q)) * pre_scale + pre_shift) inside the loader of the
  * register-chain kernel; W / scale / shift / Kpad / Cout / relu describe the REMAINING layers (widths per g4d_mlp_chain_supported),
  * pool / out / ldo / col0 as g4d_mlp_chain_f32.  rows = B*P*S. */
+/* 1 when a g4d_mlp_chain_group_table_f32 launch of `rows` grouped rows with first-layer width Kt (stack Kt -> Kt -> 2 Kt), nsample S and
+ * this pooling mode runs on the persistent kernel (csrc/sa_table.hip) under the calling thread's tuning state -- the only kernel that accepts
+ * tab_ld == 0 (an xyz-only stack: one shared table row of zeros).  Hosts ask before choosing that route. */
+int g4d_sa_table_supported(long long rows, int Kt, int S, int pool);
 int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx,
                                   const float *table, int tab_ld, int Kt, const float *tab_wx, const float *pre_scale,
                                   const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,

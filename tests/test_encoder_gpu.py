@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from garment4d_amd import synthetic as syn
+from garment4d_amd import fused, pointnet2_modules as PM, synthetic as syn
 from garment4d_amd.encoder import Pointnet2MSGSEG, seed_encoder
 from oracle import modules_oracle as MO
 
@@ -31,7 +31,15 @@ def test_encoder_vs_oracle(kind):
     with torch.no_grad():
         x = torch.from_numpy(xyz).cuda()
         _, logits, l_f, l_xyz = model.forward_fused(x, channel_major=True)
-        _, logits2, l_f2, l_xyz2 = model(x)
+        with PM.op_by_op():
+            _, logits2, l_f2, l_xyz2 = model(x)
+        _, logits3, l_f3, l_xyz3 = model(x)      # the drop-in route: eval() + no_grad -> the fused kernels behind the reference's forward()
+    # model(pc) IS forward_fused(channel_major=True), bit for bit, with the reference's (B, C, N) contract
+    assert torch.equal(logits3, logits) and all(torch.equal(a, b) for a, b in zip(l_xyz3, l_xyz))
+    assert l_f3[0].shape == (B, 64, N) and l_f3[3].shape == (B, 384, 64)
+    for a, b in zip(l_f3, l_f):
+        assert torch.equal(a, b)
+        assert torch.equal(fused.point_major_of(a), a.transpose(1, 2).contiguous())   # the twin rides along
     for lvl in range(1, 4):  # FPS-selected centroids: bit-exact
         assert np.array_equal(l_xyz[lvl].cpu().numpy(), want_xyz[lvl])
         assert np.array_equal(l_xyz2[lvl].cpu().numpy(), want_xyz[lvl])

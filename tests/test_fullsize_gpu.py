@@ -9,6 +9,15 @@ from oracle import pointnet2_oracle as K
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("contraction_mode")]   # every test runs in both numerics modes
 
+@pytest.fixture(autouse=True)
+def _module_forward_is_op_by_op():
+    """In this file `module(...)` is the op-by-op REFERENCE the fused kernels are compared with: switch the eval-mode drop-in dispatch
+    of pointnet2_modules.py off (it would compare the fused kernels with themselves); tests/test_dropin_gpu.py covers that dispatch."""
+    from garment4d_amd import pointnet2_modules as _PM
+    with _PM.op_by_op():
+        yield
+
+
 
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()

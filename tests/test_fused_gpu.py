@@ -11,6 +11,15 @@ from conftest import sub_state_dict
 from garment4d_amd import fused, pointnet2_modules as PM, synthetic as syn
 
 pytestmark = pytest.mark.gpu
+
+@pytest.fixture(autouse=True)
+def _module_forward_is_op_by_op():
+    """In this file `module(...)` is the op-by-op REFERENCE the fused kernels are compared with: switch the eval-mode drop-in dispatch
+    of pointnet2_modules.py off (it would compare the fused kernels with themselves); tests/test_dropin_gpu.py covers that dispatch."""
+    from garment4d_amd import pointnet2_modules as _PM
+    with _PM.op_by_op():
+        yield
+
 # north_star: 1e-5 fp32 for grouped features -- elementwise |a - b| <= tol * (1 + |b|), i.e. rtol = atol = tol.  (The MFMA
 # contraction sums in a different order than the reference's conv; measured worst case at the benched sizes: 4.7e-6.)
 def close(a, b, tol=1e-5):

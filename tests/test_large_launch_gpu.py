@@ -14,6 +14,15 @@ from garment4d_amd import _lib, fused, lbs as L, pointnet2_modules as PM, pytorc
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _module_forward_is_op_by_op():
+    """In this file `module(...)` is the op-by-op REFERENCE the fused kernels are compared with: switch the eval-mode drop-in dispatch
+    of pointnet2_modules.py off (it would compare the fused kernels with themselves); tests/test_dropin_gpu.py covers that dispatch."""
+    from garment4d_amd import pointnet2_modules as _PM
+    with _PM.op_by_op():
+        yield
+
+
 
 def tuning(**kv):
     """The library's tuning keys (include/g4d.h) for the duration of the block, through an explicit Tuning object (garment4d_amd/tuning.py:
@@ -48,6 +57,33 @@ def test_sa_table_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, mlps, 
     assert torch.equal(outs[0], outs[1])
     want = sa(xyz, fused.to_channel_major(fpm))[1]
     np.testing.assert_allclose(fused.to_channel_major(outs[1]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("widths,S,native", [
+    ((64, 64, 128), 64, {}),                                  # BASELINE config 5's stack: the persistent kernel reads a stride-0 table row
+    ((64, 64, 128), 64, {"sa_table_persistent": 0}),          # ADVICE r5: with the A/B switch off the stride-0 route must not be chosen (used to raise)
+    ((64, 64, 128), 64, {"sa_table_min_rows": 1 << 30}),
+    ((32, 32, 64), 64, {}),                                   # (C = 32, S = 64) is not an instantiated shape of the persistent kernel
+    ((128, 128, 256), 16, {}),                                # nor (C = 128, S = 16)
+    ((128, 128, 256), 64, {"sa_table_128": 0}),
+])
+def test_wide_xyz_only_stack_route_follows_what_the_persistent_kernel_accepts(widths, S, native):
+    """[3, C, C, 2C] xyz-only stacks with >= 262144 grouped rows: whatever the tuning state and whichever (C, S) pair, the call computes (the
+    route through sa_table.hip's stride-0 table is taken exactly when g4d_sa_table_supported says that kernel will run) and every setting gives
+    the same bits as the default one."""
+    torch.manual_seed(S + widths[0])
+    P = 262144 // S // 2 + 3
+    xyz = torch.from_numpy(syn.unit_cloud(2, 4096 if P <= 2048 + 3 else 16384, seed=S)).cuda()
+    sa = _seed_bn(PM.PointnetSAModule(npoint=P, radius=0.3, nsample=S, mlp=[0] + list(widths)))
+    with torch.no_grad():
+        with tuning(**native):
+            got = fused.sa_forward(sa, xyz, None)[1]
+        from garment4d_amd import tuning as T
+        with T.use(T.current().replace(sa_xyz_table=False)):
+            ref = fused.sa_forward(sa, xyz, None)[1]
+        want = sa(xyz, None)[1]
+    assert torch.equal(got, ref)
+    np.testing.assert_allclose(fused.to_channel_major(got).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("cells", [True, False])

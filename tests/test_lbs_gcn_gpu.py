@@ -305,7 +305,8 @@ def test_lbs_rejects_mismatched_shapes_before_touching_the_device():
 
 
 @pytest.mark.parametrize("B,V,J,NB,rot", [(1, 64, 24, 10, True), (8, 6890, 24, 10, True), (19, 1500, 24, 10, False), (9, 777, 25, 1, True),
-                                          (3, 130, 5, 16, True), (17, 63, 23, 3, False)])
+                                          (3, 130, 5, 16, True), (17, 63, 23, 3, False),
+                                          (5, 200, 4, 100, True), (2, 96, 10, 70, False)])   # more betas than the 64 lanes that stage them
 def test_lbs_one_launch_kernel_vs_three_launch_route_and_oracle(B, V, J, NB, rot, tune):
     """g4d_lbs_one_f32 against g4d_lbs_fused_f32 (same constants, different summation order of the blend) and the numpy oracle:
     frame counts that are not a multiple of the 8-frame group, vertex counts that are not a multiple of the 64-vertex tile, joint
