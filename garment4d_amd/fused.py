@@ -217,6 +217,19 @@ def point_major_of(cm):
     return pm
 
 
+def attach_grid(xyz, grid):
+    """Remember the cloud's cell grid (build_ball_grid) on the coordinate tensor itself: the drop-in modules are called one by one with the same
+    `xyz` object (pointnet2encoder.py: l_xyz[0] goes to SA level 1 and, as `unknown`, to the last FP level), so the FP level's three_nn can walk
+    the queries in cell order without the caller knowing that a grid exists.  Keyed on the version counter like the twins."""
+    xyz._g4d_grid = (grid, xyz._version)
+    return grid
+
+
+def grid_of(xyz):
+    g = getattr(xyz, "_g4d_grid", None)
+    return g[0] if g is not None and g[1] == xyz._version else None
+
+
 def channel_major_with_twin(pm):
     """(B, N, C) kernel output -> the (B, C, N) tensor the reference returns, carrying `pm` as its twin."""
     return attach_twin(to_channel_major(pm), pm)

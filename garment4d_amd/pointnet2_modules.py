@@ -60,8 +60,20 @@ class _PointnetSAModuleBase(nn.Module):
         if (self.pool_method in ("max_pool", "avg_pool") and fused_route(self, self.mlps, xyz, features, new_xyz)
                 and all(int(g.use_xyz) or features is not None for g in self.groupers)):
             from . import fused
+            grid = None
+            if self.npoint is not None and xyz.is_contiguous() and xyz.shape[0] > 0 and xyz.shape[1] >= _T().grid_min_n:
+                radii = [g.radius for g in self.groupers]
+                if max(radii) <= 2.01 * min(radii):
+                    # the cloud's cell grid, kept on `xyz` for a later module called with the same tensor (the last FP level's three_nn)
+                    grid = fused.grid_of(xyz)
+                    if grid is None or grid[1] < max(radii):
+                        if new_xyz is None and xyz.shape[1] <= 12800:
+                            new_xyz, grid = fused.fps_gather_grid(xyz, self.npoint, max(radii))   # sampling + the grid build: one launch
+                        else:
+                            grid = fused.build_ball_grid(xyz, max(radii))
+                        fused.attach_grid(xyz, grid)
             nx, f_pm = fused.sa_forward(self, xyz.contiguous(), None if features is None else fused.point_major_of(features),
-                                        new_xyz=None if new_xyz is None else new_xyz.contiguous())
+                                        new_xyz=None if new_xyz is None else new_xyz.contiguous(), grid=grid)
             return (nx if nx is not None else new_xyz), fused.channel_major_with_twin(f_pm)
         if new_xyz is None and self.npoint is not None:
             sample_idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
@@ -122,7 +134,8 @@ class PointnetFPModule(nn.Module):
         if fused_route(self, [self.mlp], unknown, known, unknow_feats, known_feats):
             from . import fused
             out_pm = fused.fp_forward(self, unknown.contiguous(), None if known is None else known.contiguous(),
-                                      None if unknow_feats is None else fused.point_major_of(unknow_feats), fused.point_major_of(known_feats))
+                                      None if unknow_feats is None else fused.point_major_of(unknow_feats), fused.point_major_of(known_feats),
+                                      unknown_grid=fused.grid_of(unknown) if unknown.is_contiguous() else None)
             return fused.channel_major_with_twin(out_pm)
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)

@@ -325,9 +325,10 @@ def test_lbs_one_launch_kernel_vs_three_launch_route_and_oracle(B, V, J, NB, rot
     tune(lbs_mfma=True)                                       # round 5: the matrix-pipe route on the same ragged shapes (JS = 6 and 8, V % 32 != 0, B % 16 != 0)
     mf = L.lbs(dev(betas), dev(np.ascontiguousarray(pose_in)), *args, pose2rot=rot)
     np.testing.assert_allclose(host(mf[0]), host(outs[False][0]), rtol=2e-6, atol=2e-6)
-    assert torch.equal(mf[1], outs[False][1])                 # the rigid chain is the same code
+    same_joints = torch.equal if NB <= 64 else (lambda a, b: bool(np.allclose(host(a), host(b), rtol=2e-6, atol=2e-6)))   # (many betas: the three-launch route regresses the joints from the shaped vertices)
+    assert same_joints(mf[1], outs[False][1])                 # the rigid chain is the same code
     np.testing.assert_allclose(host(outs[True][0]), host(outs[False][0]), rtol=2e-6, atol=2e-6)
-    assert torch.equal(outs[True][1], outs[False][1])        # the rigid chain is the same code
+    assert same_joints(outs[True][1], outs[False][1])        # the rigid chain is the same code
     wv, wj = lbs_oracle.lbs(betas, pose_in, P["v_template"], P["shapedirs"], P["posedirs"], P["J_regressor"], P["parents"], P["lbs_weights"],
                             pose2rot=rot)
     np.testing.assert_allclose(host(outs[True][0]), wv, **TOL)
