@@ -89,9 +89,14 @@ def timed(fn, reps=5):
         fn()
         e1.record(sa); e2.record(sb)
         torch.cuda.synchronize()
-        best.append(max(e0.elapsed_time(e1), e0.elapsed_time(e2)) * 1e3)
+        best.append((max(e0.elapsed_time(e1), e0.elapsed_time(e2)) * 1e3, e0.elapsed_time(e1) * 1e3, e0.elapsed_time(e2) * 1e3))
     best.sort()
-    return best[len(best) // 2]
+    global last_ends
+    last_ends = best[len(best) // 2][1:]          # when stream a / stream b finished in the median run
+    return best[len(best) // 2][0]
+
+
+last_ends = (0.0, 0.0)
 
 
 alone = {}
@@ -124,6 +129,7 @@ for a, b in want:
     if a is None or b is None:
         continue
     t_ab = timed(lambda: (replay(byname[a], sa), replay(byname[b], sb)))
+    ends = last_ends
     t_ba = timed(lambda: (replay(byname[b], sb), replay(byname[a], sa)))
     ta, tb = alone[a], alone[b]
-    print(f"{a[:44]:44s} | {b[:44]:44s} | {ta:7.1f} | {tb:7.1f} | {t_ab:7.1f} | {t_ab / (ta + tb):5.2f} | {t_ab / max(ta, tb):5.2f} || {t_ba:7.1f}")
+    print(f"{a[:44]:44s} | {b[:44]:44s} | {ta:7.1f} | {tb:7.1f} | {t_ab:7.1f} | {t_ab / (ta + tb):5.2f} | {t_ab / max(ta, tb):5.2f} || {t_ba:7.1f} || a ended {ends[0]:7.1f}, b ended {ends[1]:7.1f}")

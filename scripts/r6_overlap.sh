@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 6: overlap pairs of the persistent kernels next to the level-1 sampling launch / the pruned three_nn, static partition vs dynamic unit claims
+export PAIRS="fps_gather_grid:sa_xyz_mlp3_pair,fps_gather_grid:group[mlp_chain_group_table+mlp_chain_group_table]#0,fps_gather_grid:group[mlp_chain_group_table+mlp_chain_group_table]#1,fps_gather_grid:mlp_chain_interp_init,fps_gather_grid:mlp_chain_table_cells,fps_gather_grid:linear_interp_add,three_nn_pruned:mlp_chain_interp_init,three_nn_pruned:mlp_chain_table_cells,three_nn_pruned:group[mlp_chain_group_table+mlp_chain_group_table]#1"
+for d in 0 1; do
+  echo "### G4D_DYNAMIC_UNITS=$d"
+  G4D_DYNAMIC_UNITS=$d python scripts/exp_overlap.py 240 fp32 2>&1 | grep -v amdgpu.ids
+done
