@@ -124,9 +124,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int kcap = (deal_kcap >> 8) & 0xff, deal = deal_kcap & 0xff;   // (small ints in one kernel argument)
-    if ((deal_kcap >> 16) == 3) __builtin_amdgcn_s_setprio(3);           // experiment G4D_FPS_PRIO
-    else if ((deal_kcap >> 16) == 1) __builtin_amdgcn_s_setprio(1);
+    const int kcap = deal_kcap >> 8, deal = deal_kcap & 0xff;   // (two small ints in one kernel argument)
     const float *xyz = xyz_all + (size_t)cloud * n * 3;
     float *temp = temp_all ? temp_all + (size_t)cloud * n : nullptr;
     int *idx = idx_all + (size_t)cloud * m;
@@ -642,8 +640,7 @@ static bool fps_soa(int b) {
 }
 static int fps_kcap() {   // tuning hook: at most this many samples per round
     static const int k = getenv("G4D_FPS_KCAP") ? atoi(getenv("G4D_FPS_KCAP")) : 8;
-    static const int prio = getenv("G4D_FPS_PRIO") ? atoi(getenv("G4D_FPS_PRIO")) : 0;
-    return (k < 1 ? 1 : (k > 64 ? 64 : k)) | (prio << 8);
+    return k < 1 ? 1 : (k > 64 ? 64 : k);
 }
 
 // The sampling launch with a second ROLE: workgroups [0, b) run the FPS of cloud blockIdx.x, workgroups [b, 2 b) build the ball-query

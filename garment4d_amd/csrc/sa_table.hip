@@ -35,7 +35,6 @@ struct SaTabArgs {
     const float *W3, *sc3, *sh3;         // (T k-steps per channel tile: Kpad == C)
     float *out;
     int ldo, col0;
-    int prio;                            // experiment (G4D_MFMA_PRIO): s_setprio of the kernel's waves
 };
 
 __device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, float v3) {   // sa_xyz.hip: lane 16 c + fi = max over the 16 rows of tile c
@@ -82,9 +81,6 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
     float *s_w2 = smem + NCONST, *s_w3 = s_w2 + NW2;
     float *s_stage = smem + NCONST;                  // WM == 2: [2][kStageK * T3 * 256] floats: two buffers of one chunk's fragments
     const int tid = threadIdx.x;
-    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     for (int i = tid; i < 3 * C; i += 256) s_wx[i] = a.wx[i];
     for (int i = tid; i < C; i += 256) { s_ps[i] = a.ps[i]; s_pf[i] = a.pf[i]; s_sc2[i] = a.sc2[i]; s_sh2[i] = a.sh2[i]; }
     for (int i = tid; i < 2 * C; i += 256) { s_sc3[i] = a.sc3[i]; s_sh3[i] = a.sh3[i]; }
@@ -473,8 +469,6 @@ int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, con
     a.W2 = W[0]; a.sc2 = scale[0]; a.sh2 = shift[0];
     a.W3 = W[1]; a.sc3 = scale[1]; a.sh3 = shift[1];
     a.out = out; a.ldo = ldo; a.col0 = col0;
-    static const int prio = getenv("G4D_MFMA_PRIO") ? atoi(getenv("G4D_MFMA_PRIO")) : 0;
-    a.prio = prio;
     if (Kt == 32 && S == 16) return sa_table_launch<32, 16, 2, 1>(a, st);
     if (Kt == 32 && S == 32) return sa_table_launch<32, 32, 2, 1>(a, st);
     if (Kt == 64 && S == 32) return sa_table_launch<64, 32, 2, 1>(a, st);
