@@ -323,6 +323,29 @@ def cpu_model_name():
     return "unknown"
 
 
+def cpu_topology():
+    """(logical CPUs, physical cores, threads per core, sockets) from /proc/cpuinfo: physical cores = distinct (physical id, core id) pairs."""
+    logical = os.cpu_count() or 1
+    cores, sockets = set(), set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core)); sockets.add(phys)
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core)); sockets.add(phys)
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    return logical, physical, max(1, logical // physical), max(1, len(sockets))
+
+
 def cpu_baseline(frames_all, with_lbs):
     """The CPU oracle on this box's host cores, per BASELINE.md section 3 / SURVEY 8(d): the C restatement of the reference's
     CUDA kernels (OpenMP) + the numpy restatement of SharedMLP (channel contraction through the multi-threaded BLAS) and lbs(),
@@ -334,7 +357,7 @@ def cpu_baseline(frames_all, with_lbs):
     from oracle import lbs_oracle, modules_oracle as MO, pointnet2_oracle as K
     model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=0).eval()
     sd = {k: v.numpy() for k, v in model.state_dict().items()}
-    ncores = os.cpu_count() or 1
+    ncores, nphys, smt, nsock = cpu_topology()   # ncores = LOGICAL CPUs (what the all-core runs use); nphys = physical cores
     P = syn.smpl_like_params(seed=40)
 
     def lbs_call(betas, pose):
@@ -372,10 +395,11 @@ def cpu_baseline(frames_all, with_lbs):
     e_1, b_1, d_1 = run(1, 1, 2)
     fps_all = frames_all / (e_all + b_all)
     # frames are independent: the strongest CPU configuration is one single-threaded oracle per physical core
-    workers = max(1, ncores // 2)
+    workers = nphys                                  # one worker per PHYSICAL core
     par = cpu_frame_parallel(sd, workers, 3, with_lbs)
     best = max(fps_all, 1.0 / (e_1 + b_1), 0.0 if par is None else par["frames_per_s"])
-    return {"value": best, "unit": "frames/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model_name(),
+    return {"value": best, "unit": "frames/s", "cores": nphys, "cores_are": "physical cores", "logical_cpus": ncores, "threads_per_core": smt, "sockets": nsock,
+            "threads_used": {"frame_parallel": workers, "all_cores_intra_op": ncores, "1_thread": 1}, "kind": "port", "cpu_model": cpu_model_name(),
             "value_is": "best of the three configurations below",
             "value_all_cores_intra_op": fps_all, "value_1_thread": 1.0 / (e_1 + b_1), "value_frame_parallel": par,
             "encoder_s_per_frame": {"all_cores": e_all / frames_all, "1_thread": e_1},

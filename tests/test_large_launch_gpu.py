@@ -86,6 +86,36 @@ def test_wide_xyz_only_stack_route_follows_what_the_persistent_kernel_accepts(wi
     np.testing.assert_allclose(fused.to_channel_major(got).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_nonfinite_features_through_the_no_honor_nans_kernels():
+    """The persistent shared-MLP kernels are built with -fno-honor-nans (csrc/Makefile: a third fewer VALU instructions in their max / ReLU
+    epilogues).  What that means for non-finite INPUT, pinned here: a NaN / inf feature that reaches a ReLU leaves it as 0
+    (fmaxf(NaN, 0) = 0 -- in the chain kernels, built WITH NaNs honoured, too), so the kernels return finite numbers where torch's layers
+    return NaN for the whole neighbourhood; the two kernel families agree BIT FOR BIT on such input as well, and nothing leaks into other
+    clouds or into neighbourhoods that do not contain the point.  Finite input -> the 1e-5 / bit-identity contract of every other test."""
+    torch.manual_seed(0)
+    B, N, P, C = 3, 1024, 255, 96
+    xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=1)).cuda()
+    f = torch.randn(B, N, C, device="cuda")
+    fn = f.clone()
+    fn[0, 5, 7] = float("nan"); fn[0, 100, :] = float("inf"); fn[0, 200, 3] = -float("inf")
+    sa = _seed_bn(PM.PointnetSAModuleMSG(npoint=P, radii=[0.2, 0.3], nsamples=[16, 32], mlps=[[C, 32, 32, 64], [C, 64, 64, 128]]))
+    outs = {}
+    with torch.no_grad():
+        for on in (0, 1):
+            with tuning(sa_table_persistent=on, sa_table_min_rows=0):
+                outs[on] = (fused.sa_forward(sa, xyz, f)[1], fused.sa_forward(sa, xyz, fn)[1])
+        ref = sa(xyz, fused.to_channel_major(fn))[1].transpose(1, 2)          # torch layers (op-by-op route): NaN propagates
+    for on in (0, 1):
+        clean, dirty = outs[on]
+        assert torch.equal(clean[1:], dirty[1:])                              # other clouds: untouched
+        assert bool(torch.isfinite(dirty).all())                               # the kernels' ReLU maps NaN to 0
+        assert 0 < int((clean[0] != dirty[0]).any(1).sum()) < P                # only the neighbourhoods holding the three points change
+    assert torch.equal(outs[0][1], outs[1][1])                                 # -fno-honor-nans kernel == NaN-honouring chain kernel, bit for bit
+    both = torch.isfinite(ref)
+    assert int((~both).sum()) > 0                                              # torch: NaN for those neighbourhoods (documented difference)
+    np.testing.assert_allclose(outs[1][1][both].cpu().numpy(), ref[both].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("cells", [True, False])
 @pytest.mark.parametrize("B,n,m", [(2, 8192, 1024), (3, 5000, 300), (1, 4100, 257)])
 def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, tune):
@@ -302,3 +332,95 @@ def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, 
     want = fp(unknown, known, fused.to_channel_major(skip), fused.to_channel_major(kf))
     np.testing.assert_allclose(outs[True].cpu().numpy(), outs[False].cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(fused.to_channel_major(outs[True]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---- the selection matrix: every `*_min_rows` key of include/g4d.h at its DEFAULT value, launch sizes one tile below, at and
+#      one tile above it -- the launch just below runs the register-chain kernel, the others the persistent one; all must give the bits of a run
+#      with the persistent kernel switched off.  (The per-kernel tests above force the threshold to 0 and so never see this edge.)
+def _both(switch, fn):
+    with torch.no_grad():
+        with tuning(**{switch: 0}):
+            ref = fn()
+        got = fn()                     # default tuning: the thresholds of the library decide
+    return ref, got
+
+
+def _eq(a, b):
+    if isinstance(a, tuple):
+        return all(_eq(x, y) for x, y in zip(a, b))
+    return torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dP", [-1, 0, 1])
+def test_threshold_sa_table_min_rows(dP):
+    B, S, P = 8, 32, 1024 + dP           # 8 x P x 32 grouped rows around sa_table_min_rows = 262144 (one 32-row block per centroid)
+    torch.manual_seed(1)
+    xyz = torch.from_numpy(syn.unit_cloud(B, 2048, seed=3)).cuda()
+    fpm = torch.randn(B, 2048, 96, device="cuda")
+    sa = _seed_bn(PM.PointnetSAModuleMSG(npoint=P, radii=[0.15, 0.2], nsamples=[S, S], mlps=[[96, 32, 32, 64], [96, 64, 64, 128]]))
+    ref, got = _both("sa_table_persistent", lambda: fused.sa_forward(sa, xyz, fpm)[1])
+    assert _eq(ref, got)
+
+
+@pytest.mark.parametrize("dn", [-16, 0, 16])
+def test_threshold_fp_table_min_rows(dn):
+    B, n, m = 32, 8192 + dn, 512           # 32 x n rows around fp_table_min_rows = 262144 (16-row tiles)
+    torch.manual_seed(2)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=5)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 128, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    head = _seed_bn(torch.nn.Sequential(pt_utils.Conv1d(64, 32, bn=True), torch.nn.Dropout(), pt_utils.Conv1d(32, 7, activation=None)))
+    ref, got = _both("fp_table_persistent", lambda: fused.fp_forward(fp, unknown, known, None, kf, head=head))
+    assert _eq(ref, got)
+
+
+@pytest.mark.parametrize("dn", [-16, 0, 16])
+def test_threshold_fp_init_min_rows(dn):
+    B, n, m = 128, 1024 + dn, 256          # 128 x n rows around fp_init_min_rows = 131072
+    torch.manual_seed(3)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=7)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 256, device="cuda")
+    skip = torch.randn(B, n, 96, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[352, 256, 128]))
+    nxt = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    raw = fused.fp_table_layer(nxt, 0, 128, None)
+    ref, got = _both("fp_init_persistent", lambda: fused.fp_forward(fp, unknown, known, skip, kf, also_table=raw))
+    assert isinstance(got, tuple) and _eq(ref, got)
+
+
+@pytest.mark.parametrize("drows", [-1, 0, 1, 127, 128])
+def test_threshold_gemm_tile_min_rows(drows):
+    rows = 32768 + drows                   # around gemm_tile_min_rows = 32768 (128-row tiles; +-1: a ragged last tile)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(rows, 256, generator=g).cuda()
+    L = fused.PackedLayer(torch.randn(256, 256, generator=g).cuda() * 0.06, torch.rand(256, generator=g).cuda() + 0.5, torch.randn(256, generator=g).cuda() * 0.1, relu=True)
+    ref, got = _both("gemm_tile", lambda: fused.linear(x, L))
+    assert _eq(ref, got)
+
+
+@pytest.mark.parametrize("dn", [-16, 0, 16])
+def test_threshold_fp_head_bf16_min_rows(dn):
+    B, n, m = 32, 8192 + dn, 512
+    torch.manual_seed(5)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=9)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 128, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    head = _seed_bn(torch.nn.Sequential(pt_utils.Conv1d(64, 32, bn=True), torch.nn.Dropout(), pt_utils.Conv1d(32, 7, activation=None)))
+    with fused.precision("bf16"):
+        ref, got = _both("fp_head_bf16_persistent", lambda: fused.fp_forward(fp, unknown, known, None, kf, head=head))
+    assert _eq(ref, got)
+
+
+@pytest.mark.parametrize("dP", [-1, 0, 1])
+def test_threshold_sa_group_bf16_min_rows(dP):
+    B, S, P = 8, 32, 1024 + dP
+    torch.manual_seed(6)
+    xyz = torch.from_numpy(syn.unit_cloud(B, 2048, seed=11)).cuda()
+    fpm = torch.randn(B, 2048, 96, device="cuda")
+    sa = _seed_bn(PM.PointnetSAModuleMSG(npoint=P, radii=[0.15, 0.2], nsamples=[S, S], mlps=[[96, 32, 32, 64], [96, 64, 64, 128]]))
+    with fused.precision("bf16"):
+        ref, got = _both("sa_group_bf16_persistent", lambda: fused.sa_forward(sa, xyz, fpm)[1])
+    assert _eq(ref, got)
