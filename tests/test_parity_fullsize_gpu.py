@@ -129,6 +129,8 @@ def test_cfg3_encoder_bf16_full_size_vs_bf16_oracle(monkeypatch):
     for lvl in range(0, 4):
         bf16_gate(f"cfg3 l_features[{lvl}] (bf16 vs bf16-emulating oracle)", l_f[lvl], want_f[lvl])
     bf16_gate("cfg3 sem_logits", logits, want_logits)
+    from test_pipeline_gpu import argmax_agreement
+    argmax_agreement("cfg3 bf16 (B = 8)", logits.cpu().numpy(), want_logits, 0.999)
 
 
 # ---- a5: QueryAndGroup / GroupAll directly on the GPU (pointnet2_utils.py:232-291) ------------------------------------

@@ -13,6 +13,23 @@ from garment4d_amd.pipeline import StepPipeline
 pytestmark = pytest.mark.gpu
 
 
+def argmax_agreement(tag, got, want, floor):
+    """What the logits are FOR: the share of points whose predicted class (argmax over the 7 logits) equals the oracle's, and
+    -- a point can only flip when the oracle's own top-2 margin is below twice the error -- the largest margin among the flipped points."""
+    a, b = got.argmax(-1), want.argmax(-1)
+    agree = float((a == b).mean())
+    srt = np.sort(want, -1)
+    margin = srt[..., -1] - srt[..., -2]
+    flipped = margin[a != b]
+    err = float(np.abs(got - want).max())
+    print(f"[parity] {tag} sem_logits argmax agreement {agree:.5f} ({int((a != b).sum())} of {a.size} points flip; largest oracle top-2 margin among them "
+          f"{float(flipped.max()) if flipped.size else 0.0:.3g}, median margin of all points {float(np.median(margin)):.3g}, max |err| {err:.3g})")
+    assert agree >= floor, (tag, agree)
+    assert flipped.size == 0 or float(flipped.max()) <= 2.0 * err + 1e-12
+    return agree
+
+
+
 def _smpl(seed=1):
     return {k: torch.from_numpy(v).cuda() for k, v in syn.smpl_like_params(seed=seed).items()}
 
@@ -88,6 +105,7 @@ def test_clouds_of_a_240_cloud_call_vs_the_oracle_directly(precision, monkeypatc
             assert err.max() <= 3e-2 * scale and np.quantile(err, 0.999) <= qgate * scale, (name, err.max(), scale)
 
     gate("sem_logits", logits, want_logits)                                       # both (3, N, classes)
+    argmax_agreement(f"240-cloud {precision}", logits, want_logits, 1.0 if precision == "fp32" else 0.999)
     for lvl, f in enumerate(out[2]):
         if f is None:
             continue
