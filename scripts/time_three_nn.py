@@ -24,4 +24,7 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 240]:
                 t = timeit(lambda: fused.three_nn(x, known, unknown_grid=grid))
                 res[prune] = (t, fused.three_nn(x, known, unknown_grid=grid))
         same = torch.equal(res[False][1][1], res[True][1][1]) and torch.equal(res[False][1][0], res[True][1][0])
-        print(f"B={B:4d} {kind:5s}: scan {res[False][0]:8.1f} us | pruned {res[True][0]:8.1f} us | identical={same}")
+        tg = timeit(lambda: fused.three_nn(x, known, grid=True))           # cell grid of the KNOWN points, one lane per query (g4d_three_nn_grid_f32; build included)
+        rg = fused.three_nn(x, known, grid=True)
+        same_g = torch.equal(rg[1], res[True][1][1]) and torch.equal(rg[0], res[True][1][0])
+        print(f"B={B:4d} {kind:5s}: scan {res[False][0]:8.1f} us | pruned {res[True][0]:8.1f} us | identical={same} | known-grid {tg:8.1f} us identical={same_g}")
