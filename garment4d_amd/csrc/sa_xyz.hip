@@ -7,8 +7,12 @@
 // stacks are tiny (3.2k weights) and their rows are many (131k + 262k per 8 clouds), so here, like the positional encoders
 // (pos_encode.hip):
 //   * waves are persistent and autonomous (no LDS, no barrier); ALL weights, scales and shifts live in registers for the whole launch;
-//   * layer 1 (K = 3) runs on the VALU -- three FMAs per value instead of a K = 4-padded MFMA -- and is produced directly in the MFMA
-//     operand layout: lane (fi = l & 15, fq = l >> 4) holds channels {16 ks + 4 fq + e} of row fi of a 16-row tile;
+//   * layer 1 (K = 3) is ONE K = 4-padded MFMA per (row tile, 16 channels) since round 6 (rounds 1-5: three VALU FMAs per value -- and VALU
+//     work is ADDED to the matrix pipe's time on this chip, profiles/r04_mfma_valu_overlap.txt): A = W1 (lane (channel fi, k = fq) holds
+//     W1[16 ks + fi][fq], 0 for k = 3), B = the lane's OWN component fq of its row's offset x_j - q (one 4-byte load instead of a 12-byte
+//     row, one subtraction instead of three).  v_mfma_f32_16x16x4_f32 is the k-ascending FMA chain fma(w2, dz, fma(w1, dy, w0 * dx)) the
+//     VALU form computed (pos_encode.hip, round 5: bit-identical), and the result arrives in the operand layout layer 2 wants: lane
+//     (fi = l & 15, fq = l >> 4) holds channels {16 ks + 4 fq + e} of row fi of a 16-row tile;
 //   * layer 2 is evaluated TRANSPOSED (A = W2, B = h1): the accumulators come out as lane (row fi, channels 16 ct + 4 fq + r), i.e.
 //     already in the operand layout of the next layer -- affine + ReLU in place, no shuffle;
 //   * layer 3 in the normal orientation (A = h2, B = W3) gives lane (channel fi, rows 4 fq + r): the max / mean over the S rows of a
@@ -69,15 +73,18 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
     const int lane = threadIdx.x & 63;
     const int fi = lane & 15, fq = lane >> 4;
     // ---- weights into registers, once per wave
-    float w1[T1][4][3], s1[T1][4], h1s[T1][4];
+    float w1f[T1], s1[T1][4], h1s[T1][4];   // w1f: A fragment of layer 1, lane (channel fi, k = fq): W1[16 ks + fi][fq], 0 for the padding column k = 3
 #pragma unroll
-    for (int ks = 0; ks < T1; ++ks)
+    for (int ks = 0; ks < T1; ++ks) {
+        const float w = a.W1[(ks * 16 + fi) * a.ldw1 + min(fq, 2)];
+        w1f[ks] = fq < 3 ? w : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = ks * 16 + fq * 4 + e;
-            w1[ks][e][0] = a.W1[c * a.ldw1 + 0]; w1[ks][e][1] = a.W1[c * a.ldw1 + 1]; w1[ks][e][2] = a.W1[c * a.ldw1 + 2];
             s1[ks][e] = a.sc1[c]; h1s[ks][e] = a.sh1[c];
         }
+    }
+    const unsigned cfq = (unsigned)min(fq, 2);   // the coordinate this lane feeds to layer 1 (lanes with fq = 3 feed the zero padding)
     f32x4 w2[T2][T1], w3[T3][T2];
 #pragma unroll
     for (int ct = 0; ct < T2; ++ct)
@@ -101,7 +108,7 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
     const int npass = (rows + 31) >> 5;      // 32 rows per pass; S = 16 divides it, S = 32 is it
     // Two-level software pipeline over the wave's passes (the gather is two dependent loads: index -> coordinates): while pass k is on
     // the VALU / MFMA, the coordinates of pass k + 1 are in flight and so are the indices of pass k + 2.
-    struct Rows { F3s px[2], pq[2]; };
+    struct Rows { float px[2], pq[2]; };   // component cfq of the neighbour / of the centre
     int ivn[2];
     auto load_idx = [&](int pass, int (&v)[2]) {
 #pragma unroll
@@ -117,8 +124,8 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
         for (int mt = 0; mt < 2; ++mt) {
             const int qi = __builtin_amdgcn_readfirstlane(min((pass * 32 + mt * 16) >> LOGS, nq - 1));   // S >= 16: a tile belongs to one query
             const int f = qi / a.p;
-            rw.px[mt] = ld3(a.xyz, (unsigned)(f * a.n + v[mt]) * 3u);
-            rw.pq[mt] = ld3(a.new_xyz, (unsigned)qi * 3u);
+            rw.px[mt] = a.xyz[(unsigned)(f * a.n + v[mt]) * 3u + cfq];
+            rw.pq[mt] = a.new_xyz[(unsigned)qi * 3u + cfq];
         }
     };
     // One pass: rows `use` (requested a pass ago) through the three layers while the next pass's rows arrive in `fill` and the indices of the
@@ -133,18 +140,18 @@ __device__ __forceinline__ void sa_xyz_body(const SaXyzArgs &a, int first, int s
         // (without this fence the machine scheduler sinks both prefetches to the BOTTOM of the pass: ~15 MFMAs of cover)
         __builtin_amdgcn_sched_barrier(0);
         const int row0 = pass * 32;
-        // ---- layer 1 on the VALU, in operand layout
+        // ---- layer 1 on the matrix pipe (K = 3 padded to one k-step), in operand layout
         f32x4 h1[2][T1];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const float i0 = cur.px[mt].x - cur.pq[mt].x, i1 = cur.px[mt].y - cur.pq[mt].y, i2 = cur.px[mt].z - cur.pq[mt].z;   // pointnet2_utils.py:254
+            const float d = cur.px[mt] - cur.pq[mt];          // pointnet2_utils.py:254, this lane's component
+            const float comp = fq < 3 ? d : 0.f;
 #pragma unroll
-            for (int ks = 0; ks < T1; ++ks)
+            for (int ks = 0; ks < T1; ++ks) {
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[ks], comp, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float acc = __builtin_fmaf(w1[ks][e][2], i2, __builtin_fmaf(w1[ks][e][1], i1, w1[ks][e][0] * i0));
-                    h1[mt][ks][e] = fmaxf(__builtin_fmaf(acc, s1[ks][e], h1s[ks][e]), 0.f);
-                }
+                for (int e = 0; e < 4; ++e) h1[mt][ks][e] = fmaxf(__builtin_fmaf(acc[e], s1[ks][e], h1s[ks][e]), 0.f);
+            }
         }
         // ---- layer 2, transposed: D[out channel 4 fq + r][row fi]
         f32x4 h2[2][T2];
@@ -333,8 +340,9 @@ extern "C" int g4d_sa_xyz_mlp3_pair_f32(int b, int n, int p, const float *xyz, c
                              W3_frag1, kpad3_1, scale3_1, shift3_1, pool, out, ldo, col0_1)) return rc;
     if (a0.rows == 0) return G4D_OK;
     G4D_REQUIRE(nsample0 == 16 && nsample1 == 32, "g4d_sa_xyz_mlp3_pair_f32: scale 0 takes 16 samples, scale 1 takes 32");
-    // one persistent pool, two workgroups per CU (two waves per SIMD), never more waves than the wide stack has passes
-    static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+    // one persistent pool, three workgroups per CU (round 6: with layer 1 on the matrix pipe the kernel needs 155 registers instead of 190, three
+    // waves per SIMD fit: 534 -> 513 us at 240 clouds), never more waves than the wide stack has passes
+    static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
     const long long want = ((a1.rows + 31) / 32 + 3) / 4;
     const unsigned grid = (unsigned)(want < 256 * bpc ? want : 256 * bpc);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -364,8 +372,8 @@ extern "C" int g4d_sa_xyz_mlp3_f32(int b, int n, int p, int nsample, const float
     a.W2f = W2_frag; a.sc2 = scale2; a.sh2 = shift2; a.W3f = W3_frag; a.sc3 = scale3; a.sh3 = shift3; a.kst2 = kpad2 / 16; a.kst3 = kpad3 / 16;
     a.out = out; a.ldo = ldo; a.col0 = col0;
     const long long npass = (rows + 31) / 32, want = (npass + 3) / 4;
-    static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
-    const unsigned grid = (unsigned)(want < 256 * bpc ? want : 256 * bpc);   // persistent waves (2 per SIMD): the weights are loaded once per wave
+    static const int bpc = [] { const char *e = getenv("G4D_SA_XYZ_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 3; }();
+    const unsigned grid = (unsigned)(want < 256 * bpc ? want : 256 * bpc);   // persistent waves (3 per SIMD): the weights are loaded once per wave
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (c1 == 16) hipLaunchKernelGGL((sa_xyz_kernel<16, 16, 32>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((sa_xyz_kernel<32, 32, 64>), dim3(grid), dim3(256), 0, st, a);
