@@ -17,6 +17,7 @@
 //     64 channels per store.
 // Arithmetic and summation order are those of mlp_chain.hip's table loader and chained layers: results are bit-identical.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mlp_common.h"
 
@@ -226,10 +227,29 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
     auto sfrag = [&](int gks, int nt, int ct) -> f32x4 {
         return *reinterpret_cast<const f32x4 *>(s_stage + ((gks / kStageK) & 1) * (kStageK * T3 * 256) + (((gks % kStageK) * nt + ct) * 64 + lane) * 4);
     };
+    // DEAD TILES (round 6).  ball_query pads a neighbourhood with copies of its first hit (ball_query_gpu.cu:32-36); a padded row is the same
+    // (source point, centroid) pair as row 0, gives the same output, and max pooling does not see it.  On the encoder's third level 5 of the 32
+    // samples of the r = 0.2 scale are distinct on average (uniform clouds; fewer on surfaces): the second 16-row tile of every neighbourhood is
+    // all padding.  A tile whose rows ALL carry the neighbourhood's first index (and that is not the tile holding row 0) is skipped -- exact for
+    // any index list, padded or not; tiles_alive() = how many leading tiles of a block have to be computed (0: a whole trailing block of a
+    // 64-sample neighbourhood).  Blocks are whole neighbourhoods or halves of one here (S >= 32), waves are autonomous (no lock step to keep).
+    constexpr bool DEDUP = WM != 2 && MT == 2 && GP == 1;
+    int h0 = 0;                                      // first neighbour index of the neighbourhood the block being looked at belongs to
+    auto tiles_alive = [&](int it_, const int (&v)[MT]) {
+        if constexpr (!DEDUP) return MT;
+        else {
+            const bool head = it_ % G == 0;          // the block starts a neighbourhood
+            if (head) h0 = __builtin_amdgcn_readlane(v[0], 0);
+            const bool t1 = __builtin_amdgcn_ballot_w64(v[MT - 1] != h0) != 0ull;
+            const bool t0 = head || __builtin_amdgcn_ballot_w64(v[0] != h0) != 0ull;
+            return t1 ? 2 : (t0 ? 1 : 0);
+        }
+    };
     stage_issue(0);
     int ivn[MT];
     Rows cur, nxt;
     load_idx(block_of(0), ivn);
+    int nt_cur = tiles_alive(0, ivn), nt_nxt = MT;
     load_rows(block_of(0), ivn, cur);
     load_idx(block_of(1), ivn);
     float pm[T3];                                    // running maximum of the neighbourhood across its blocks (G > 1)
@@ -240,20 +260,24 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
         if constexpr (WM != 2) {
             if constexpr (kSpread) rows_begin(block_of(it + 1), ivn, nxt, trn);   // level 2 of the next block: pointers + coordinates now, the table rows between layer 2's chains
             else load_rows(block_of(it + 1), ivn, nxt);
+            nt_nxt = tiles_alive(it + 1, ivn);       // (the indices are in registers: rows_begin has just used them)
             load_idx(block_of(it + 2), ivn);         // level 1 of the one after
         }
+        float x[T3];                                 // the block's maximum per channel tile (compute<NT >= 1> sets it)
+        auto compute = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;  // leading row tiles of the block that are computed
         // ---- first layer: relu(affine(table row + Wx (x_j - q))), the arithmetic of mlp_chain.hip's table loader, one k-step at a time
         //      in front of that k-step's share of layer 2 (transposed: A = weights, B = activations -- lane (fi, fq) ends with channels
         //      16 ct + 4 fq + r of row fi).  Fragment (ks, ct): every accumulator sees k ascending, as in the chain kernel.
         f32x4 sring[2];
         float gx[MT], gy[MT], gz[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { gx[mt] = cur.px[mt] - cur.cx[mt]; gy[mt] = cur.py[mt] - cur.cy[mt]; gz[mt] = cur.pz[mt] - cur.cz[mt]; }
+        for (int mt = 0; mt < NT; ++mt) { gx[mt] = cur.px[mt] - cur.cx[mt]; gy[mt] = cur.py[mt] - cur.cy[mt]; gz[mt] = cur.pz[mt] - cur.cz[mt]; }
         f32x4 h2[T][MT];
 #pragma unroll
         for (int ct = 0; ct < T; ++ct)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) h2[ct][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mt = 0; mt < NT; ++mt) h2[ct][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
             constexpr int F = T * T;
             f32x4 ring[RD];
@@ -271,7 +295,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
                 const f32x4 ps = *reinterpret_cast<const f32x4 *>(s_ps + k0), pf = *reinterpret_cast<const f32x4 *>(s_pf + k0);
                 f32x4 h1[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = cur.raw[ks][mt][e] + __builtin_fmaf(wz[e], gz[mt], __builtin_fmaf(wy[e], gy[mt], wx[e] * gx[mt]));
@@ -295,7 +319,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) h2[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], h1[mt][e], h2[ct][mt], 0, 0, 0);
+                        for (int mt = 0; mt < NT; ++mt) h2[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], h1[mt][e], h2[ct][mt], 0, 0, 0);
                 }
             }
         }
@@ -311,7 +335,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
         for (int ct = 0; ct < T; ++ct) {
             const f32x4 sc = *reinterpret_cast<const f32x4 *>(s_sc2 + ct * 16 + fq * 4), sh = *reinterpret_cast<const f32x4 *>(s_sh2 + ct * 16 + fq * 4);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h2[ct][mt][r] = fmaxf(__builtin_fmaf(h2[ct][mt][r], sc[r], sh[r]), 0.f);
         }
@@ -320,7 +344,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
 #pragma unroll
         for (int ct = 0; ct < T3; ++ct)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mt = 0; mt < NT; ++mt) acc[ct][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < F3; ++f) {
             const int ks = f / T3, ct = f % T3;
@@ -353,7 +377,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[ks][mt][e], w[e], acc[ct][mt], 0, 0, 0);
+                for (int mt = 0; mt < NT; ++mt) acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[ks][mt][e], w[e], acc[ct][mt], 0, 0, 0);
         }
         // ---- affine, max over the rows, ReLU once per output (max_r relu(y_r) = relu(max_r y_r) exactly)
         float v[T3][MT];
@@ -361,7 +385,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
         for (int ct = 0; ct < T3; ++ct) {
             const float sc = s_sc3[ct * 16 + fi], sh = s_sh3[ct * 16 + fi];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < NT; ++mt) {
                 const float y0 = __builtin_fmaf(acc[ct][mt][0], sc, sh), y1 = __builtin_fmaf(acc[ct][mt][1], sc, sh),
                             y2 = __builtin_fmaf(acc[ct][mt][2], sc, sh), y3 = __builtin_fmaf(acc[ct][mt][3], sc, sh);
                 v[ct][mt] = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
@@ -378,18 +402,33 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
                 }
             }
         } else {
-            float x[T3];
 #pragma unroll
             for (int ct = 0; ct < T3; ++ct) {
                 x[ct] = v[ct][0];
 #pragma unroll
-                for (int mt = 1; mt < MT; ++mt) x[ct] = fmaxf(x[ct], v[ct][mt]);
+                for (int mt = 1; mt < NT; ++mt) x[ct] = fmaxf(x[ct], v[ct][mt]);
             }
-            const int j = it % G;
             if constexpr (G > 1) {
+                const int j = it % G;
 #pragma unroll
                 for (int ct = 0; ct < T3; ++ct) pm[ct] = j == 0 ? x[ct] : fmaxf(pm[ct], x[ct]);
             }
+        }
+        };   // compute
+        if (!DEDUP || nt_cur == MT) compute(std::integral_constant<int, MT>{});
+        else if (nt_cur == 1) compute(std::integral_constant<int, 1>{});
+        else {                                       // a block of padding only: nothing to compute, the pipeline moves on
+            if constexpr (WM != 2) {
+                if constexpr (kSpread) {
+#pragma unroll
+                    for (int q = 0; q < T * MT; ++q) rows_raw(trn, nxt, q);
+                }
+                cur = nxt;
+            }
+        }
+        nt_cur = nt_nxt;
+        if constexpr (GP == 1) {
+            const int j = it % G;
             if (j == G - 1) {
                 const int g = blk / G;
 #pragma unroll

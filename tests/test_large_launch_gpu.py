@@ -59,6 +59,41 @@ def test_sa_table_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, mlps, 
     np.testing.assert_allclose(fused.to_channel_major(outs[1]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("C,mlp,S", [(40, [40, 64, 64, 128], 32), (24, [24, 32, 32, 64], 32), (40, [40, 64, 64, 128], 64)])
+@pytest.mark.parametrize("kind", ["ball_r0.04", "ball_r0.3", "arbitrary"])
+def test_sa_table_dead_tile_skipping_is_exact(C, mlp, S, kind):
+    """Round 6: sa_table.hip skips a 16-row tile whose rows all carry the neighbourhood's first index (ball_query's padding: the same (source
+    point, centroid) pair as row 0, so the same output -- max pooling does not see it).  Bit-identical to the chain kernel, which computes every
+    row: tiny balls (almost every second tile is padding, many neighbourhoods without a hit at all), large balls (no padding) and ARBITRARY index
+    lists -- padding-like runs that do NOT start at a tile boundary, a dead first tile behind a live one in the second half of a 64-sample
+    neighbourhood, a neighbourhood of one index repeated, rows equal to the first index scattered among others."""
+    torch.manual_seed(C + S)
+    B, N, P = 3, 512, 77
+    xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=S)).cuda()
+    fpm = torch.randn(B, N, C, device="cuda")
+    new_xyz = fused.fps_gather(xyz, P)
+    sa = _seed_bn(PM.PointnetSAModule(npoint=P, radius=0.3, nsample=S, mlp=list(mlp)))
+    if kind == "arbitrary":
+        g = torch.Generator().manual_seed(5)
+        idx = torch.randint(0, N, (B, P, S), generator=g, dtype=torch.int32)
+        first = idx[..., :1]
+        idx[:, 0::7, 16:] = first[:, 0::7]                       # second tile (and everything behind it) = padding
+        idx[:, 1::7, 9:] = first[:, 1::7]                        # padding that starts inside the first tile
+        idx[:, 2::7, :] = first[:, 2::7]                         # one index repeated S times
+        idx[:, 3::7, 16:32] = first[:, 3::7]                     # S = 64: a dead tile with live rows behind it
+        idx[:, 4::7, 32:48] = first[:, 4::7]                     # S = 64: the second block's FIRST tile dead, its second alive
+        idx[:, 5::7, 5::3] = first[:, 5::7]                      # the first index scattered among others
+        idxs = [idx.cuda()]
+    else:
+        idxs = fused.ball_query_msg([float(kind.split("r")[1])], [S], xyz, new_xyz)
+    outs = {}
+    with torch.no_grad():
+        for on in (0, 1):
+            with tuning(sa_table_persistent=on, sa_table_min_rows=0):
+                outs[on] = fused.sa_forward(sa, xyz, fpm, new_xyz=new_xyz, idxs=idxs)[1]
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("widths,S,native", [
     ((64, 64, 128), 64, {}),                                  # BASELINE config 5's stack: the persistent kernel reads a stride-0 table row
     ((64, 64, 128), 64, {"sa_table_persistent": 0}),          # ADVICE r5: with the A/B switch off the stride-0 route must not be chosen (used to raise)
