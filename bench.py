@@ -154,6 +154,35 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
         if smpl is not None:
             G.lbs(betas, pose, smpl["v_template"], smpl["shapedirs"], smpl["posedirs"], smpl["J_regressor"], smpl["parents"], smpl["lbs_weights"], pose2rot=True)
 
+    # The persistent SA kernels skip 16-row tiles / blocks that hold nothing but ball-query padding (round 6, csrc/sa_table.hip): the flops a launch
+    # EXECUTES depend on the clouds.  Recorded here from the index lists of one call, with the kernels' own rule, per table launch in call order.
+    live_frac = []
+    if precision == "fp32":
+        real = fused.sa_scale_mlp
+
+        def spy(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=None, tab_ld=None):
+            if table is not None and pool == 1:
+                S = idx.shape[2]
+                kt = layers[0].Cout
+                if S >= 32 and kt in (32, 64, 128):
+                    t = idx.view(idx.shape[0], idx.shape[1], S // 16, 16)
+                    livet = (t != idx[..., :1].unsqueeze(-1)).any(-1)                       # tile holds an index other than the first
+                    livet[..., 0] = True
+                    if kt == 128:                                                            # lock-step kernel: 1 + last live block
+                        nb = (livet * torch.arange(1, S // 16 + 1, device=idx.device)).amax(-1)
+                        live_frac.append(float(nb.sum()) / float(livet.numel()))
+                    else:                                                                    # autonomous waves: per 32-row block, leading live tiles
+                        pr = livet.view(idx.shape[0], idx.shape[1], S // 32, 2)
+                        nt = torch.where(pr[..., 1], 2, torch.where(pr[..., 0], 1, 0))
+                        live_frac.append(float(nt.sum()) / float(livet.numel()))
+                else:
+                    live_frac.append(1.0)
+            return real(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=table, tab_ld=tab_ld)
+        fused.sa_scale_mlp = spy
+        try:
+            call()
+        finally:
+            fused.sa_scale_mlp = real
     call()
     torch.cuda.synchronize()
     passes = []
@@ -173,7 +202,7 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     mfma_peak = (MFMA_F32_PEAK_TFLOPS if precision == "fp32" else MFMA_BF16_PEAK_TFLOPS) * 1e12
     rows_out, labels = [], {}
     sa_lvl = {}
-    chain_i = lin_i = 0
+    chain_i = lin_i = tab_i = 0
     chain_desc = []
     for li in (1, 2):                                  # SA levels 2 and 3, scale 0 then scale 1: layers behind the first-layer table
         for si, mlp in enumerate(SA[li].mlps):
@@ -225,12 +254,17 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             rows_, k_, cout_ = iv[0], iv[3], iv[5]
             row.update(what=f"{rows_} rows x {k_} skip columns -> {cout_}, interpolated table of the known rows added in the epilogue (wide FP level)", bound="mfma",
                        executed_flops=2.0 * rows_ * k_ * cout_, algorithmic_flops=2.0 * rows_ * k_ * cout_)
-        elif nm in ("g4d_mlp_chain_group_table_f32", "g4d_mlp_chain_interp_init_f32", "g4d_mlp_chain_table_cells_f32", "g4d_mlp_chain_table_f32", "g4d_mlp_chain_f32",
+        elif nm in ("g4d_mlp_chain_group_table_f32", "g4d_mlp_chain_group_table_ws_f32", "g4d_mlp_chain_interp_init_f32", "g4d_mlp_chain_table_cells_f32", "g4d_mlp_chain_table_f32", "g4d_mlp_chain_f32",
                     "g4d_mlp_chain_bf16", "g4d_mlp_chain_cells_bf16", "g4d_mlp_stack_bf16") and chain_i < len(chain_desc):
             desc, layers, full = chain_desc[chain_i]
             chain_i += 1
             rows_ = iv[1] if nm in ("g4d_mlp_chain_bf16", "g4d_mlp_chain_cells_bf16", "g4d_mlp_stack_bf16", "g4d_mlp_chain_f32") else iv[0]   # (these take the loader mode first)
-            row.update(what=desc, bound="mfma", executed_flops=2.0 * rows_ * sum(k * c for k, c in layers), algorithmic_flops=2.0 * rows_ * sum(k * c for k, c in full))
+            lf = 1.0
+            if nm.startswith("g4d_mlp_chain_group_table") and tab_i < len(live_frac):
+                lf = live_frac[tab_i]
+                tab_i += 1
+                row["live_rows_frac"] = lf      # share of the grouped rows that are computed (the rest: tiles of ball-query padding, skipped)
+            row.update(what=desc, bound="mfma", executed_flops=2.0 * rows_ * lf * sum(k * c for k, c in layers), algorithmic_flops=2.0 * rows_ * sum(k * c for k, c in full))
         elif nm in ("g4d_three_nn_cells_sorted_f32", "g4d_three_nn_cells_f32"):
             b_, n_, m_ = iv[0], iv[1], iv[2]
             ev = float(b_) * n_ * m_
@@ -709,7 +743,7 @@ def main():
             "roofline_hbm": roof.get("roofline_hbm"),
             "launches": {"clouds_per_call": B_CLOUDS * kco, "eager_one_stream_us": call_us, "note": "one coalesced call launched eagerly on one stream, HIP events around every "
                          "C-ABI call (median of 3): us per call and per B=8 step", "table": [{k: (round(v, 3) if isinstance(v, float) and k in ("us", "us_per_step", "frac") else v)
-                                                                                              for k, v in r.items() if k in ("entry", "what", "us", "us_per_step", "bound", "frac")} for r in table]},
+                                                                                              for k, v in r.items() if k in ("entry", "what", "us", "us_per_step", "bound", "frac", "live_rows_frac")} for r in table]},
             # SURVEY 8(d) whole-path fractions, per GPU: frames/s x per-frame algorithmic cost / peak
             "whole_path": {"mfma_frac": per_gpu * 2.22e9 / (MFMA_F32_PEAK_TFLOPS * 1e12 if args.precision == "fp32" else 2.5e15),
                            # what the matrix pipe actually delivers: the MFMA flops one coalesced call EXECUTES (first layers pre-contracted per source point in fp32

@@ -81,6 +81,9 @@ SIGNATURES = {
     "g4d_mlp_chain_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_group_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
     "g4d_sa_table_supported": [ctypes.c_longlong, _I, _I, _I],
+    "g4d_sa_table_ws_bytes": [ctypes.c_longlong, _I, _I, _I],
+    "g4d_mlp_chain_group_table_ws_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp,
+                                         ctypes.c_longlong, _vp],
     "g4d_three_nn_cells_f32": [_I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp],
     "g4d_mlp_chain_interp_init_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_three_nn_multi_f32": [_I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -120,7 +123,7 @@ SIGNATURES = {
 _lib = None
 
 
-RESTYPES = {"g4d_gcn_tile_meta_bytes": ctypes.c_longlong, "g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_three_nn_pruned_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
+RESTYPES = {"g4d_sa_table_ws_bytes": ctypes.c_longlong, "g4d_gcn_tile_meta_bytes": ctypes.c_longlong, "g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_three_nn_pruned_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):

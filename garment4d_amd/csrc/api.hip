@@ -45,7 +45,7 @@ int distance_contraction() {
 namespace g4d {
 namespace {
 struct Tune { const char *key; long long value; int state; };   // state: 0 unset, 1 from the environment / default (cached), 2 set by g4d_tuning_set
-Tune g_tune[] = {{"sa_table_persistent", 0, 0}, {"sa_table_min_rows", 0, 0}, {"sa_table_128", 0, 0}, {"sa_table_oversub", 0, 0}, {"fp_table_persistent", 0, 0},
+Tune g_tune[] = {{"sa_table_persistent", 0, 0}, {"sa_table_min_rows", 0, 0}, {"sa_table_128", 0, 0}, {"sa_table_oversub", 0, 0}, {"sa_table_dedup", 0, 0}, {"fp_table_persistent", 0, 0},
                  {"fp_table_min_rows", 0, 0}, {"gemm_tile", 0, 0}, {"gemm_tile_min_rows", 0, 0}, {"gemm_tile_min_cout", 0, 0}, {"gemm_tile_min_kpad", 0, 0}, {"fp_init_persistent", 0, 0}, {"fp_init_min_rows", 0, 0},
                  {"fp_head_bf16_persistent", 0, 0}, {"fp_head_bf16_min_rows", 0, 0}, {"sa_group_bf16_persistent", 0, 0}, {"sa_group_bf16_min_rows", 0, 0}};
 }

@@ -791,13 +791,24 @@ extern "C" int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S
                                              const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
                                              const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool,
                                              float *out, int ldo, int col0, g4d_stream_t stream) {
+    return g4d_mlp_chain_group_table_ws_f32(rows, N, P, S, xyz, new_xyz, idx, table, tab_ld, Kt, tab_wx, pre_scale, pre_shift, nlayers, W, scale, shift, Kpad,
+                                            Cout, relu, pool, out, ldo, col0, nullptr, 0, stream);
+}
+
+// The same launch with caller-owned scratch (g4d_sa_table_ws_bytes; ws == NULL / too small: every block is computed): the widest stack's
+// lock-step kernel then walks a work list without the blocks that hold ball-query padding only.  Same bits either way.
+extern "C" int g4d_mlp_chain_group_table_ws_f32(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx,
+                                                const float *table, int tab_ld, int Kt, const float *tab_wx, const float *pre_scale,
+                                                const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
+                                                const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool,
+                                                float *out, int ldo, int col0, void *ws, long long ws_bytes, g4d_stream_t stream) {
     G4D_REQUIRE(table && Kt > 0, "g4d_mlp_chain_group_table_f32: null table");
     if (xyz && new_xyz && idx && tab_wx && pre_scale && pre_shift && W && scale && shift && Kpad && Cout && relu && out && (tab_ld >= Kt || tab_ld == 0) && tab_ld % 4 == 0 &&
         (reinterpret_cast<size_t>(table) & 15) == 0 && P > 0 && N > 0) {
         // large launches: the persistent, software-pipelined kernel (sa_table.hip; bit-identical results).  Inside a launch group it simply goes out
         // on its own -- merging launches pays only while they are small.
         const int rc = sa_table_try(rows, N, P, S, xyz, new_xyz, idx, table, tab_ld, Kt, tab_wx, pre_scale, pre_shift, nlayers, W, scale, shift, Kpad,
-                                    Cout, relu, pool, out, ldo, col0, reinterpret_cast<hipStream_t>(stream));
+                                    Cout, relu, pool, out, ldo, col0, reinterpret_cast<hipStream_t>(stream), ws, ws_bytes);
         if (rc != -1) return rc;
     }
     return chain_f32_impl(LOAD_GROUP, rows, Kt, nullptr, 0, N, P, S, 0, 1, xyz, new_xyz, nullptr, idx, 0, 0, 0, 0, nullptr, nullptr, nullptr,

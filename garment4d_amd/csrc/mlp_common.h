@@ -112,7 +112,8 @@ int sa_group_bf16_try(long long rows, int N, int P, int S, int C, int use_xyz, c
 // sa_table.hip: persistent, software-pipelined form of g4d_mlp_chain_group_table_f32 for large launches (same arguments); -1 = not its kind
 int sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld, int Kt,
                  const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
-                 const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, hipStream_t st);
+                 const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, hipStream_t st,
+                 void *ws = nullptr, long long ws_bytes = 0);   // ws: scratch for the work list that skips blocks of ball-query padding (g4d_sa_table_ws_bytes)
 
 template <int MODE>
 struct RowCtx {  // per-thread, per-row state reused across K chunks

@@ -36,7 +36,90 @@ struct SaTabArgs {
     const float *W3, *sc3, *sh3;         // (T k-steps per channel tile: Kpad == C)
     float *out;
     int ldo, col0;
+    // WM == 2 with a work list (round 6, sa_units_*_kernel below): wave w of workgroup g walks items[(4 g + w) * cap + i], i < wg_len[g];
+    // nullptr: the static partition of rounds 4-5 (every block of every neighbourhood)
+    const int *items, *wg_len;
+    int cap;
 };
+
+// ---- work list of the lock-step kernel (round 6).  A neighbourhood of S = 64 samples is four 16-row blocks, and ball_query pads it with copies
+// of its first hit: a block of padding only reproduces row 0's output, and max pooling does not see it.  On the encoder's third level (r = 0.4
+// over 256 points) 31 of the 64 samples are distinct on average, 2.4 of the 4 blocks.  The four waves of a workgroup run in lock step (they
+// share every weight fragment through LDS), so they must be given neighbourhoods with the SAME number of live blocks:
+//   sa_units_count_kernel   live blocks nb(q) = 1 + the last block holding an index other than the first, per neighbourhood; neighbourhoods
+//                           counting-sorted by nb into G lists (one wave ranks 64 of them with ballots, one global atomic per list and wave);
+//   sa_units_items_kernel   rounds of four neighbourhoods of equal nb, longest first, dealt round-robin to the workgroups of the main launch
+//                           (sorted dealing balances them to within one round) and written out as one item list per wave:
+//                           item = block number | first-of-neighbourhood | last | dead (a padding slot of a round / of a workgroup's list).
+// The main kernel only replaces its arithmetic block number by a (prefetched) item.  Exact for ANY index list: a block is dropped only if every
+// one of its rows carries the neighbourhood's first index, i.e. is the same (source point, centroid) pair as row 0.
+constexpr int kItemFirst = 1 << 28, kItemLast = 1 << 29, kItemDead = 1 << 30, kItemBlk = (1 << 28) - 1;
+
+// counts[1 .. G]: neighbourhoods with nb live blocks; order[(nb - 1) * nq_cap + i]: the i-th of them.  One wave ranks 64 neighbourhoods.
+template <int S>
+__global__ void __launch_bounds__(256) sa_units_count_kernel(int nq, int nq_cap, const int *__restrict__ idx, int *__restrict__ counts, int *__restrict__ order) {
+    constexpr int G = S / 16, UPL = 64 / S;          // neighbourhoods per 64-lane load
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int q0 = wave * 64;                        // this wave's 64 neighbourhoods: lane l keeps nb of neighbourhood q0 + l
+    if (q0 >= nq) return;
+    int mine = 0;
+    // all of the wave's loads first (64 / UPL independent 256-byte rows in flight: one memory round trip instead of eight), then the ranking
+    int vv[64 / UPL];
+    const long long last_ = (long long)nq * S - 1;
+#pragma unroll
+    for (int i = 0; i < 64 / UPL; ++i) {
+        const long long e_ = (long long)(q0 + i * UPL) * S + lane;
+        vv[i] = idx[e_ < last_ ? e_ : last_];        // (past the end: clamped, dropped below -- a neighbourhood inside the range has all its rows inside)
+    }
+#pragma unroll
+    for (int i = 0; i < 64 / UPL; ++i) {
+        const int v = vv[i];
+#pragma unroll
+        for (int u = 0; u < UPL; ++u) {
+            const int h0 = __builtin_amdgcn_readlane(v, u * S);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(v != h0);
+            if constexpr (UPL == 2) m = u == 0 ? (m & 0xffffffffull) : (m >> 32);
+            const int nb = m ? (63 - __builtin_clzll(m)) / 16 + 1 : 1;
+            if (lane == i * UPL + u) mine = nb;
+        }
+    }
+    const bool ok = q0 + lane < nq;
+#pragma unroll
+    for (int b = 1; b <= G; ++b) {
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(ok && mine == b);
+        if (mk == 0ull) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&counts[b], (int)__builtin_popcountll(mk));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ok && mine == b) order[(size_t)(b - 1) * nq_cap + base + (int)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = q0 + lane;
+    }
+}
+
+// thread = (workgroup g, wave w) of the main launch: its item list.  Rounds: all neighbourhoods with G live blocks first, four per round, then
+// G - 1, ...; round r goes to workgroup r % nwg.
+__global__ void __launch_bounds__(256) sa_units_items_kernel(int G, int nq_cap, int nwg, int cap, const int *__restrict__ counts, const int *__restrict__ order,
+                                                             int *__restrict__ items, int *__restrict__ wg_len) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nwg * 4) return;
+    const int g = t >> 2, w = t & 3;
+    int *mine = items + (size_t)t * cap;
+    int n = 0, r0 = 0;                               // items written; first round of the bucket being walked
+    for (int b = G; b >= 1; --b) {
+        const int c = counts[b], rb = (c + 3) >> 2;
+        // this workgroup's rounds of the bucket: r = g, g + nwg, ... within [r0, r0 + rb)
+        int r = r0 + ((g - r0 % nwg + nwg) % nwg);
+        for (; r < r0 + rb; r += nwg) {
+            const int e = (r - r0) * 4 + w;          // entry of the bucket's list
+            const int q = e < c ? order[(size_t)(b - 1) * nq_cap + e] : -1;
+            for (int j = 0; j < b && n < cap; ++j)
+                mine[n++] = q < 0 ? kItemDead : ((q * G + j) | (j == 0 ? kItemFirst : 0) | (j == b - 1 ? kItemLast : 0));
+        }
+        r0 += rb;
+    }
+    if (w == 0) wg_len[g] = n;                       // (the same for the four waves: equal nb per round)
+    for (; n < cap; ++n) mine[n] = kItemDead;
+}
+
 
 __device__ __forceinline__ float pool4_rows_max_t(float v0, float v1, float v2, float v3) {   // sa_xyz.hip: lane 16 c + fi = max over the 16 rows of tile c
     const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
@@ -104,12 +187,21 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
     const int nwaves = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
     const int nq = a.rows / S;
 
-    // block of iteration `it` of this wave (past the wave's last block: clamped -- read again, never used)
-    auto block_of = [&](int it) {
-        const int unit = wg + (it / G) * nwaves;
-        return min(unit * G + it % G, nblk - 1);
+    // WM == 2 with a work list: the items of iterations it .. it + 3 (item 3 in flight), shifted at the end of every iteration
+    const bool listed = WM == 2 && a.items != nullptr;
+    const int *my_items = listed ? a.items + (size_t)wg * a.cap : nullptr;
+    int itm0 = 0, itm1 = 0, itm2 = 0, itm3 = 0;
+    auto item_at = [&](int i) { return my_items[min(i, a.cap - 1)]; };   // (wave-uniform address: a scalar load)
+    if (listed) { itm0 = item_at(0); itm1 = item_at(1); itm2 = item_at(2); itm3 = item_at(3); }
+    // block of iteration `it` + d of this wave, d = 0, 1, 2 (past the wave's last block: clamped -- read again, never used)
+    auto block_of = [&](int it, int d = 0) {
+        if (listed) return min((d == 0 ? itm0 : (d == 1 ? itm1 : itm2)) & kItemBlk, nblk - 1);
+        const int unit = wg + ((it + d) / G) * nwaves;
+        return min(unit * G + (it + d) % G, nblk - 1);
     };
-    auto live = [&](int it) { return WM != 2 || wg + (it / G) * nwaves < nunit; };   // WM == 2: is this iteration's unit real?
+    auto live = [&](int it) { return WM != 2 || (listed ? !(itm0 & kItemDead) : wg + (it / G) * nwaves < nunit); };   // WM == 2: is this iteration's unit real?
+    auto blk_first = [&](int it) { return listed ? (itm0 & kItemFirst) != 0 : it % G == 0; };   // first / last block of its neighbourhood
+    auto blk_last = [&](int it) { return listed ? (itm0 & kItemLast) != 0 : it % G == G - 1; };
     struct Rows { f32x4 raw[T][MT]; float px[MT], py[MT], pz[MT], cx[MT], cy[MT], cz[MT]; };
     auto load_idx = [&](int blk, int (&v)[MT]) {
 #pragma unroll
@@ -157,7 +249,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
     // computes on clamped rows and stores nothing
     const int units_first = WM == 2 ? blockIdx.x * 4 : wg;
     const int my_units = units_first < nunit ? (nunit - units_first + nwaves - 1) / nwaves : 0;
-    const int iters = my_units * G;
+    const int iters = listed ? a.wg_len[blockIdx.x] : my_units * G;
     if (iters == 0) return;
     // kStageK k-steps' fragments (a chunk) into the stage buffer `chunk & 1`: chunks 0 .. T/kStageK-1 are layer 2's, the rest layer 3's; periodic
     // per block (an even number of chunks).  Fragment (kk, ct) of a chunk sits at slot kk * (tiles of the layer) + ct.
@@ -251,17 +343,17 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
     load_idx(block_of(0), ivn);
     int nt_cur = tiles_alive(0, ivn), nt_nxt = MT;
     load_rows(block_of(0), ivn, cur);
-    load_idx(block_of(1), ivn);
+    load_idx(block_of(0, 1), ivn);
     float pm[T3];                                    // running maximum of the neighbourhood across its blocks (G > 1)
     const float *trn[MT];                            // table-row pointers of the next block (rows_begin -> rows_raw)
     for (int it = 0; it < iters; ++it) {
         const int blk = block_of(it);
         if constexpr (WM != 1) asm volatile("" : "+v"(lane16));   // no hoisted fragment addresses
         if constexpr (WM != 2) {
-            if constexpr (kSpread) rows_begin(block_of(it + 1), ivn, nxt, trn);   // level 2 of the next block: pointers + coordinates now, the table rows between layer 2's chains
-            else load_rows(block_of(it + 1), ivn, nxt);
+            if constexpr (kSpread) rows_begin(block_of(it, 1), ivn, nxt, trn);   // level 2 of the next block: pointers + coordinates now, the table rows between layer 2's chains
+            else load_rows(block_of(it, 1), ivn, nxt);
             nt_nxt = tiles_alive(it + 1, ivn);       // (the indices are in registers: rows_begin has just used them)
-            load_idx(block_of(it + 2), ivn);         // level 1 of the one after
+            load_idx(block_of(it, 2), ivn);         // level 1 of the one after
         }
         float x[T3];                                 // the block's maximum per channel tile (compute<NT >= 1> sets it)
         auto compute = [&](auto nt_tag) {
@@ -353,9 +445,9 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
                 if constexpr (WM == 2) {
                     if (ks == 0) {   // the next block's rows: requested here, behind a k-step barrier -- every barrier drains this wave's loads (vmcnt(0)),
                                      // so they get the 2k cycles of layer 3's first k-step instead of stalling the block's first one
-                        if constexpr (kSpread) rows_begin(block_of(it + 1), ivn, nxt, trn);   // (the table rows: between the chains below)
-                        else load_rows(block_of(it + 1), ivn, nxt);
-                        load_idx(block_of(it + 2), ivn);
+                        if constexpr (kSpread) rows_begin(block_of(it, 1), ivn, nxt, trn);   // (the table rows: between the chains below)
+                        else load_rows(block_of(it, 1), ivn, nxt);
+                        load_idx(block_of(it, 2), ivn);
                     }
                 }
             }
@@ -409,9 +501,9 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
                 for (int mt = 1; mt < NT; ++mt) x[ct] = fmaxf(x[ct], v[ct][mt]);
             }
             if constexpr (G > 1) {
-                const int j = it % G;
+                const bool first = blk_first(it);
 #pragma unroll
-                for (int ct = 0; ct < T3; ++ct) pm[ct] = j == 0 ? x[ct] : fmaxf(pm[ct], x[ct]);
+                for (int ct = 0; ct < T3; ++ct) pm[ct] = first ? x[ct] : fmaxf(pm[ct], x[ct]);
             }
         }
         };   // compute
@@ -428,8 +520,7 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
         }
         nt_cur = nt_nxt;
         if constexpr (GP == 1) {
-            const int j = it % G;
-            if (j == G - 1) {
+            if (blk_last(it)) {
                 const int g = blk / G;
 #pragma unroll
                 for (int c4 = 0; c4 < T3 / 4; ++c4) {
@@ -440,7 +531,10 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
                 }
             }
         }
-        if constexpr (WM == 2) cur = nxt;
+        if constexpr (WM == 2) {
+            cur = nxt;
+            if (listed) { itm0 = itm1; itm1 = itm2; itm2 = itm3; itm3 = item_at(it + 4); }
+        }
     }
 }
 
@@ -448,8 +542,22 @@ __global__ void __launch_bounds__(256, (WM == 1 && C == 64 && S == 32 && G4D_SA6
 
 using namespace g4d;
 
+// workspace of the lock-step kernel's work list for nq neighbourhoods of G blocks dealt to at most nwg_max workgroups:
+// counts[8] | order[G * nq] | wg_len[nwg_max] | items[nwg_max * 4 * cap]
+namespace {
+constexpr int kListWgMax = 1024;                 // >= resident workgroups of the lock-step kernel (2 per CU)
+inline long long list_cap(long long nq, int G, long long nwg) { return (((nq + 3) / 4 + G + nwg - 1) / nwg + 1) * G; }
+inline long long list_bytes(long long nq, int G) {
+    // (cap shrinks as the grid grows: size for the smallest grid that can occur, min(want, resident) >= min(want, 1), bounded by the list itself)
+    const long long want = (nq + 3) / 4;
+    const long long nwg_lo = want < kListWgMax ? want : 256;   // a launch uses min(want, resident) workgroups, resident in [256, kListWgMax]
+    const long long items = (want < kListWgMax ? want : (long long)kListWgMax) * 4 * list_cap(nq, G, nwg_lo);
+    return 32 + 4 * ((long long)G * nq + kListWgMax + items);
+}
+}  // namespace
+
 template <int C, int S, int MT, int WM>
-static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
+static int sa_table_launch(SaTabArgs a, hipStream_t st, void *ws = nullptr, long long ws_bytes = 0) {
     constexpr bool WLDS = WM == 1;
     const int lds = (int)sizeof(float) * (11 * C + (WLDS ? 3 * C * C : 0) + (WM == 2 ? 2 * kStageK * (C / 8) * 256 : 0));
     static unsigned long long attr = 0;
@@ -472,6 +580,19 @@ static int sa_table_launch(const SaTabArgs &a, hipStream_t st) {
     //  them over whatever CUs other streams' launches leave free; A/B switch)
     const long long cap = (long long)resident * (long long)tuning("sa_table_oversub", 1);
     const unsigned grid = (unsigned)(want < cap ? want : cap);
+    a.items = nullptr; a.wg_len = nullptr; a.cap = 0;
+    if constexpr (WM == 2) {
+        const long long nq = a.rows / S;
+        if (ws && tuning("sa_table_dedup", 1) && a.rows % S == 0 && grid <= (unsigned)kListWgMax && ws_bytes >= list_bytes(nq, G) && nq * G < (1ll << 28)) {
+            int *counts = reinterpret_cast<int *>(ws), *order = counts + 8, *wg_len = order + (size_t)G * nq, *items = wg_len + kListWgMax;
+            const long long icap = list_cap(nq, G, grid);
+            if (hipMemsetAsync(counts, 0, 32, st) != hipSuccess) return check_launch("g4d_sa_table(work list)");
+            hipLaunchKernelGGL((sa_units_count_kernel<S>), dim3((unsigned)(((nq + 63) / 64 + 3) / 4)), dim3(256), 0, st, (int)nq, (int)nq, a.idx, counts, order);
+            hipLaunchKernelGGL(sa_units_items_kernel, dim3((grid * 4 + 255) / 256), dim3(256), 0, st, G, (int)nq, (int)grid, (int)icap, counts, order, items, wg_len);
+            if (const int rc = check_launch("g4d_sa_table(work list)")) return rc;
+            a.items = items; a.wg_len = wg_len; a.cap = (int)icap;
+        }
+    }
     hipLaunchKernelGGL((sa_table_kernel<C, S, MT, WM>), dim3(grid), dim3(256), lds, st, a);
     return check_launch("g4d_sa_table");
 }
@@ -488,12 +609,19 @@ extern "C" int g4d_sa_table_supported(long long rows, int Kt, int S, int pool) {
     return (wide && Kt == 128 && (S == 32 || S == 64)) ? 1 : 0;
 }
 
+// Bytes of caller-owned scratch with which a g4d_mlp_chain_group_table_ws_f32 launch of this shape skips the blocks of ball-query padding (the
+// lock-step kernel's work list: Kt = 128 only -- the narrower stacks skip dead tiles without one); 0: the shape / tuning state takes none.
+extern "C" long long g4d_sa_table_ws_bytes(long long rows, int Kt, int S, int pool) {
+    if (Kt != 128 || !(S == 64 || S == 32) || !g4d_sa_table_supported(rows, Kt, S, pool) || !g4d::tuning("sa_table_dedup", 1) || rows % S != 0) return 0;
+    return list_bytes(rows / S, S / 16);
+}
+
 // Takes the launch if it is one of the instantiated shapes and large enough to pipeline (several row blocks per resident wave);
 // returns -1 when it is not (the caller then runs the register-chain kernel), else the launch status.
 int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx, const float *table, int tab_ld,
                       int Kt, const float *tab_wx, const float *pre_scale, const float *pre_shift, int nlayers, const float *const *W,
                       const float *const *scale, const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
-                      int ldo, int col0, hipStream_t st) {
+                      int ldo, int col0, hipStream_t st, void *ws, long long ws_bytes) {
     if (nlayers != 2 || !g4d_sa_table_supported(rows, Kt, S, pool)) return -1;
     if (Cout[0] != Kt || Cout[1] != 2 * Kt || !relu[0] || !relu[1] || Kpad[0] != Kt || Kpad[1] != Kt) return -1;
     if ((long long)(rows / S / P) * N >= (1ll << 31)) return -1;
@@ -515,7 +643,7 @@ int g4d::sa_table_try(long long rows, int N, int P, int S, const float *xyz, con
     if (Kt == 64 && S == 16) return sa_table_launch<64, 16, 1, 1>(a, st);
     const int wide = (int)tuning("sa_table_128", 1);   // A/B switch: the 128-wide stack (weights streamed from L2: 192 KB do not fit LDS)
     if (wide == 2 && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, 0>(a, st);   // (A/B: every wave streaming its own fragments)
-    if (wide && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, 2>(a, st);
-    if (wide && Kt == 128 && S == 32) return sa_table_launch<128, 32, 1, 2>(a, st);
+    if (wide && Kt == 128 && S == 64) return sa_table_launch<128, 64, 1, 2>(a, st, ws, ws_bytes);
+    if (wide && Kt == 128 && S == 32) return sa_table_launch<128, 32, 1, 2>(a, st, ws, ws_bytes);
     return -1;
 }

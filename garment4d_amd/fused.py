@@ -717,12 +717,15 @@ def sa_scale_mlp(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, 
         tab, c0, wxT = table
         L0, rest = layers[0], layers[1:]
         PA, IA = ctypes.c_void_p * len(rest), ctypes.c_int * len(rest)
-        _lib.call("g4d_mlp_chain_group_table_f32", B * P * S, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
+        # scratch for the widest stack's work list (round 6: blocks of ball-query padding are not computed; csrc/sa_table.hip) -- 0 bytes for every other shape
+        nws = int(_lib.lib().g4d_sa_table_ws_bytes(B * P * S, L0.Cout, S, pool)) if len(rest) == 2 else 0
+        ws = torch.empty((nws + 3) // 4, dtype=torch.int32, device=xyz.device) if nws > 0 else None
+        _lib.call("g4d_mlp_chain_group_table_ws_f32", B * P * S, N, P, S, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
                   tab.data_ptr() + 4 * c0, tab.shape[-1] if tab_ld is None else tab_ld, L0.Cout, wxT.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), len(rest),
                   ctypes.cast(PA(*[L.Wf.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(PA(*[L.scale.data_ptr() for L in rest]), ctypes.c_void_p),
                   ctypes.cast(PA(*[L.shift.data_ptr() for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.Kpad for L in rest]), ctypes.c_void_p),
                   ctypes.cast(IA(*[L.Cout for L in rest]), ctypes.c_void_p), ctypes.cast(IA(*[L.relu for L in rest]), ctypes.c_void_p),
-                  pool, out.data_ptr(), out.shape[-1], col0, stream)
+                  pool, out.data_ptr(), out.shape[-1], col0, _ptr(ws), nws, stream)
         return
 
     def first(L, pl, o, c0):

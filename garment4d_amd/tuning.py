@@ -38,7 +38,7 @@ def _env_int(name, default):
     return int(os.environ.get(name, str(default)))
 
 
-NATIVE_KEYS = ("sa_table_persistent", "sa_table_min_rows", "sa_table_128", "sa_table_oversub", "fp_table_persistent", "fp_table_min_rows", "gemm_tile",
+NATIVE_KEYS = ("sa_table_persistent", "sa_table_min_rows", "sa_table_128", "sa_table_oversub", "sa_table_dedup", "fp_table_persistent", "fp_table_min_rows", "gemm_tile",
                "gemm_tile_min_rows", "gemm_tile_min_cout", "gemm_tile_min_kpad", "fp_init_persistent", "fp_init_min_rows",
                "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "sa_group_bf16_persistent", "sa_group_bf16_min_rows")
 

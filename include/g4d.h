@@ -353,7 +353,7 @@ int g4d_linear_interp_add_f32(long long rows, int n, int m, int K, int Kpad, int
                               int tab_ld, const float *dist2, const int *nn_idx, const float *scale, const float *shift, int relu, float *out, int ldo,
                               int col0, g4d_stream_t stream);
 
-/* Run-time tuning switches of the large-launch kernels.  Keys: "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "sa_table_oversub", "fp_table_persistent",
+/* Run-time tuning switches of the large-launch kernels.  Keys: "sa_table_persistent", "sa_table_min_rows", "sa_table_128", "sa_table_oversub", "sa_table_dedup", "fp_table_persistent",
  * "fp_table_min_rows", "fp_init_persistent", "fp_init_min_rows", "fp_head_bf16_persistent", "fp_head_bf16_min_rows", "sa_group_bf16_persistent",
  * "sa_group_bf16_min_rows", "gemm_tile", "gemm_tile_min_rows", "gemm_tile_min_cout", "gemm_tile_min_kpad".  Resolution order, per launch, on the
  * launching host thread: the thread's override (g4d_tuning_set_thread) > the process-wide value (g4d_tuning_set) > the environment variable
@@ -440,6 +440,19 @@ int g4d_mlp_chain_group_table_f32(long long rows, int N, int P, int S, const flo
                                   const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
                                   const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
                                   int ldo, int col0, g4d_stream_t stream);
+
+/* g4d_mlp_chain_group_table_f32 with caller-owned scratch.  ball_query pads a neighbourhood with copies of its first hit
+ * (ball_query_gpu.cu:32-36); a padded row is the same (source point, centroid) pair as row 0, produces the same output, and max pooling does not
+ * see it.  The persistent kernels therefore skip 16-row tiles / blocks that hold nothing but the neighbourhood's first index -- exact for ANY
+ * index list.  The 32- / 64-wide stacks do it on their own; the 128-wide stack's lock-step kernel needs its neighbourhoods sorted by live blocks
+ * first (two small pre-pass launches into `ws`: g4d_sa_table_ws_bytes(rows, Kt, S, pool) bytes, 16-byte aligned; 0 = this shape takes no
+ * workspace).  ws == NULL or too small: every block is computed.  Tuning key "sa_table_dedup" = 0 switches the work list off. */
+long long g4d_sa_table_ws_bytes(long long rows, int Kt, int S, int pool);
+int g4d_mlp_chain_group_table_ws_f32(long long rows, int N, int P, int S, const float *xyz, const float *new_xyz, const int *idx,
+                                     const float *table, int tab_ld, int Kt, const float *tab_wx, const float *pre_scale,
+                                     const float *pre_shift, int nlayers, const float *const *W, const float *const *scale,
+                                     const float *const *shift, const int *Kpad, const int *Cout, const int *relu, int pool, float *out,
+                                     int ldo, int col0, void *ws, long long ws_bytes, g4d_stream_t stream);
 
 /* three_nn (interpolate_gpu.cu:9-52) when the ball-grid workspace of the UNKNOWN cloud exists already (g4d_ball_grid_build_f32 on
  * `unknown`, any radius -- the encoder has built it for the first set-abstraction level): the scan of g4d_three_nn_f32 with the queries

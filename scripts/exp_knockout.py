@@ -1,7 +1,7 @@
 """DIAGNOSTIC ONLY (not a valid throughput number): what each launch of the cfg2 step costs the 16-stream mix.  bench.py is run with chosen
 C-ABI calls skipped (their outputs keep whatever the eager warm-up left there); the drop in ms_per_step is that launch's marginal cost.
 Only launches whose outputs are not used as indices are knocked out (MLP stacks, tables, lbs).
-    KNOCK="g4d_linear_f32#0,g4d_mlp_chain_group_table_f32#0" python scripts/exp_knockout.py [bench.py flags]
+    KNOCK="g4d_linear_f32#0,g4d_mlp_chain_group_table_ws_f32#0" python scripts/exp_knockout.py [bench.py flags]
 '#k' = the k-th call of that entry point within a step (a step starts at g4d_fps_gather_grid_f32); without '#k' every call; '*' globs names.
 G4D_KNOCK_TRACE=1 prints the C-ABI calls of one step."""
 import fnmatch, os, runpy, sys

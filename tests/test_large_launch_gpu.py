@@ -59,8 +59,9 @@ def test_sa_table_kernel_is_bit_identical_to_the_chain_kernel(B, N, P, C, mlps, 
     np.testing.assert_allclose(fused.to_channel_major(outs[1]).cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("C,mlp,S", [(40, [40, 64, 64, 128], 32), (24, [24, 32, 32, 64], 32), (40, [40, 64, 64, 128], 64)])
-@pytest.mark.parametrize("kind", ["ball_r0.04", "ball_r0.3", "arbitrary"])
+@pytest.mark.parametrize("C,mlp,S", [(40, [40, 64, 64, 128], 32), (24, [24, 32, 32, 64], 32), (40, [40, 64, 64, 128], 64),
+                                      (40, [40, 128, 128, 256], 64), (24, [24, 128, 128, 256], 32)])   # the last two: the lock-step kernel's work list
+@pytest.mark.parametrize("kind", ["ball_r0.04", "ball_r0.15", "ball_r0.3", "arbitrary"])
 def test_sa_table_dead_tile_skipping_is_exact(C, mlp, S, kind):
     """Round 6: sa_table.hip skips a 16-row tile whose rows all carry the neighbourhood's first index (ball_query's padding: the same (source
     point, centroid) pair as row 0, so the same output -- max pooling does not see it).  Bit-identical to the chain kernel, which computes every
@@ -91,7 +92,11 @@ def test_sa_table_dead_tile_skipping_is_exact(C, mlp, S, kind):
         for on in (0, 1):
             with tuning(sa_table_persistent=on, sa_table_min_rows=0):
                 outs[on] = fused.sa_forward(sa, xyz, fpm, new_xyz=new_xyz, idxs=idxs)[1]
-    assert torch.equal(outs[0], outs[1])
+        with tuning(sa_table_min_rows=0, sa_table_dedup=0):
+            plain = fused.sa_forward(sa, xyz, fpm, new_xyz=new_xyz, idxs=idxs)[1]
+        with tuning(sa_table_min_rows=0):
+            again = [fused.sa_forward(sa, xyz, fpm, new_xyz=new_xyz, idxs=idxs)[1] for _ in range(3)]   # the work list's order is up to atomics; the result is not
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], plain) and all(torch.equal(a_, outs[0]) for a_ in again)
 
 
 @pytest.mark.parametrize("widths,S,native", [
