@@ -80,6 +80,8 @@ SIGNATURES = {
                            _vp, _vp, _vp, _I, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _I, _I, _vp, _I, _vp],
     "g4d_mlp_chain_group_table_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp],
+    "g4d_mlp_args_size": [],
+    "g4d_mlp_run": [_I, _vp, _vp],
     "g4d_sa_table_supported": [ctypes.c_longlong, _I, _I, _I],
     "g4d_sa_table_ws_bytes": [ctypes.c_longlong, _I, _I, _I],
     "g4d_mlp_chain_group_table_ws_f32": [ctypes.c_longlong, _I, _I, _I, _vp, _vp, _vp, _vp, _I, _I, _vp, _vp, _vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _I, _I, _vp,
@@ -123,11 +125,30 @@ SIGNATURES = {
 _lib = None
 
 
-RESTYPES = {"g4d_sa_table_ws_bytes": ctypes.c_longlong, "g4d_gcn_tile_meta_bytes": ctypes.c_longlong, "g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_three_nn_pruned_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
+RESTYPES = {"g4d_mlp_args_size": ctypes.c_uint, "g4d_sa_table_ws_bytes": ctypes.c_longlong, "g4d_gcn_tile_meta_bytes": ctypes.c_longlong, "g4d_frag_bf16_elems": ctypes.c_longlong, "g4d_lbs_mfma_ws_bytes": ctypes.c_longlong, "g4d_three_nn_pruned_ws_bytes": ctypes.c_longlong, "g4d_temporal_attention_scratch_floats": ctypes.c_size_t, "g4d_ball_grid_bytes": ctypes.c_size_t, "g4d_ball_query_lanes_qsort_bytes": ctypes.c_size_t}   # everything else returns an int status
 
 
 class G4DError(RuntimeError):
     pass
+
+
+MLP_ARGS_VERSION = 1
+MLP_STACK_F32, MLP_STACK_BF16, MLP_WAVE_F32, MLP_CHAIN_F32, MLP_CHAIN_BF16, MLP_CHAIN_BF16X3 = range(6)   # enum g4d_mlp_family
+
+
+class MlpArgs(ctypes.Structure):
+    """include/g4d.h `g4d_mlp_args`, field for field -- the ONE argument block of the whole-stack launchers (g4d_mlp_run).  tests/test_abi_cpu.py
+    checks sizeof against the library's g4d_mlp_args_size() and the field order against the header's text."""
+    _fields_ = [("size", ctypes.c_uint), ("version", ctypes.c_uint), ("mode", _I), ("K0", _I), ("rows", ctypes.c_longlong),
+                ("X", _vp), ("ldx", _I),
+                ("N", _I), ("P", _I), ("S", _I), ("C", _I), ("use_xyz", _I), ("xyz", _vp), ("new_xyz", _vp), ("feats", _vp), ("idx", _vp),
+                ("n", _I), ("m", _I), ("C2", _I), ("C1", _I), ("known_feats", _vp), ("skip", _vp), ("dist2", _vp), ("nn_idx", _vp),
+                ("Vg", _I), ("rowptr", _vp), ("colidx", _vp), ("vals", _vp),
+                ("nlayers", _I), ("W", _vp), ("scale", _vp), ("shift", _vp), ("Kpad", _vp), ("Cout", _vp), ("relu", _vp),
+                ("pool", _I), ("out", _vp), ("ldo", _I), ("col0", _I), ("tap_layer", _I), ("tap_out", _vp), ("tap_ld", _I), ("unknown_grid", _vp)]
+
+    def __init__(self, **kw):
+        super().__init__(size=ctypes.sizeof(MlpArgs), version=MLP_ARGS_VERSION, tap_layer=-1, **kw)
 
 
 def lib():
@@ -184,9 +205,31 @@ class timed_calls:
         return [(name, ints, e0.elapsed_time(e1) * 1e3) for name, ints, e0, e1 in self._rec]
 
 
+_MLP_FAMILY_NAMES = ("g4d_mlp_stack_f32", "g4d_mlp_stack_bf16", "g4d_mlp_wave_f32", "g4d_mlp_chain_f32", "g4d_mlp_chain_bf16", "g4d_mlp_chain_bf16x3")
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point; non-zero status -> G4DError (the reference would exit(-1))."""
     L = lib()
+    if name == "g4d_mlp_run" and (_TRACE or _TIMED is not None):
+        # tracing / timing tables name the kernel family behind the argument block and list its leading integers (mode, rows, K0, ...) as the
+        # positional entry points did
+        blk = args[1].contents if hasattr(args[1], "contents") else MlpArgs.from_address(args[1])
+        fam = _MLP_FAMILY_NAMES[args[0]] if blk.unknown_grid is None else "g4d_mlp_chain_cells_bf16"
+        shown = (blk.mode, blk.rows, blk.K0, blk.ldx, blk.N, blk.P, blk.S, blk.C, blk.use_xyz, blk.n, blk.m, blk.C2, blk.C1, blk.nlayers, blk.pool)
+        if _TRACE:
+            import sys
+            print("g4d call g4d_mlp_run ->", fam, *shown, file=sys.stderr)
+        if _TIMED is not None:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = L.g4d_mlp_run(*args)
+            e1.record()
+            _TIMED.append((fam, shown, e0, e1))
+            if rc != 0:
+                raise G4DError(f"g4d_mlp_run({fam}) failed with status {rc}: {L.g4d_last_error().decode(errors='replace')}")
+            return rc
     if _TRACE:
         import sys
         print("g4d call", name, *[a for a in args if isinstance(a, (int, float)) and abs(a) < (1 << 31)], file=sys.stderr)

@@ -1,5 +1,6 @@
 // Library-level entry points of libg4d_hip: version + thread-local error text.
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -180,4 +181,54 @@ extern "C" int g4d_copy_segments_f32(int nseg, float *const *dst, const float *c
     G4D_REQUIRE(blocks < (1ll << 31), "g4d_copy_segments_f32: too large");
     hipLaunchKernelGGL(g4d::copy_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c, k);
     return g4d::check_launch("g4d_copy_segments_f32");
+}
+
+
+// ---- g4d_mlp_run: the whole-stack launchers behind ONE argument block (include/g4d.h) ----------------------------------------------------
+extern "C" unsigned g4d_mlp_args_size(void) { return (unsigned)sizeof(g4d_mlp_args); }
+
+extern "C" int g4d_mlp_run(int family, const g4d_mlp_args *args, g4d_stream_t stream) {
+    G4D_REQUIRE(args, "g4d_mlp_run: null argument block");
+    G4D_REQUIRE(args->version == G4D_MLP_ARGS_VERSION, "g4d_mlp_run: argument block version %u, this library speaks %d", args->version, G4D_MLP_ARGS_VERSION);
+    G4D_REQUIRE(args->size >= 16 && args->size <= sizeof(g4d_mlp_args), "g4d_mlp_run: argument block of %u bytes, this library's is %u (a newer caller?)",
+                args->size, (unsigned)sizeof(g4d_mlp_args));
+    g4d_mlp_args a;
+    memset(&a, 0, sizeof(a));
+    memcpy(&a, args, args->size);                 // an older caller's shorter block: the appended fields read as zero
+    if (args->size < sizeof(g4d_mlp_args)) a.tap_layer = args->size > offsetof(g4d_mlp_args, tap_layer) ? a.tap_layer : -1;
+    typedef const float *const *FPP;
+    typedef const unsigned short *const *HPP;
+    switch (family) {
+        case G4D_MLP_STACK_F32:
+            return g4d_mlp_stack_f32(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2, a.C1,
+                                     a.known_feats, a.skip, a.dist2, a.nn_idx, a.Vg, a.rowptr, a.colidx, a.vals, a.nlayers, reinterpret_cast<FPP>(a.W), a.scale,
+                                     a.shift, a.Kpad, a.Cout, a.relu, a.pool, a.out, a.ldo, a.col0, a.tap_layer, a.tap_out, a.tap_ld, stream);
+        case G4D_MLP_STACK_BF16:
+            return g4d_mlp_stack_bf16(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2, a.C1,
+                                      a.known_feats, a.skip, a.dist2, a.nn_idx, a.Vg, a.rowptr, a.colidx, a.vals, a.nlayers, reinterpret_cast<HPP>(a.W), a.scale,
+                                      a.shift, a.Kpad, a.Cout, a.relu, a.pool, a.out, a.ldo, a.col0, a.tap_layer, a.tap_out, a.tap_ld, stream);
+        case G4D_MLP_WAVE_F32:
+            G4D_REQUIRE(!a.tap_out, "g4d_mlp_run(G4D_MLP_WAVE_F32): the wave-autonomous kernel has no tap");
+            return g4d_mlp_wave_f32(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2, a.C1,
+                                    a.known_feats, a.skip, a.dist2, a.nn_idx, a.Vg, a.rowptr, a.colidx, a.vals, a.nlayers, reinterpret_cast<FPP>(a.W), a.scale,
+                                    a.shift, a.Kpad, a.Cout, a.relu, a.pool, a.out, a.ldo, a.col0, stream);
+        case G4D_MLP_CHAIN_F32:
+            return g4d_mlp_chain_f32(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2, a.C1,
+                                     a.known_feats, a.skip, a.dist2, a.nn_idx, a.nlayers, reinterpret_cast<FPP>(a.W), a.scale, a.shift, a.Kpad, a.Cout, a.relu,
+                                     a.pool, a.out, a.ldo, a.col0, a.tap_layer, a.tap_out, a.tap_ld, stream);
+        case G4D_MLP_CHAIN_BF16:
+            if (a.unknown_grid)
+                return g4d_mlp_chain_cells_bf16(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2,
+                                                a.C1, a.known_feats, a.skip, a.dist2, a.nn_idx, a.nlayers, reinterpret_cast<HPP>(a.W), a.scale, a.shift, a.Kpad,
+                                                a.Cout, a.relu, a.pool, a.out, a.ldo, a.col0, a.tap_layer, a.tap_out, a.tap_ld, a.unknown_grid, stream);
+            return g4d_mlp_chain_bf16(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2, a.C1,
+                                      a.known_feats, a.skip, a.dist2, a.nn_idx, a.nlayers, reinterpret_cast<HPP>(a.W), a.scale, a.shift, a.Kpad, a.Cout, a.relu,
+                                      a.pool, a.out, a.ldo, a.col0, a.tap_layer, a.tap_out, a.tap_ld, stream);
+        case G4D_MLP_CHAIN_BF16X3:
+            return g4d_mlp_chain_bf16x3(a.mode, a.rows, a.K0, a.X, a.ldx, a.N, a.P, a.S, a.C, a.use_xyz, a.xyz, a.new_xyz, a.feats, a.idx, a.n, a.m, a.C2, a.C1,
+                                        a.known_feats, a.skip, a.dist2, a.nn_idx, a.nlayers, reinterpret_cast<HPP>(a.W), a.scale, a.shift, a.Kpad, a.Cout, a.relu,
+                                        a.pool, a.out, a.ldo, a.col0, a.tap_layer, a.tap_out, a.tap_ld, stream);
+    }
+    g4d::set_error("g4d_mlp_run: unknown kernel family %d", family);
+    return G4D_EINVAL;
 }

@@ -368,45 +368,33 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
         cV, rowptr, colidx, vals = csr
         cr, cc, cv = rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr()
     tl, tp, tld = (-1, 0, 0) if tap is None else (tap[0], tap[1].data_ptr(), tap[1].shape[-1])
+    vp = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+    # ONE argument block for every kernel family (include/g4d.h g4d_mlp_args / g4d_mlp_run; round 6 -- the seven positional entry points took
+    # 34-41 arguments each, mirrored here by hand)
+    a = _lib.MlpArgs(mode=mode, K0=K0, rows=rows, X=_ptr(X), ldx=ldx, N=gN, P=gP, S=S, C=gC, use_xyz=gU, xyz=gx, new_xyz=gn, feats=gf, idx=gi,
+                     n=inn, m=im, C2=iC2, C1=iC1, known_feats=ik, skip=isk, dist2=idd, nn_idx=ii, Vg=cV, rowptr=cr, colidx=cc, vals=cv, nlayers=n,
+                     scale=vp(Sc), shift=vp(Sh), Kpad=vp(Kp), Cout=vp(Co), relu=vp(Re), pool=pool, out=out.data_ptr(), ldo=out.shape[-1], col0=col0,
+                     tap_out=tp, tap_ld=tld)
+    a.tap_layer = tl
+    def run(family, wptrs):
+        a.W = vp(wptrs)
+        a._keep = (wptrs, Sc, Sh, Kp, Co, Re)    # the host arrays the block points at live as long as the block (a recorded call may be replayed: scripts/exp_overlap.py)
+        _lib.call("g4d_mlp_run", family, ctypes.pointer(a), _lib.stream_ptr())
+        return out
+
     if current_precision() == "bf16" and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
-        W16 = PA(*[L.Wc16.data_ptr() for L in layers])
-        cells = mode == 2 and cells_grid is not None
-        _lib.call("g4d_mlp_chain_cells_bf16" if cells else "g4d_mlp_chain_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1,
-                  ik, isk, idd, ii, n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
-                  ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
-                  out.shape[-1], col0, tl, tp, tld, *((cells_grid.data_ptr(),) if cells else ()), _lib.stream_ptr())
-        return out
+        if mode == 2 and cells_grid is not None:
+            a.unknown_grid = cells_grid.data_ptr()       # rows walked in the cell order of the unknown cloud's grid (same bits)
+        return run(_lib.MLP_CHAIN_BF16, PA(*[L.Wc16.data_ptr() for L in layers]))
     if current_precision() == "bf16x3" and chain_fits(layers, pool, S, mode):
-        W3 = (ctypes.c_void_p * (3 * n))(*[t.data_ptr() for L in layers for t in L.Wc16x3()])
-        _lib.call("g4d_mlp_chain_bf16x3", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
-                  n, ctypes.cast(W3, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
-                  ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
-                  out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
-        return out
+        return run(_lib.MLP_CHAIN_BF16X3, (ctypes.c_void_p * (3 * n))(*[t.data_ptr() for L in layers for t in L.Wc16x3()]))
     if _use_bf16(rows):
-        W16 = PA(*[L.Wf16.data_ptr() for L in layers])
-        _lib.call("g4d_mlp_stack_bf16", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
-                  idd, ii, cV, cr, cc, cv, n, ctypes.cast(W16, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
-                  ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
-                  ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
-        return out
+        return run(_lib.MLP_STACK_BF16, PA(*[L.Wf16.data_ptr() for L in layers]))
     if current_precision() in ("fp32", "bf16x3") and chain_fits(layers, pool, S, mode):
-        _lib.call("g4d_mlp_chain_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk, idd, ii,
-                  n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p), ctypes.cast(Sh, ctypes.c_void_p),
-                  ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p), ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(),
-                  out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
-        return out
+        return run(_lib.MLP_CHAIN_F32, Wp)
     if tap is None and wave_fits(layers, pool, S):
-        _lib.call("g4d_mlp_wave_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
-                  idd, ii, cV, cr, cc, cv, n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
-                  ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
-                  ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, _lib.stream_ptr())
-        return out
-    _lib.call("g4d_mlp_stack_f32", mode, rows, K0, _ptr(X), ldx, gN, gP, S, gC, gU, gx, gn, gf, gi, inn, im, iC2, iC1, ik, isk,
-              idd, ii, cV, cr, cc, cv, n, ctypes.cast(Wp, ctypes.c_void_p), ctypes.cast(Sc, ctypes.c_void_p),
-              ctypes.cast(Sh, ctypes.c_void_p), ctypes.cast(Kp, ctypes.c_void_p), ctypes.cast(Co, ctypes.c_void_p),
-              ctypes.cast(Re, ctypes.c_void_p), pool, out.data_ptr(), out.shape[-1], col0, tl, tp, tld, _lib.stream_ptr())
-    return out
+        return run(_lib.MLP_WAVE_F32, Wp)
+    return run(_lib.MLP_STACK_F32, Wp)
 
 
 def _pool_rows(x2d, groups, S, out, col0, is_max):

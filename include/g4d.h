@@ -272,6 +272,44 @@ int g4d_mlp_chain_cells_bf16(int mode, long long rows, int K0, const float *X, i
                              const int *Cout, const int *relu, int pool, float *out, int ldo, int col0, int tap_layer,
                              float *tap_out, int tap_ld, const void *unknown_grid, g4d_stream_t stream);
 
+/* ---- ONE argument block for the whole-stack launchers (round 6).  The seven entry points above take 34-41 positional arguments that every
+ * binding has to mirror by hand; new code fills a g4d_mlp_args and calls g4d_mlp_run(family, &args, stream) -- the positional entry points stay
+ * (same kernels behind both) for source compatibility.  `size` = sizeof(g4d_mlp_args) as the CALLER compiled it and `version` =
+ * G4D_MLP_ARGS_VERSION: a block that is larger than the library's, or of another version, is refused (G4D_EINVAL) instead of misread; a
+ * smaller one of the same version is accepted with its missing tail treated as zero (fields are only ever appended).  Fields of loaders the
+ * chosen `mode` does not use are ignored.  g4d_mlp_args_size() returns the library's sizeof for bindings that cannot see this header. */
+#define G4D_MLP_ARGS_VERSION 1
+enum g4d_mlp_family {
+    G4D_MLP_STACK_F32 = 0,   /* g4d_mlp_stack_f32:  LDS-resident stack, fp32; W = fp32 fragment order */
+    G4D_MLP_STACK_BF16 = 1,  /* g4d_mlp_stack_bf16: W = bf16 fragment order */
+    G4D_MLP_WAVE_F32 = 2,    /* g4d_mlp_wave_f32:   wave-autonomous narrow stacks (no tap) */
+    G4D_MLP_CHAIN_F32 = 3,   /* g4d_mlp_chain_f32:  register chain (no CSR loader) */
+    G4D_MLP_CHAIN_BF16 = 4,  /* g4d_mlp_chain_bf16 -- or g4d_mlp_chain_cells_bf16 when unknown_grid != NULL; W = bf16 chain order */
+    G4D_MLP_CHAIN_BF16X3 = 5 /* g4d_mlp_chain_bf16x3: W = 3 * nlayers pointers (hi | mid | lo pieces) */
+};
+typedef struct g4d_mlp_args {
+    unsigned size, version;
+    int mode;                      /* 0 DIRECT | 1 GROUP | 2 INTERP | 3 CSR */
+    int K0;                        /* input width of the first layer */
+    long long rows;
+    const float *X; int ldx;       /* DIRECT / CSR: the (rows, ldx) input */
+    int N, P, S, C, use_xyz;       /* GROUP: source points / centroids per cloud, samples, feature columns; S is also the pooling window */
+    const float *xyz, *new_xyz, *feats; const int *idx;
+    int n, m, C2, C1;              /* INTERP: unknown / known points per cloud, known-feature and skip columns */
+    const float *known_feats, *skip, *dist2; const int *nn_idx;
+    int Vg; const int *rowptr, *colidx; const float *vals;   /* CSR */
+    int nlayers;
+    const void *const *W;          /* nlayers pointers (3 * nlayers for G4D_MLP_CHAIN_BF16X3), layout per family */
+    const float *const *scale, *const *shift;
+    const int *Kpad, *Cout, *relu; /* HOST arrays of nlayers */
+    int pool;                      /* 0 none | 1 max | 2 avg over S rows, last layer */
+    float *out; int ldo, col0;
+    int tap_layer; float *tap_out; int tap_ld;   /* tap_out == NULL: no tap */
+    const void *unknown_grid;      /* G4D_MLP_CHAIN_BF16, mode 2: the unknown cloud's ball-grid workspace (rows walked in cell order) or NULL */
+} g4d_mlp_args;
+unsigned g4d_mlp_args_size(void);
+int g4d_mlp_run(int family, const g4d_mlp_args *args, g4d_stream_t stream);
+
 /* Wide feature-propagation level with bf16 operands as two tiled GEMMs behind an interpolation pre-pass (csrc/gemm_bf16.hip): the
  * large-launch form of g4d_mlp_stack_bf16 in its interpolating mode, bit-identical to it.  Buffers in "fragment order" hold a (rows, kpad)
  * bf16 matrix as [16-row tile][32-column k-step][64 lanes][8] -- the A operand of v_mfma_f32_16x16x32_bf16 -- with the rows padded to whole

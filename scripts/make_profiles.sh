@@ -3,7 +3,7 @@
 #   gpurun -- 'bash scripts/make_profiles.sh r04').  Kernel traces and PMC passes are separate runs (a --pmc run never carries a trace
 # domain); everything lands in gpurun_out/profiles/ and is copied into profiles/ by hand.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p $OUT

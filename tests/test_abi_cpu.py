@@ -35,6 +35,33 @@ def test_ctypes_signatures_cover_header():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
 
 
+def test_mlp_argument_block_mirrors_the_header():
+    """g4d_mlp_args (include/g4d.h) <-> _lib.MlpArgs: same size as the library compiled it, same field names in the same order, and the
+    library refuses a block of another version / a larger size instead of misreading it (no launch is made: the checks come first)."""
+    from garment4d_amd import _lib
+    L = _lib.lib()
+    assert ctypes.sizeof(_lib.MlpArgs) == L.g4d_mlp_args_size()
+    hdr = open(os.path.join(ROOT, "include", "g4d.h")).read()
+    body = hdr[hdr.index("typedef struct g4d_mlp_args {"):hdr.index("} g4d_mlp_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for piece in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", piece)[-1])
+    assert names == [f for f, _ in _lib.MlpArgs._fields_], (names, [f for f, _ in _lib.MlpArgs._fields_])
+    a = _lib.MlpArgs()
+    assert a.size == ctypes.sizeof(_lib.MlpArgs) and a.version == _lib.MLP_ARGS_VERSION and a.tap_layer == -1
+    a.version = 99
+    assert L.g4d_mlp_run(_lib.MLP_CHAIN_F32, ctypes.addressof(a), None) == 10001 and b"version" in L.g4d_last_error()
+    a = _lib.MlpArgs()
+    a.size += 8
+    assert L.g4d_mlp_run(_lib.MLP_CHAIN_F32, ctypes.addressof(a), None) == 10001 and b"bytes" in L.g4d_last_error()
+    assert L.g4d_mlp_run(_lib.MLP_CHAIN_F32, None, None) == 10001
+
+
 def test_shim_has_reference_entry_points():
     from garment4d_amd import pointnet2_cuda as shim
     # /root/reference/modules/pointnet2/pointnet2/src/pointnet2_api.cpp:10-24
