@@ -234,9 +234,10 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             row.update(what=f"FPS {iv[1]} -> {iv[2]} -> {iv[3]} + gathers", bound="latency", rounds=iv[2] + iv[3] - 2, us_per_round=t_us / (iv[2] + iv[3] - 2))
         elif nm == "g4d_sa_xyz_mlp3_pair_f32":
             b_, p_ = iv[0], iv[2]
-            ex = 2.0 * b_ * p_ * (16 * (16 * 16 + 16 * 32) + 32 * (32 * 32 + 32 * 64))
-            row.update(what="SA level 1, both xyz-only scales: layer 1 on the VALU, layers 2-3 on the matrix pipe, max pool", bound="mfma", executed_flops=ex,
-                       algorithmic_flops=ex + 2.0 * b_ * p_ * (16 * 3 * 16 + 32 * 3 * 32))
+            ex23 = 2.0 * b_ * p_ * (16 * (16 * 16 + 16 * 32) + 32 * (32 * 32 + 32 * 64))
+            ex1 = 2.0 * b_ * p_ * (16 * 4 * 16 + 32 * 4 * 32)          # layer 1 since round 6: K = 3 padded to one k-step of v_mfma_f32_16x16x4_f32
+            row.update(what="SA level 1, both xyz-only scales: all three layers on the matrix pipe (layer 1: K = 3 padded to 4), max pool", bound="mfma", executed_flops=ex23 + ex1,
+                       algorithmic_flops=ex23 + 2.0 * b_ * p_ * (16 * 3 * 16 + 32 * 3 * 32))
         elif nm == "g4d_linear_f32":
             rows_, k_, cout_ = iv[0], iv[1], iv[3]
             row.update(what=f"{rows_} rows x {k_} -> {cout_} (first-layer table / wide FP level)", bound="mfma", executed_flops=2.0 * rows_ * k_ * cout_,
