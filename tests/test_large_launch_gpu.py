@@ -99,6 +99,33 @@ def test_sa_table_dead_tile_skipping_is_exact(C, mlp, S, kind):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], plain) and all(torch.equal(a_, outs[0]) for a_ in again)
 
 
+@pytest.mark.parametrize("S", [64, 32])
+def test_sa_table_work_list_under_hipgraph_replay(S):
+    """The work list of the lock-step kernel is rebuilt by every launch (memset of its counters + two pre-pass kernels + the main kernel, all
+    stream-ordered): captured once and replayed on OTHER clouds -- other index lists, other live-block counts -- it must give what eager launches
+    give on those clouds; the scratch is the capture's own."""
+    torch.manual_seed(S)
+    B, N, P, C = 4, 512, 96, 40
+    sa = _seed_bn(PM.PointnetSAModule(npoint=P, radius=0.12, nsample=S, mlp=[C, 128, 128, 256]))
+    xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=1)).cuda()
+    fpm = torch.randn(B, N, C, device="cuda")
+    with torch.no_grad(), tuning(sa_table_min_rows=0):
+        fused.sa_forward(sa, xyz, fpm)                                    # eager once: packs weights, sets kernel attributes
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            nx, out = fused.sa_forward(sa, xyz, fpm)
+        for seed, r in ((2, 1.0), (3, 0.3), (4, 2.5)):                    # other clouds, sparser / denser balls (scaled coordinates)
+            xyz.copy_(torch.from_numpy(syn.unit_cloud(B, N, seed=seed)).cuda() * r)
+            fpm.copy_(torch.randn(B, N, C, device="cuda"))
+            g.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            with tuning(sa_table_persistent=0):
+                want = fused.sa_forward(sa, xyz, fpm)[1]
+            assert torch.equal(got, want), (seed, r)
+
+
 @pytest.mark.parametrize("widths,S,native", [
     ((64, 64, 128), 64, {}),                                  # BASELINE config 5's stack: the persistent kernel reads a stride-0 table row
     ((64, 64, 128), 64, {"sa_table_persistent": 0}),          # ADVICE r5: with the A/B switch off the stride-0 route must not be chosen (used to raise)
