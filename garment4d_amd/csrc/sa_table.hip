@@ -55,15 +55,19 @@ struct SaTabArgs {
 // one of its rows carries the neighbourhood's first index, i.e. is the same (source point, centroid) pair as row 0.
 constexpr int kItemFirst = 1 << 28, kItemLast = 1 << 29, kItemDead = 1 << 30, kItemBlk = (1 << 28) - 1;
 
-// counts[1 .. G]: neighbourhoods with nb live blocks; order[(nb - 1) * nq_cap + i]: the i-th of them.  One wave ranks 64 neighbourhoods.
+// counts[1 .. G]: neighbourhoods with nb live blocks; order[(nb - 1) * nq_cap + i]: the i-th of them.  One wave ranks 64 neighbourhoods with
+// ballots, the 16 waves of a workgroup add up in LDS, and ONE global atomic per list and workgroup reserves the range (agent-scope fetch-adds on one
+// cache line run at 88 per microsecond whatever the number of waves -- scripts/micro/atomic_rate.hip: one atomic per wave and list made this
+// kernel 16 us long).
+constexpr int kCountWaves = 16;
 template <int S>
-__global__ void __launch_bounds__(256) sa_units_count_kernel(int nq, int nq_cap, const int *__restrict__ idx, int *__restrict__ counts, int *__restrict__ order) {
+__global__ void __launch_bounds__(64 * kCountWaves) sa_units_count_kernel(int nq, int nq_cap, const int *__restrict__ idx, int *__restrict__ counts, int *__restrict__ order) {
     constexpr int G = S / 16, UPL = 64 / S;          // neighbourhoods per 64-lane load
-    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 4 + (threadIdx.x >> 6));
+    __shared__ int s_cnt[kCountWaves][4], s_base[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave = blockIdx.x * kCountWaves + wv;
     const int q0 = wave * 64;                        // this wave's 64 neighbourhoods: lane l keeps nb of neighbourhood q0 + l
-    if (q0 >= nq) return;
     int mine = 0;
-    // all of the wave's loads first (64 / UPL independent 256-byte rows in flight: one memory round trip instead of eight), then the ranking
+    // all of the wave's loads first (64 / UPL independent 256-byte rows in flight), then the ranking
     int vv[64 / UPL];
     const long long last_ = (long long)nq * S - 1;
 #pragma unroll
@@ -71,6 +75,8 @@ __global__ void __launch_bounds__(256) sa_units_count_kernel(int nq, int nq_cap,
         const long long e_ = (long long)(q0 + i * UPL) * S + lane;
         vv[i] = idx[e_ < last_ ? e_ : last_];        // (past the end: clamped, dropped below -- a neighbourhood inside the range has all its rows inside)
     }
+#pragma unroll
+    for (int i = 0; i < 64 / UPL; ++i) asm volatile("" : "+v"(vv[i]));   // (every load issued before the first use)
 #pragma unroll
     for (int i = 0; i < 64 / UPL; ++i) {
         const int v = vv[i];
@@ -84,14 +90,25 @@ __global__ void __launch_bounds__(256) sa_units_count_kernel(int nq, int nq_cap,
         }
     }
     const bool ok = q0 + lane < nq;
+    unsigned long long mk[G];
 #pragma unroll
     for (int b = 1; b <= G; ++b) {
-        const unsigned long long mk = __builtin_amdgcn_ballot_w64(ok && mine == b);
-        if (mk == 0ull) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&counts[b], (int)__builtin_popcountll(mk));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (ok && mine == b) order[(size_t)(b - 1) * nq_cap + base + (int)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = q0 + lane;
+        mk[b - 1] = __builtin_amdgcn_ballot_w64(ok && mine == b);
+        if (lane == 0) s_cnt[wv][b - 1] = (int)__builtin_popcountll(mk[b - 1]);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {                           // thread b - 1: the workgroup's total of list b, one reservation
+        int tot = 0;
+        for (int w = 0; w < kCountWaves; ++w) tot += s_cnt[w][threadIdx.x];
+        s_base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x + 1], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 1; b <= G; ++b) {
+        if (!(ok && mine == b)) continue;
+        int off = s_base[b - 1];
+        for (int w = 0; w < wv; ++w) off += s_cnt[w][b - 1];
+        order[(size_t)(b - 1) * nq_cap + off + (int)__builtin_popcountll(mk[b - 1] & ((1ull << lane) - 1ull))] = q0 + lane;
     }
 }
 
@@ -587,7 +604,7 @@ static int sa_table_launch(SaTabArgs a, hipStream_t st, void *ws = nullptr, long
             int *counts = reinterpret_cast<int *>(ws), *order = counts + 8, *wg_len = order + (size_t)G * nq, *items = wg_len + kListWgMax;
             const long long icap = list_cap(nq, G, grid);
             if (hipMemsetAsync(counts, 0, 32, st) != hipSuccess) return check_launch("g4d_sa_table(work list)");
-            hipLaunchKernelGGL((sa_units_count_kernel<S>), dim3((unsigned)(((nq + 63) / 64 + 3) / 4)), dim3(256), 0, st, (int)nq, (int)nq, a.idx, counts, order);
+            hipLaunchKernelGGL((sa_units_count_kernel<S>), dim3((unsigned)(((nq + 63) / 64 + kCountWaves - 1) / kCountWaves)), dim3(64 * kCountWaves), 0, st, (int)nq, (int)nq, a.idx, counts, order);
             hipLaunchKernelGGL(sa_units_items_kernel, dim3((grid * 4 + 255) / 256), dim3(256), 0, st, G, (int)nq, (int)grid, (int)icap, counts, order, items, wg_len);
             if (const int rc = check_launch("g4d_sa_table(work list)")) return rc;
             a.items = items; a.wg_len = wg_len; a.cap = (int)icap;
