@@ -247,6 +247,15 @@ def call(name, *args):
     return rc
 
 
+def ver(t):
+    """A tensor's version counter for cache keys, or None for an inference tensor (torch.inference_mode(): no counter is kept -- and no in-place
+    update outside inference mode is possible either)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def stream_ptr():
     """The current torch HIP stream as a raw hipStream_t (reference: at::cuda::getCurrentCUDAStream())."""
     import torch

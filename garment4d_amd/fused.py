@@ -133,7 +133,7 @@ def _pack_block(block):
 
 
 def _param_key(m):
-    return tuple((p.data_ptr(), p._version) for p in list(m.parameters()) + list(m.buffers()))
+    return tuple((p.data_ptr(), _ver(p)) for p in list(m.parameters()) + list(m.buffers()))
 
 
 def pack_conv_stack(stack):
@@ -196,12 +196,19 @@ def to_channel_major(x):
     return out
 
 
+_ver = _lib.ver   # a tensor's version counter, or None for an inference tensor (torch.inference_mode(): no counter is kept)
+
+
 def attach_twin(cm, pm):
     """Remember on the channel-major tensor `cm` (B, C, N) -- what the reference's operator API returns -- the point-major tensor `pm`
     (B, N, C) the kernels produced it from, so that the next drop-in module of a chain (pointnet2encoder.py:127-140 feeds level l's
     output to level l+1 and to two FP levels) reads the kernels' own layout instead of transposing back.  Keyed on cm's version counter:
-    an in-place update of `cm` invalidates the twin; a view / slice / clone of `cm` is a new tensor object and carries none."""
-    cm._g4d_pm = (pm, cm._version)
+    an in-place update of `cm` invalidates the twin; a view / slice / clone of `cm` is a new tensor object and carries none.  Inference
+    tensors (torch.inference_mode()) keep no version counter, so an in-place edit could not be noticed: they get NO twin (the next module
+    transposes, results unchanged)."""
+    v = _ver(cm)
+    if v is not None:
+        cm._g4d_pm = (pm, v)
     return cm
 
 
@@ -209,7 +216,7 @@ def point_major_of(cm):
     """(B, C, N) features of the operator API -> (B, N, C) for the kernels: the attached twin when `cm` came out of a fused drop-in
     module and has not been written since, else one transpose launch."""
     tw = getattr(cm, "_g4d_pm", None)
-    if tw is not None and tw[1] == cm._version and tuple(tw[0].shape) == (cm.shape[0], cm.shape[2], cm.shape[1]):
+    if tw is not None and tw[1] == _ver(cm) and tuple(tw[0].shape) == (cm.shape[0], cm.shape[2], cm.shape[1]):
         return tw[0]
     pm = to_point_major(cm.contiguous())
     if cm.is_contiguous():
@@ -220,14 +227,16 @@ def point_major_of(cm):
 def attach_grid(xyz, grid):
     """Remember the cloud's cell grid (build_ball_grid) on the coordinate tensor itself: the drop-in modules are called one by one with the same
     `xyz` object (pointnet2encoder.py: l_xyz[0] goes to SA level 1 and, as `unknown`, to the last FP level), so the FP level's three_nn can walk
-    the queries in cell order without the caller knowing that a grid exists.  Keyed on the version counter like the twins."""
-    xyz._g4d_grid = (grid, xyz._version)
+    the queries in cell order without the caller knowing that a grid exists.  Keyed on the version counter like the twins (inference tensors: none)."""
+    v = _ver(xyz)
+    if v is not None:
+        xyz._g4d_grid = (grid, v)
     return grid
 
 
 def grid_of(xyz):
     g = getattr(xyz, "_g4d_grid", None)
-    return g[0] if g is not None and g[1] == xyz._version else None
+    return g[0] if g is not None and g[1] == _ver(xyz) else None
 
 
 def channel_major_with_twin(pm):

@@ -143,7 +143,7 @@ class GraphConvolution(torch.nn.Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def _packed(self):
-        key = (self.weight.data_ptr(), self.weight._version, None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        key = (self.weight.data_ptr(), _lib.ver(self.weight), None if self.bias is None else (self.bias.data_ptr(), _lib.ver(self.bias)))
         hit = getattr(self, "_g4d_packed", None)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -163,7 +163,7 @@ class GraphConvolution(torch.nn.Module):
         """The support contraction for an input whose rows carry `width` >= in_features columns, the extra ones ZERO (the caller pads a ragged
         feature width -- 323, 195 -- to a multiple of 4 so that the rows are 16-byte aligned and the tiled GEMM takes the launch): the weight
         gets zero rows for them, every partial sum keeps its value and its k order -- the same bits as _packed()[0] on the unpadded rows."""
-        key = (self.weight.data_ptr(), self.weight._version, int(width))
+        key = (self.weight.data_ptr(), _lib.ver(self.weight), int(width))
         hit = getattr(self, "_g4d_packed_pad", None)
         if hit is None or hit[0] != key:
             with torch.no_grad():

@@ -52,7 +52,7 @@ def _model_constants(v_template, shapedirs, posedirs, J_regressor):
     """[shapedirs^T ; posedirs] ((NB+PF), V*3), J_regressor v_template (J,3), J_regressor shapedirs (J,3,NB): constants of a body
     model, computed once (the two regressor products in float64) and cached on the tensors' identities."""
     src = (v_template, shapedirs, posedirs, J_regressor)
-    key = tuple((id(t), t._version) for t in src)
+    key = tuple((id(t), _lib.ver(t)) for t in src)
     hit = _const_cache.get(key)
     if hit is not None and not all(a is b for a, b in zip(hit[3], src)):
         hit = None                       # an id recycled by a new tensor: the entry keeps its sources alive, so this cannot happen while cached

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import dist as gdist
 from . import fused
 from . import gcn
@@ -35,7 +36,7 @@ class_num = 7
 
 def _pack_plain_stack(seq):
     """nn.Sequential of nn.Conv1d(k=1) [nn.BatchNorm1d] [nn.ReLU] -> packed layers (eval-mode BN folded), cached."""
-    key = tuple((p.data_ptr(), p._version) for p in list(seq.parameters()) + list(seq.buffers()))
+    key = tuple((p.data_ptr(), _lib.ver(p)) for p in list(seq.parameters()) + list(seq.buffers()))
     hit = getattr(seq, "_g4d_packed", None)
     if hit is not None and hit[0] == key:
         return hit[1]

@@ -62,7 +62,7 @@ _csr_cache = {}
 
 
 def _vf_csr(vertex_index, face_index, nv):
-    key = (id(vertex_index), id(face_index), vertex_index._version, face_index._version, nv)
+    key = (id(vertex_index), id(face_index), _lib.ver(vertex_index), _lib.ver(face_index), nv)
     hit = _csr_cache.get(key)
     if hit is not None and not (hit[2] is vertex_index and hit[3] is face_index):
         hit = None

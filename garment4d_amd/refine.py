@@ -24,7 +24,7 @@ from .gcn import GraphConvolution, gcn_stack_forward
 
 def _pack_linear_mlp(seq):
     """nn.Sequential(Linear, ReLU, Linear) -> packed layers (cached on the module)."""
-    key = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    key = tuple((p.data_ptr(), _lib.ver(p)) for p in seq.parameters())
     hit = getattr(seq, "_g4d_packed", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -47,7 +47,7 @@ def _split_first_linear(seq):
     (query, sample) pair (Vg * S rows), and the grouped row shrinks from 3 + C (up to 387) to 3 + H = 35 columns
     [x_j - q ; G_j] against the weight [Wx | I].  The coordinate difference is still formed first, in fp32, as the
     reference does; only the summation order of the feature dot product changes."""
-    key = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    key = tuple((p.data_ptr(), _lib.ver(p)) for p in seq.parameters())
     hit = getattr(seq, "_g4d_split", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
@@ -86,7 +86,7 @@ def _pe_kernel_weights(seq, n_in):
             and seq[0].out_features == 32 and seq[2].in_features == 32 and seq[2].out_features == 32 and seq[2].bias is not None
             and seq[0].bias is not None):
         return None
-    key = (tuple((p.data_ptr(), p._version) for p in seq.parameters()), n_in)
+    key = (tuple((p.data_ptr(), _lib.ver(p)) for p in seq.parameters()), n_in)
     hit = getattr(seq, "_g4d_pe", None)
     if hit is None or hit[0] != key:
         with torch.no_grad():
@@ -160,7 +160,7 @@ class GarmentRefinementHead(nn.Module):
         self.lbs_graph_regress3 = gcn(self.graph_start_feature_dim + self.hidden_dim)
 
     def _qkv(self, lin):
-        key = (lin.weight.data_ptr(), lin.weight._version)
+        key = (lin.weight.data_ptr(), _lib.ver(lin.weight))
         hit = getattr(lin, "_g4d_packed", None)
         if hit is None or hit[0] != key:
             dev = lin.weight.device

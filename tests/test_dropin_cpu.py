@@ -61,6 +61,16 @@ def test_twin_is_keyed_on_the_version_counter():
     assert fused.grid_of(x) is None
 
 
+def test_inference_tensors_get_no_twin():
+    """torch.inference_mode() tensors keep no version counter: an in-place edit could not be noticed, so nothing is attached to them."""
+    with torch.inference_mode():
+        cm, pm = torch.zeros(2, 3, 5), torch.ones(2, 5, 3)
+        assert fused.attach_twin(cm, pm) is cm and getattr(cm, "_g4d_pm", None) is None
+        x = torch.zeros(1, 4, 3)
+        fused.attach_grid(x, ("ws", 0.1))
+        assert fused.grid_of(x) is None
+
+
 def test_tuning_fields_of_the_dropin_route():
     t = tuning.Tuning()
     assert t.dropin_fused and t.dropin_whole_model

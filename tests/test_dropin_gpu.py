@@ -206,6 +206,23 @@ def test_twin_is_dropped_when_the_tensor_is_written():
     assert torch.equal(c, b)
 
 
+def test_dropin_under_inference_mode():
+    """torch.inference_mode(): autograd is off (the fused route is taken) but tensors keep no version counter -- no twins are attached, every
+    module transposes its inputs itself, and the results are those of the no_grad run."""
+    B, N = 2, 2048
+    model = seed_encoder(Pointnet2MSGSEG(input_channels=0, global_feat=False), seed=8).cuda().eval()
+    pc = dev(syn.unit_cloud(B, N, seed=21))
+    with torch.no_grad():
+        want = reference_encoder_loop(model, pc)
+        want_m = model(pc)
+    with torch.inference_mode():
+        got = reference_encoder_loop(model, pc.clone())
+        got_m = model(pc.clone())
+    assert torch.equal(got[1], want[1]) and torch.equal(got_m[1], want_m[1])
+    for a, b in zip(got[2], want[2]):
+        assert torch.equal(a, b)
+
+
 def test_conv1d_block_dropin():
     """pytorch_utils.Conv1d on its own (the FC head of pointnet2encoder.py:100-104,141): one HIP contraction in eval + no_grad."""
     torch.manual_seed(0)
