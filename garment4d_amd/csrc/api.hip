@@ -117,7 +117,7 @@ extern "C" int g4d_tuning_set_thread(const char *key, long long value, int set) 
     return G4D_EINVAL;
 }
 
-extern "C" int g4d_version(void) { return 206; /* 0.2.0: round 2 (g4d_ball_query_boxes_f32 takes 16-point sub-block bounds; new entry points, see include/g4d.h) */ }
+extern "C" int g4d_version(void) { return 260; /* round 6: g4d_mlp_run / g4d_mlp_args, g4d_mlp_chain_group_table_ws_f32 + g4d_sa_table_ws_bytes / _supported (include/g4d.h); 206: round 2 */ }
 extern "C" const char *g4d_last_error(void) { return g4d::g_err; }
 
 extern "C" int g4d_get_distance_contraction(void) { return g4d::distance_contraction(); }

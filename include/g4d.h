@@ -31,7 +31,7 @@ typedef struct ihipStream_t *g4d_stream_t; /* == hipStream_t */
 #define G4D_OK 0
 #define G4D_EINVAL 10001 /* bad argument (negative size, null pointer, unsupported width) */
 
-int g4d_version(void); /* 100 * major + minor: 200 = round 2 (the `boxes` scratch of g4d_ball_query_boxes_f32 grew to 16-point sub-blocks); 205 / 206 = round 5 (entry points added, none changed; 206: g4d_gcn_tile_meta_*, g4d_gcn_agg_linear_meta_f32) */
+int g4d_version(void); /* 100 * major + minor: 200 = round 2 (the `boxes` scratch of g4d_ball_query_boxes_f32 grew to 16-point sub-blocks); 205 / 206 = round 5 (entry points added, none changed; 206: g4d_gcn_tile_meta_*, g4d_gcn_agg_linear_meta_f32); 260 = round 6 (added: g4d_mlp_run / g4d_mlp_args, g4d_mlp_chain_group_table_ws_f32, g4d_sa_table_ws_bytes, g4d_sa_table_supported; none changed) */
 const char *g4d_last_error(void);
 
 /* ---- numerics: how the squared distance of FPS / ball query / three_nn / knn is rounded ---------------------------------
