@@ -210,6 +210,7 @@ static int launch_linear(int mode, const LinearArgs &a, hipStream_t s) {
         int rc = G4D_OK;
         // (round 5: the tile kernel first -- since its loads sit between the MFMA chains it is level with the row-streaming kernel at
         //  K = 128 -> 128 and 8 % ahead at 128 -> 384 (983k rows: 1128 vs 1230 us); the streaming kernel keeps the shapes the tile kernel declines)
+        if (gemm_narrow_try(a, s, &rc)) return rc;   // tall, un-pooled, K = Cout = 96: weights in registers (gemm_narrow.hip, round 6)
         if (gemm_tile_try(a, s, &rc)) return rc;     // tall, un-pooled, K >= 128, Cout a multiple of 128: 128 x 128 tiles (gemm_tile.hip)
         if (gemm_stream_try(a, s, &rc)) return rc;   // tall, un-pooled, Cout a multiple of 128 after padding, K <= 128: the row-streaming GEMM
     }

@@ -84,6 +84,7 @@ __device__ __forceinline__ float interp_at(const LinearArgs &a, const InterpRow 
 
 // gemm_stream.hip: persistent row-streaming GEMM for tall DIRECT launches; returns false when the launch is not its kind
 bool gemm_stream_try(const LinearArgs &a, hipStream_t s, int *rc);
+bool gemm_narrow_try(const LinearArgs &a, hipStream_t s, int *rc);   // gemm_narrow.hip: K = Cout = 96, weights in registers
 // gemm_tile.hip: 128 x 128-tile GEMM for tall DIRECT launches with a deep contraction; same contract
 bool gemm_tile_try(const LinearArgs &a, hipStream_t s, int *rc);
 

@@ -457,6 +457,30 @@ def test_threshold_fp_init_min_rows(dn):
     assert isinstance(got, tuple) and _eq(ref, got)
 
 
+@pytest.mark.parametrize("rows,relu,col0,extra", [(65536, False, 0, 0), (70001, True, 0, 0), (98304, False, 8, 12), (32768, True, 0, 4), (32767, False, 0, 0)])
+def test_narrow_gemm_equals_lds_tiled_kernel(rows, relu, col0, extra):
+    """csrc/gemm_narrow.hip (K = Cout = 96, the first-layer table of SA level 2: weights in LDS in fragment order, autonomous persistent waves) against
+    the LDS-tiled kernel -- the same k order, so EQUAL -- and against float64: a row count that is not a multiple of 16, an output window inside a
+    wider matrix, the launch size at / one row below the route's threshold."""
+    g = torch.Generator().manual_seed(rows % 89)
+    x = torch.randn(rows, 96, generator=g).cuda()
+    W = (torch.randn(96, 96, generator=g) / 96 ** 0.5).cuda()
+    sc, sh = (torch.rand(96, generator=g) + 0.5).cuda(), torch.randn(96, generator=g).cuda()
+    L = fused.PackedLayer(W, sc, sh, relu=relu)
+    ldo = col0 + 96 + extra
+    outs = [torch.full((rows, ldo), 7.0, device="cuda") for _ in range(2)]
+    fused.linear(x, L, out=outs[1], col0=col0)
+    for r0 in range(0, rows, 16384):                 # below the threshold the library takes the LDS-tiled kernel
+        r1 = min(rows, r0 + 16384)
+        fused.linear(x[r0:r1], L, out=outs[0][r0:r1], col0=col0)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[1][:, :col0] == 7.0).all() and (outs[1][:, col0 + 96:] == 7.0).all()
+    sel = torch.randint(0, rows, (2048,), generator=g).cuda()
+    ref = (x[sel].double() @ W.double().T) * sc.double() + sh.double()
+    ref = torch.relu(ref) if relu else ref
+    torch.testing.assert_close(outs[1][sel, col0:col0 + 96].double(), ref, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("drows", [-1, 0, 1, 127, 128])
 def test_threshold_gemm_tile_min_rows(drows):
     rows = 32768 + drows                   # around gemm_tile_min_rows = 32768 (128-row tiles; +-1: a ragged last tile)
