@@ -157,11 +157,20 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     # The persistent SA kernels skip 16-row tiles / blocks that hold nothing but ball-query padding (round 6, csrc/sa_table.hip): the flops a launch
     # EXECUTES depend on the clouds.  Recorded here from the index lists of one call, with the kernels' own rule, per table launch in call order.
     live_frac = []
-    if precision == "fp32":
+    if precision in ("fp32", "bf16"):
         real = fused.sa_scale_mlp
 
         def spy(xyz, new_xyz, feats_pm, idx, layers, use_xyz, pool, out, col0, table=None, tab_ld=None):
-            if table is not None and pool == 1:
+            if precision == "bf16" and pool == 1:           # sa_group_bf16.hip: every tile of padding that is not the neighbourhood's first is skipped
+                S = idx.shape[2]
+                if S >= 32:
+                    t = idx.view(idx.shape[0], idx.shape[1], S // 16, 16)
+                    livet = (t != idx[..., :1].unsqueeze(-1)).any(-1)
+                    livet[..., 0] = True
+                    live_frac.append(float(livet.sum()) / float(livet.numel()))
+                else:
+                    live_frac.append(1.0)
+            elif table is not None and pool == 1:
                 S = idx.shape[2]
                 kt = layers[0].Cout
                 if S >= 32 and kt in (32, 64, 128):
@@ -261,7 +270,7 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
             chain_i += 1
             rows_ = iv[1] if nm in ("g4d_mlp_chain_bf16", "g4d_mlp_chain_cells_bf16", "g4d_mlp_stack_bf16", "g4d_mlp_chain_f32") else iv[0]   # (these take the loader mode first)
             lf = 1.0
-            if nm.startswith("g4d_mlp_chain_group_table") and tab_i < len(live_frac):
+            if ((nm.startswith("g4d_mlp_chain_group_table") or (precision == "bf16" and desc.startswith("SA level"))) and tab_i < len(live_frac)):
                 lf = live_frac[tab_i]
                 tab_i += 1
                 row["live_rows_frac"] = lf      # share of the grouped rows that are computed (the rest: tiles of ball-query padding, skipped)

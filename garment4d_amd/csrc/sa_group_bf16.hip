@@ -133,7 +133,11 @@ __global__ void __launch_bounds__(64 * NW) sa_group_bf16_kernel(const SaGrpHArgs
     };
     auto wfrag = [&](const unsigned short *sw, int kst, int ct, int ks) -> uint4 { return *reinterpret_cast<const uint4 *>(sw + ((ct * kst + ks) * 64 + lane) * 8); };
 
+    // DEAD TILES (round 6, as sa_table.hip): a tile whose 16 rows all carry the neighbourhood's first index -- ball_query's padding -- reproduces row
+    // 0's output, and max pooling does not see it: it is not computed (the pipeline moves on).  Exact for any index list.
     int jn = load_idx(tile_of(0));
+    int h0 = __builtin_amdgcn_readlane(jn, 0);        // first neighbour index of the neighbourhood being looked at
+    bool dead_cur = false, dead_nxt = false;
     Ctx cur = make(tile_of(0), jn);
     jn = load_idx(tile_of(1));
     Item item[KS0];
@@ -143,7 +147,20 @@ __global__ void __launch_bounds__(64 * NW) sa_group_bf16_kernel(const SaGrpHArgs
     for (int it = 0; it < iters; ++it) {
         const int tile = tile_of(it);
         const Ctx nxt = make(tile_of(it + 1), jn);    // from the index loaded one tile ago; its coordinate loads have this whole tile
+        if constexpr (G > 1) {
+            const bool head = (it + 1) % G == 0;
+            if (head) h0 = __builtin_amdgcn_readlane(jn, 0);
+            dead_nxt = !head && __builtin_amdgcn_ballot_w64(jn != h0) == 0ull;
+        }
         jn = load_idx(tile_of(it + 2));
+        const int j = it % G;
+        float v[T3];
+        if (dead_cur) {                               // (never the first tile of a neighbourhood: pm holds its maximum so far)
+#pragma unroll
+            for (int ks = 0; ks < KS0; ++ks) item[ks] = load_item(nxt, ks);
+#pragma unroll
+            for (int ct = 0; ct < T3; ++ct) v[ct] = pm[ct];
+        } else {
         // ---- layer 1 (3 + CIN -> 16 T1), transposed: lane (fi, g) ends with channels 16 ct + 4 g + r of row fi
         f32x4 a1[T1];
 #pragma unroll
@@ -212,8 +229,6 @@ __global__ void __launch_bounds__(64 * NW) sa_group_bf16_kernel(const SaGrpHArgs
 #pragma unroll
             for (int ct = 0; ct < T3; ++ct) a3[ct] = mfma32h(b2[ks], wfrag(s_w3, KS2, ct, ks), a3[ct]);
         // ---- affine, max over the rows, ReLU once per output
-        const int j = it % G;
-        float v[T3];
 #pragma unroll
         for (int ct = 0; ct < T3; ++ct) {
             const float sc = s_sc3[ct * 16 + fi], sh = s_sh3[ct * 16 + fi];
@@ -222,6 +237,8 @@ __global__ void __launch_bounds__(64 * NW) sa_group_bf16_kernel(const SaGrpHArgs
             v[ct] = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
             if constexpr (G > 1) { pm[ct] = j == 0 ? v[ct] : fmaxf(pm[ct], v[ct]); v[ct] = pm[ct]; }
         }
+        }   // !dead_cur
+        dead_cur = dead_nxt;
         if (j == G - 1) {
             const int q = tile / G;
             float *o = a.out + (size_t)q * a.ldo + a.col0;

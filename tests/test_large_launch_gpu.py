@@ -99,6 +99,37 @@ def test_sa_table_dead_tile_skipping_is_exact(C, mlp, S, kind):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], plain) and all(torch.equal(a_, outs[0]) for a_ in again)
 
 
+@pytest.mark.parametrize("C,mlp,S", [(96, [96, 64, 64, 128], 32), (192, [192, 64, 64, 128], 32), (192, [192, 128, 128, 256], 64), (0, [0, 32, 32, 64], 32)])
+@pytest.mark.parametrize("kind", ["ball_r0.04", "ball_r0.3", "arbitrary"])
+def test_sa_group_bf16_dead_tile_skipping_is_exact(C, mlp, S, kind):
+    """The bf16 persistent SA kernel (csrc/sa_group_bf16.hip) skips tiles of ball-query padding like sa_table.hip does: bit-identical to the bf16
+    chain kernel, which computes every row -- tiny balls, large balls and arbitrary index lists (a dead tile with live rows behind it, one index
+    repeated, padding that starts inside a tile)."""
+    torch.manual_seed(C + S)
+    B, N, P = 3, 512, 77
+    xyz = torch.from_numpy(syn.unit_cloud(B, N, seed=S)).cuda()
+    fpm = torch.randn(B, N, C, device="cuda") if C else None
+    new_xyz = fused.fps_gather(xyz, P)
+    sa = _seed_bn(PM.PointnetSAModule(npoint=P, radius=0.3, nsample=S, mlp=list(mlp)))
+    if kind == "arbitrary":
+        g = torch.Generator().manual_seed(5)
+        idx = torch.randint(0, N, (B, P, S), generator=g, dtype=torch.int32)
+        first = idx[..., :1]
+        idx[:, 0::5, 16:] = first[:, 0::5]
+        idx[:, 1::5, 9:] = first[:, 1::5]
+        idx[:, 2::5, :] = first[:, 2::5]
+        idx[:, 3::5, 16:32] = first[:, 3::5]
+        idxs = [idx.cuda()]
+    else:
+        idxs = fused.ball_query_msg([float(kind.split("r")[1])], [S], xyz, new_xyz)
+    outs = {}
+    with torch.no_grad(), fused.precision("bf16"):
+        for on in (0, 1):
+            with tuning(sa_group_bf16_persistent=on, sa_group_bf16_min_rows=0):
+                outs[on] = fused.sa_forward(sa, xyz, fpm, new_xyz=new_xyz, idxs=idxs)[1]
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("S", [64, 32])
 def test_sa_table_work_list_under_hipgraph_replay(S):
     """The work list of the lock-step kernel is rebuilt by every launch (memset of its counters + two pre-pass kernels + the main kernel, all
