@@ -41,7 +41,7 @@ def _chk(t, dtype=torch.float32):
 
 class PackedLayer:
     """One 1x1-conv(+BN)(+ReLU) layer in kernel layout."""
-    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3", "_raw", "_xyz_table", "_wf16k64")
+    __slots__ = ("W", "Wf", "Wf16", "Wc16", "scale", "shift", "K", "Kpad", "Cout", "relu", "_kperm", "_x3", "_raw", "_xyz_table")
 
     def __init__(self, weight2d, scale, shift, relu):
         cout, k = weight2d.shape
@@ -64,21 +64,7 @@ class PackedLayer:
         Wc16 = W.to(torch.bfloat16).view(cpad // 16, 16, kpad // 32, 32)[..., kperm].permute(0, 2, 3, 1, 4).contiguous()
         self.W, self.Wf, self.Wf16, self.Wc16, self.scale, self.shift = W, Wf, Wf16, Wc16, sc, sh
         self.K, self.Kpad, self.Cout, self.relu = k, kpad, cout, int(relu)
-        self._kperm, self._x3, self._raw, self._xyz_table, self._wf16k64 = kperm, None, None, None, None
-
-    def Wf16_k64(self):
-        """(kpad64, Wf16 with K zero-padded to a multiple of 64): the operand layout of g4d_gemm_frag_bf16, whose k chunks are 64 deep.  The extra
-        columns are zeros on both operands: the same sums as over Kpad columns."""
-        if self._wf16k64 is None:
-            cpad, kpad = self.W.shape
-            k64 = (kpad + 63) // 64 * 64
-            if k64 == kpad:
-                self._wf16k64 = (kpad, self.Wf16)
-            else:
-                Wp = torch.zeros((cpad, k64), dtype=torch.float32, device=self.W.device)
-                Wp[:, :kpad] = self.W
-                self._wf16k64 = (k64, Wp.to(torch.bfloat16).view(cpad // 16, 16, k64 // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous())
-        return self._wf16k64
+        self._kperm, self._x3, self._raw, self._xyz_table = kperm, None, None, None
 
     def raw(self):
         """The same contraction without the affine and the ReLU (scale 1, shift 0): the table side of a pre-contracted layer."""
@@ -365,7 +351,7 @@ def wave_fits(layers, pool, S):
     return layers[0].Kpad == 32 and all(L.Cout <= 64 for L in layers[:-1]) and all(L.Kpad <= 64 for L in layers[1:])
 
 
-def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, group=None, interp=None, csr=None, tap=None, cells_grid=None, no_chain=False):
+def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, group=None, interp=None, csr=None, tap=None, cells_grid=None):
     """One launch for the whole stack.  group = (N,P,C,use_xyz,xyz,new_xyz,feats,idx); interp = (n,m,C2,C1,known,skip,
     dist2,nn_idx); csr = (Vg,rowptr,colidx,vals); tap = (layer_index, tensor2d); cells_grid = the ball-grid workspace of the unknown cloud
     (interpolating bf16 launches may then walk the rows in cell order: same bits, shared neighbours, g4d_mlp_chain_cells_bf16)."""
@@ -405,7 +391,7 @@ def mlp_stack(mode, rows, K0, layers, out, col0=0, pool=0, S=1, X=None, ldx=0, g
         _lib.call("g4d_mlp_run", family, ctypes.pointer(a), _lib.stream_ptr())
         return out
 
-    if current_precision() == "bf16" and not no_chain and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
+    if current_precision() == "bf16" and chain_fits(layers, pool, S, mode):   # register-chain bf16 kernel: any launch size, no LDS
         if mode == 2 and cells_grid is not None:
             a.unknown_grid = cells_grid.data_ptr()       # rows walked in the cell order of the unknown cloud's grid (same bits)
         return run(_lib.MLP_CHAIN_BF16, PA(*[L.Wc16.data_ptr() for L in layers]))
@@ -1052,28 +1038,22 @@ def fp_forward(fp, unknown, known, unknow_feats_pm, known_feats_pm, head=None, u
             mlp_stack(2, B * n, C2 + C1, allL, logits.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx),
                       tap=(len(layers) - 1, out.view(B * n, -1)), cells_grid=None if unknown_grid is None else unknown_grid[0])
             return out, logits
-    # two-layer interpolating stacks with bf16 operands whose widths suit the tiled bf16 GEMMs: the GEMM route from fp_gemm_bf16_min_rows rows on, the
-    # LDS stack kernel below -- the two are bit-identical (same operands, roundings and k order), so the row count may decide.  Round 6: also for
-    # stacks the register-chain kernel could take (the encoder's middle FP level, 352 -> 256 -> 128: 284 us at 361 registers on the chain kernel
-    # against ~130 us here); such a stack then NEVER runs on the chain kernel (different summation order), whatever the launch size.
-    gemm_shape = (_T().fp_gemm_bf16 and current_precision() == "bf16" and len(layers) == 2 and C2 % 8 == 0 and _T().use_stack and stack_fits(layers, 0, 1, rows=B * n)
-                  and (_T().fp_gemm_bf16_chainable or not chain_fits(layers, 0, 1, 2)) and all(L.W.shape[0] % 128 == 0 for L in layers)
-                  and layers[0].W.shape[0] >= layers[1].Wf16_k64()[0] >= layers[0].Cout)
-    if gemm_shape and B * n >= _T().fp_gemm_bf16_min_rows:
+    if (_T().fp_gemm_bf16 and current_precision() == "bf16" and len(layers) == 2 and B * n >= _T().fp_gemm_bf16_min_rows and C2 % 8 == 0 and _T().use_stack
+            and stack_fits(layers, 0, 1, rows=B * n) and not chain_fits(layers, 0, 1, 2) and all(L.Kpad % 64 == 0 and L.W.shape[0] % 128 == 0 for L in layers)
+            and layers[0].W.shape[0] >= layers[1].Kpad >= layers[0].Cout):
+        # wide FP level with bf16 operands, large launch: interpolation pre-pass + two tiled bf16 GEMMs (csrc/gemm_bf16.hip) instead of the LDS stack
+        # kernel -- bit-identical to it (same operands, roundings and k order), so the row count may decide
         L0, L1 = layers
         rows = B * n
         elems = _lib.lib().g4d_frag_bf16_elems
-        (kp0, W0), (kp1, W1) = L0.Wf16_k64(), L1.Wf16_k64()
-        x16 = torch.empty(elems(rows, kp0), dtype=torch.bfloat16, device=unknown.device)
-        h16 = torch.empty(elems(rows, kp1), dtype=torch.bfloat16, device=unknown.device)
+        x16 = torch.empty(elems(rows, L0.Kpad), dtype=torch.bfloat16, device=unknown.device)
+        h16 = torch.empty(elems(rows, L1.Kpad), dtype=torch.bfloat16, device=unknown.device)
         _lib.call("g4d_interp_concat_frag_bf16", B, n, m, C2, C1, known_feats_pm.data_ptr(), _ptr(unknow_feats_pm), dist2.data_ptr(), nn_idx.data_ptr(),
-                  kp0, x16.data_ptr(), stream)
-        _lib.call("g4d_gemm_frag_bf16", rows, kp0, x16.data_ptr(), W0.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), L0.relu, L0.Cout,
-                  h16.data_ptr(), kp1, 0, 0, 0, stream)
-        _lib.call("g4d_gemm_frag_bf16", rows, kp1, h16.data_ptr(), W1.data_ptr(), L1.scale.data_ptr(), L1.shift.data_ptr(), L1.relu, L1.Cout,
+                  L0.Kpad, x16.data_ptr(), stream)
+        _lib.call("g4d_gemm_frag_bf16", rows, L0.Kpad, x16.data_ptr(), L0.Wf16.data_ptr(), L0.scale.data_ptr(), L0.shift.data_ptr(), L0.relu, L0.Cout,
+                  h16.data_ptr(), L1.Kpad, 0, 0, 0, stream)
+        _lib.call("g4d_gemm_frag_bf16", rows, L1.Kpad, h16.data_ptr(), L1.Wf16.data_ptr(), L1.scale.data_ptr(), L1.shift.data_ptr(), L1.relu, L1.Cout,
                   0, 0, out.data_ptr(), out.shape[-1], 0, stream)
-    elif gemm_shape:
-        mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx), no_chain=True)
     elif _T().use_stack and (stack_fits(layers, 0, 1, rows=B * n) or chain_fits(layers, 0, 1, 2)):
         mlp_stack(2, B * n, C2 + C1, layers, out.view(B * n, -1), interp=(n, m, C2, C1, known_feats_pm, unknow_feats_pm, dist2, nn_idx))
     elif (layers[0].Cout > 64 and _T().fp_wide_table and C1 > 0 and C1 % 4 == 0 and m < n and current_precision() == "fp32"):

@@ -73,7 +73,6 @@ class Tuning:
     fp_table: bool = True              # FP levels without skip features: first layer pre-contracted over the known rows
     fp_gemm_bf16: bool = True          # wide FP level, bf16 operands, large launches: tiled GEMMs (csrc/gemm_bf16.hip)
     fp_gemm_bf16_min_rows: int = 8192
-    fp_gemm_bf16_chainable: bool = True  # round 6: ... also for two-layer stacks the register-chain kernel could take (the middle FP level); they then never run on the chain kernel
     fp_wide_table: bool = True         # wide FP levels with skip features: known-feature columns pre-contracted
     # ---- the operator API (pointnet2_modules.py / encoder.py / pytorch_utils.py)
     dropin_fused: bool = True          # eval() + no_grad: module forward()s dispatch to the fused kernels (False: always the op-by-op route)
@@ -119,7 +118,7 @@ def from_environment() -> Tuning:
         nn_cells=_env_flag("G4D_NN_CELLS", d.nn_cells), nn_multi=_env_flag("G4D_NN_MULTI", d.nn_multi), nn_prune=_env_flag("G4D_NN_PRUNE", d.nn_prune), sa_xyz_pair=_env_flag("G4D_SA_XYZ_PAIR", d.sa_xyz_pair),
         use_sa_xyz=_env_flag("G4D_SA_XYZ", d.use_sa_xyz), sa_xyz_table=_env_flag("G4D_SA_XYZ_TABLE", d.sa_xyz_table), sa_table=_env_flag("G4D_SA_TABLE", d.sa_table),
         fp_wide_fused=_env_flag("G4D_FP_WIDE_FUSED", d.fp_wide_fused), fp_cells=_env_flag("G4D_FP_CELLS", d.fp_cells), fp_table=_env_flag("G4D_FP_TABLE", d.fp_table),
-        fp_gemm_bf16=_env_flag("G4D_FP_GEMM_BF16", d.fp_gemm_bf16), fp_gemm_bf16_min_rows=_env_int("G4D_FP_GEMM_BF16_MIN_ROWS", d.fp_gemm_bf16_min_rows), fp_gemm_bf16_chainable=_env_flag("G4D_FP_GEMM_BF16_CHAINABLE", d.fp_gemm_bf16_chainable),
+        fp_gemm_bf16=_env_flag("G4D_FP_GEMM_BF16", d.fp_gemm_bf16), fp_gemm_bf16_min_rows=_env_int("G4D_FP_GEMM_BF16_MIN_ROWS", d.fp_gemm_bf16_min_rows),
         fp_wide_table=_env_flag("G4D_FP_WIDE_TABLE", d.fp_wide_table), gcn_fuse_stack=_env_flag("G4D_GCN_FUSED", d.gcn_fuse_stack),
         dropin_fused=_env_flag("G4D_DROPIN_FUSED", d.dropin_fused), dropin_whole_model=_env_flag("G4D_DROPIN_WHOLE", d.dropin_whole_model), lbs_mfma=_env_flag("G4D_LBS_MFMA", d.lbs_mfma), lbs_one_launch=_env_flag("G4D_LBS_ONE", d.lbs_one_launch),
         lbs_one_launch_max_b=_env_int("G4D_LBS_ONE_MAX_B", d.lbs_one_launch_max_b))

@@ -406,30 +406,6 @@ def test_wide_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n
     assert float((fused.to_channel_major(outs[True]) - want).abs().max()) <= 3e-2 * scale
 
 
-@pytest.mark.parametrize("B,n,m", [(12, 1024, 256), (3, 1000, 100)])
-def test_middle_fp_level_bf16_gemm_route_is_bit_identical_to_the_stack_kernel(B, n, m, tune):
-    """Round 6: the encoder's middle FP level with bf16 operands ([256 + 96 -> 256 -> 128]; 352 columns = a k extent that is padded to 384 for the
-    64-deep chunks of the tiled GEMM) takes the GEMM route from fp_gemm_bf16_min_rows rows on and the LDS stack kernel below -- never the
-    register-chain kernel, whose summation order differs: both sizes of launch give the same bits per row."""
-    torch.manual_seed(n)
-    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
-    known = fused.fps_gather(unknown, m)
-    kf = torch.randn(B, m, 256, device="cuda")
-    skip = torch.randn(B, n, 96, device="cuda")
-    fp = _seed_bn(PM.PointnetFPModule(mlp=[352, 256, 128]))
-    outs, names = {}, {}
-    with torch.no_grad(), fused.precision("bf16"):
-        for thr in (0, 1 << 30):
-            tune(fp_gemm_bf16_min_rows=thr)
-            with _lib.timed_calls() as t:
-                outs[thr] = fused.fp_forward(fp, unknown, known, skip, kf)
-            names[thr] = [r[0] for r in t.results()]
-    assert "g4d_gemm_frag_bf16" in names[0] and names[1 << 30] == ["g4d_mlp_stack_bf16"], names
-    assert torch.equal(outs[0], outs[1 << 30])
-    want = fp(unknown, known, fused.to_channel_major(skip), fused.to_channel_major(kf))   # fp32 module: close, not equal
-    assert float((fused.to_channel_major(outs[0]) - want).abs().max()) <= 3e-2 * float(want.abs().max())
-
-
 @pytest.mark.parametrize("B,n,m,C2,C1,mlp", [(3, 256, 64, 384, 192, [576, 512, 256]), (2, 1000, 100, 128, 64, [192, 256, 128]), (1, 333, 40, 96, 100, [196, 384])])
 def test_wide_fp_level_with_the_known_part_pre_contracted(B, n, m, C2, C1, mlp, tune):
     """Wide FP levels with skip features (FP level 3 of the encoder): W [interp(f) ; s] = interp(Wa f) + Wb s -- table over the known rows, skip
