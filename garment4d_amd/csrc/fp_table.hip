@@ -42,7 +42,9 @@ constexpr int kT1 = kC1 / 16, kT2 = kC2 / 16, kT3 = kC3 / 16;
 // PERM: cell-ordered launch (the rows' original positions come from the grid records).  A template flag since round 5: as a run-time
 // branch around one load it made the number of loads in flight unknown at the join, and the compiler answered with s_waitcnt vmcnt(0) at the
 // top of EVERY tile -- behind the loads it had just issued, draining the whole ring.
-template <bool PERM, int kD>
+// HEAD (round 6): false = the FP level ALONE, 128-wide table -> 64 (what PointnetFPModule.forward runs when it is called on its own -- the reference's
+// encoder loop over the drop-in modules; the layers behind the tap are not instantiated: out = the tap).
+template <bool PERM, int kD, bool HEAD = true>
 __global__ void __launch_bounds__(256, kD <= 4 ? 3 : 2) fp_table_head_kernel(const FpTabArgs a) {
     static_assert(kT1 % kD == 0, "ring depth divides the k-steps of a tile");
     constexpr int NW2 = kC1 * kC2, NW3 = kC2 * kC3, NW4 = kC3 * kC4;
@@ -50,12 +52,16 @@ __global__ void __launch_bounds__(256, kD <= 4 ? 3 : 2) fp_table_head_kernel(con
     __shared__ __attribute__((aligned(16))) float s_ps[kC1], s_pf[kC1], s_sc2[kC2], s_sh2[kC2], s_sc3[kC3], s_sh3[kC3], s_sc4[kC4], s_sh4[kC4];
     const int tid = threadIdx.x;
     for (int i = tid; i < NW2 / 4; i += 256) reinterpret_cast<f32x4 *>(s_w2)[i] = reinterpret_cast<const f32x4 *>(a.W2)[i];
-    for (int i = tid; i < NW3 / 4; i += 256) reinterpret_cast<f32x4 *>(s_w3)[i] = reinterpret_cast<const f32x4 *>(a.W3)[i];
-    for (int i = tid; i < NW4 / 4; i += 256) reinterpret_cast<f32x4 *>(s_w4)[i] = reinterpret_cast<const f32x4 *>(a.W4)[i];
+    if constexpr (HEAD) {
+        for (int i = tid; i < NW3 / 4; i += 256) reinterpret_cast<f32x4 *>(s_w3)[i] = reinterpret_cast<const f32x4 *>(a.W3)[i];
+        for (int i = tid; i < NW4 / 4; i += 256) reinterpret_cast<f32x4 *>(s_w4)[i] = reinterpret_cast<const f32x4 *>(a.W4)[i];
+    }
     if (tid < kC1) { s_ps[tid] = a.ps[tid]; s_pf[tid] = a.pf[tid]; }
     if (tid < kC2) { s_sc2[tid] = a.sc2[tid]; s_sh2[tid] = a.sh2[tid]; }
-    if (tid < kC3) { s_sc3[tid] = a.sc3[tid]; s_sh3[tid] = a.sh3[tid]; }
-    if (tid < kC4) { s_sc4[tid] = a.sc4[tid]; s_sh4[tid] = a.sh4[tid]; }
+    if constexpr (HEAD) {
+        if (tid < kC3) { s_sc3[tid] = a.sc3[tid]; s_sh3[tid] = a.sh3[tid]; }
+        if (tid < kC4) { s_sc4[tid] = a.sc4[tid]; s_sh4[tid] = a.sh4[tid]; }
+    }
     __syncthreads();
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: tile numbers, cloud numbers and their divisions run on the scalar unit)
@@ -148,6 +154,7 @@ __global__ void __launch_bounds__(256, kD <= 4 ? 3 : 2) fp_table_head_kernel(con
             for (int r = 0; r < 4; ++r) h2[ct][r] = fmaxf(__builtin_fmaf(h2[ct][r], sc[r], sh[r]), 0.f);
             if (row_ok) *reinterpret_cast<f32x4 *>(a.tap + (size_t)cur.orow * a.tap_ld + ct * 16 + fq * 4) = h2[ct];   // the FP module's output
         }
+        if constexpr (HEAD) {
         // ---- layer 3 (64 -> 32), transposed
         __builtin_amdgcn_sched_barrier(0);
         f32x4 h3[kT3];
@@ -190,6 +197,7 @@ __global__ void __launch_bounds__(256, kD <= 4 ? 3 : 2) fp_table_head_kernel(con
                 if (fi < a.cout4 && tile * 16 + fq * 4 + r < a.rows) a.out[(size_t)orow * a.ldo + fi] = y;
             }
         }
+        }   // HEAD
         cur = nxt;
     }
 }
@@ -206,24 +214,30 @@ int g4d::fp_table_try(long long rows, int n, int m, int C2, const float *table, 
                       int col0, int tap_layer, float *tap_out, int tap_ld, hipStream_t st) {
     const int on = (int)tuning("fp_table_persistent", 1);          // A/B switch
     const long long min_rows = tuning("fp_table_min_rows", 262144);
-    if (!on || rows < min_rows || rows >= (1ll << 31) - 64 || C2 != kC1 || nlayers != 3 || in_tap || col0 != 0 || tap_layer != 0 || !tap_out) return -1;
-    if (Cout[0] != kC2 || Cout[1] != kC3 || Cout[2] > kC4 || Cout[2] < 1 || Kpad[0] != kC1 || Kpad[1] != kC2 || Kpad[2] != kC3 || !relu[0] || !relu[1]) return -1;
+    // the FP level alone (round 6): one layer behind the table, 128 -> 64, written where the launch's output goes
+    const bool alone = nlayers == 1 && !tap_out && !in_tap && col0 == 0 && Cout[0] == kC2 && Kpad[0] == kC1 && relu[0];
+    if (alone) { tap_out = out; tap_ld = ldo; }
+    if (!on || rows < min_rows || rows >= (1ll << 31) - 64 || C2 != kC1 || (nlayers != 3 && !alone) || in_tap || col0 != 0 || (!alone && tap_layer != 0) || !tap_out) return -1;
+    if (!alone && (Cout[0] != kC2 || Cout[1] != kC3 || Cout[2] > kC4 || Cout[2] < 1 || Kpad[0] != kC1 || Kpad[1] != kC2 || Kpad[2] != kC3 || !relu[0] || !relu[1])) return -1;
     if (n < 16 || m <= 0 || rows % n != 0 || (rows / n) * (long long)m * kC1 >= (1ll << 32) || tap_ld % 4 != 0 || (reinterpret_cast<size_t>(tap_out) & 15) != 0 ||
         (reinterpret_cast<size_t>(table) & 15) != 0) return -1;
-    G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift && out && W[0] && W[1] && W[2] && scale[0] && scale[1] && scale[2] && shift[0] && shift[1] && shift[2],
+    G4D_REQUIRE(table && dist2 && nn_idx && pre_scale && pre_shift && out && W[0] && scale[0] && shift[0] && (alone || (W[1] && W[2] && scale[1] && scale[2] && shift[1] && shift[2])),
                 "g4d_mlp_chain_table_f32: null pointer");
-    G4D_REQUIRE(ldo >= Cout[2] && tap_ld >= Cout[0], "g4d_mlp_chain_table_f32: output row stride %d < %d channels or tap stride %d < %d", ldo, Cout[2], tap_ld, Cout[0]);
+    G4D_REQUIRE((alone || ldo >= Cout[2]) && tap_ld >= Cout[0], "g4d_mlp_chain_table_f32: output row stride %d or tap stride %d too small", ldo, tap_ld);
     FpTabArgs a;
     a.rows = (int)rows; a.n = n; a.m = m; a.tab = table; a.dist2 = dist2; a.nn_idx = nn_idx;
     a.perm_rec = reinterpret_cast<const unsigned char *>(perm_rec); a.perm_stride = perm_stride;
     a.ps = pre_scale; a.pf = pre_shift;
-    a.W2 = W[0]; a.sc2 = scale[0]; a.sh2 = shift[0]; a.W3 = W[1]; a.sc3 = scale[1]; a.sh3 = shift[1]; a.W4 = W[2]; a.sc4 = scale[2]; a.sh4 = shift[2];
-    a.cout4 = Cout[2]; a.relu4 = relu[2]; a.out = out; a.ldo = ldo; a.tap = tap_out; a.tap_ld = tap_ld;
+    a.W2 = W[0]; a.sc2 = scale[0]; a.sh2 = shift[0];
+    a.W3 = alone ? nullptr : W[1]; a.sc3 = alone ? nullptr : scale[1]; a.sh3 = alone ? nullptr : shift[1];
+    a.W4 = alone ? nullptr : W[2]; a.sc4 = alone ? nullptr : scale[2]; a.sh4 = alone ? nullptr : shift[2];
+    a.cout4 = alone ? 0 : Cout[2]; a.relu4 = alone ? 0 : relu[2]; a.out = out; a.ldo = ldo; a.tap = tap_out; a.tap_ld = tap_ld;
     // ring depth 2 (measured at 240 clouds, 1.97 M rows: 2 k-steps ahead 422 us, 4: 436-440, 8: 448 -- the deeper rings only add registers)
     typedef void (*Kern)(const FpTabArgs);
-    const Kern kern = perm_rec ? fp_table_head_kernel<true, 2> : fp_table_head_kernel<false, 2>;
-    static int resident[2] = {0, 0};
-    int &res = resident[perm_rec ? 1 : 0];
+    const Kern kern = alone ? (perm_rec ? fp_table_head_kernel<true, 2, false> : fp_table_head_kernel<false, 2, false>)
+                            : (perm_rec ? fp_table_head_kernel<true, 2, true> : fp_table_head_kernel<false, 2, true>);
+    static int resident[4] = {0, 0, 0, 0};
+    int &res = resident[(perm_rec ? 1 : 0) + (alone ? 2 : 0)];
     if (res == 0) {   // (benign race: every thread computes the same value)
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;

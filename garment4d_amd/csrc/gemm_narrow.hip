@@ -94,13 +94,16 @@ static int gemm_narrow_launch(const LinearArgs &a, hipStream_t s) {
 // Used by launch_linear (mlp.hip) ahead of the wider GEMM forms: true when the launch was taken.
 bool gemm_narrow_try(const LinearArgs &a, hipStream_t s, int *rc) {
     static const int enabled = [] { const char *e = getenv("G4D_GEMM_NARROW"); return e ? atoi(e) : 1; }();   // A/B switch
-    if (!enabled || a.pool != 0 || a.tab || a.rows < 32768 || a.K != a.Kpad || a.K != a.Cout || (a.ldx & 3) || (a.ldo & 3) || (a.col0 & 3) ||
+    if (!enabled || a.pool != 0 || a.tab || a.rows < 32768 || a.K != a.Kpad || (a.ldx & 3) || (a.ldo & 3) || (a.col0 & 3) ||
         (reinterpret_cast<size_t>(a.X) & 15) || (reinterpret_cast<size_t>(a.out) & 15))
         return false;
-    // 36 KB of weights: four workgroups per CU.  (192 -> 192 -- SA level 3's table, 144 KB of weights, one 8-wave workgroup per CU at 256
-    //  registers -- measured 58 us against linear_kernel's 56, and as two column blocks of 96 channels with 72 KB each 56: at 61440 rows a wave
-    //  gets four tiles, the start-up copy is the launch.  Not instantiated.)
-    if (a.K == 96) { *rc = gemm_narrow_launch<6, 6, 4, 4>(a, s); return true; }
+    // 96 -> 96 (SA level 2's first-layer table): 36 KB of weights, four workgroups per CU.  64 -> 32 (the first block of the segmentation head when
+    // pytorch_utils.Conv1d is called on its own -- the drop-in module route: 1.97 M rows, 226 us on linear_kernel): 8 KB, eight workgroups per CU.
+    // (192 -> 192 -- SA level 3's table, 144 KB of weights, one 8-wave workgroup per CU at 256 registers -- measured 58 us against linear_kernel's
+    //  56, and as two column blocks of 96 channels with 72 KB each 56: at 61440 rows a wave gets four tiles, the start-up copy is the launch.  Not
+    //  instantiated.)
+    if (a.K == 96 && a.Cout == 96) { *rc = gemm_narrow_launch<6, 6, 4, 4>(a, s); return true; }
+    if (a.K == 64 && a.Cout == 32) { *rc = gemm_narrow_launch<4, 2, 4, 8>(a, s); return true; }
     return false;
 }
 

@@ -215,6 +215,28 @@ def test_nonfinite_features_through_the_no_honor_nans_kernels():
 
 
 @pytest.mark.parametrize("cells", [True, False])
+@pytest.mark.parametrize("B,n,m", [(2, 8192, 1024), (3, 5000, 300)])
+def test_fp_table_kernel_without_head_is_bit_identical_to_the_chain_kernel(B, n, m, cells, tune):
+    """Round 6: the last FP level ALONE (128 -> [128] -> 64, no head behind it) -- what PointnetFPModule.forward runs when the reference's encoder
+    loop calls the module on its own -- on the persistent kernel (HEAD = false) against the chain kernel, bit for bit."""
+    torch.manual_seed(n + 1)
+    unknown = torch.from_numpy(syn.unit_cloud(B, n, seed=n)).cuda()
+    known = fused.fps_gather(unknown, m)
+    kf = torch.randn(B, m, 128, device="cuda")
+    fp = _seed_bn(PM.PointnetFPModule(mlp=[128, 128, 64]))
+    grid = fused.build_ball_grid(unknown, 0.1)
+    tune(fp_cells=cells)
+    outs = {}
+    with torch.no_grad():
+        for on in (0, 1):
+            with tuning(fp_table_persistent=on, fp_table_min_rows=0):
+                outs[on] = fused.fp_forward(fp, unknown, known, None, kf, unknown_grid=grid)
+    assert torch.equal(outs[0], outs[1])
+    feats = fp(unknown, known, None, fused.to_channel_major(kf))
+    np.testing.assert_allclose(fused.to_channel_major(outs[1]).cpu().numpy(), feats.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cells", [True, False])
 @pytest.mark.parametrize("B,n,m", [(2, 8192, 1024), (3, 5000, 300), (1, 4100, 257)])
 def test_fp_table_kernel_is_bit_identical_to_the_chain_kernel(B, n, m, cells, tune):
     """Last FP level + head (128 -> [128] -> 64 -> 32 -> 7) in place and over cell-ordered rows; n = 5000 / 4100: 16-row tiles straddle clouds."""
@@ -488,28 +510,29 @@ def test_threshold_fp_init_min_rows(dn):
     assert isinstance(got, tuple) and _eq(ref, got)
 
 
+@pytest.mark.parametrize("K,Cout", [(96, 96), (64, 32)])
 @pytest.mark.parametrize("rows,relu,col0,extra", [(65536, False, 0, 0), (70001, True, 0, 0), (98304, False, 8, 12), (32768, True, 0, 4), (32767, False, 0, 0)])
-def test_narrow_gemm_equals_lds_tiled_kernel(rows, relu, col0, extra):
+def test_narrow_gemm_equals_lds_tiled_kernel(rows, relu, col0, extra, K, Cout):
     """csrc/gemm_narrow.hip (K = Cout = 96, the first-layer table of SA level 2: weights in LDS in fragment order, autonomous persistent waves) against
     the LDS-tiled kernel -- the same k order, so EQUAL -- and against float64: a row count that is not a multiple of 16, an output window inside a
     wider matrix, the launch size at / one row below the route's threshold."""
     g = torch.Generator().manual_seed(rows % 89)
-    x = torch.randn(rows, 96, generator=g).cuda()
-    W = (torch.randn(96, 96, generator=g) / 96 ** 0.5).cuda()
-    sc, sh = (torch.rand(96, generator=g) + 0.5).cuda(), torch.randn(96, generator=g).cuda()
+    x = torch.randn(rows, K, generator=g).cuda()
+    W = (torch.randn(Cout, K, generator=g) / K ** 0.5).cuda()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
     L = fused.PackedLayer(W, sc, sh, relu=relu)
-    ldo = col0 + 96 + extra
+    ldo = col0 + Cout + extra
     outs = [torch.full((rows, ldo), 7.0, device="cuda") for _ in range(2)]
     fused.linear(x, L, out=outs[1], col0=col0)
     for r0 in range(0, rows, 16384):                 # below the threshold the library takes the LDS-tiled kernel
         r1 = min(rows, r0 + 16384)
         fused.linear(x[r0:r1], L, out=outs[0][r0:r1], col0=col0)
     assert torch.equal(outs[0], outs[1])
-    assert (outs[1][:, :col0] == 7.0).all() and (outs[1][:, col0 + 96:] == 7.0).all()
+    assert (outs[1][:, :col0] == 7.0).all() and (outs[1][:, col0 + Cout:] == 7.0).all()
     sel = torch.randint(0, rows, (2048,), generator=g).cuda()
     ref = (x[sel].double() @ W.double().T) * sc.double() + sh.double()
     ref = torch.relu(ref) if relu else ref
-    torch.testing.assert_close(outs[1][sel, col0:col0 + 96].double(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[1][sel, col0:col0 + Cout].double(), ref, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("drows", [-1, 0, 1, 127, 128])
