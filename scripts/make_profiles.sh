@@ -72,7 +72,7 @@ PAIRS="fps_gather_grid:mlp_chain_bf16,fps_gather_grid:three_nn" timeout 600 pyth
 python scripts/time_gemm.py 2>&1 | grep -v amdgpu > $OUT/${R}_gemm_shapes.txt
 # 8b. gemm_tile.hip: phase stamps (debug build) and the SUSTAINED rate next to hipBLASLt's, with the shader clock (time_gemm.py's 7 ms bursts from an
 #     idle chip read ~12 % lower than a launch inside a running call)
-{
+[ -f $ROOT/garment4d_amd/lib/libg4d_hip_dbg.so ] && {
   echo "# gemm_tile.hip (g4d_linear_f32 at the wide FP level's shapes): where a workgroup's cycles go, and the sustained rate next to hipBLASLt's"
   echo "# scripts/dbg_gemm_phases.py on garment4d_amd/lib/libg4d_hip_dbg.so (make dbg: -DG4D_GEMM_DEBUG, cycle stamps of wave 0 of every workgroup; the stamps cost ~10 % themselves),"
   echo "# then scripts/exp_clock_gemm.py (one kernel back to back for 2 s, shader clock from scripts/micro/clockprobe.hip, board power from rocm-smi)"

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import sub_state_dict
-from garment4d_amd import fused, pointnet2_modules as PM, synthetic as syn
+from garment4d_amd import _lib, fused, pointnet2_modules as PM, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
@@ -117,6 +117,24 @@ def test_transpose_roundtrip():
     pm = fused.to_point_major(x)
     assert torch.equal(pm, x.transpose(1, 2).contiguous())
     assert torch.equal(fused.to_channel_major(pm), x)
+
+
+@pytest.mark.parametrize("B,r,c", [(2, 64, 64), (3, 8192, 64), (2, 1024, 128), (2, 100, 36), (1, 68, 260), (2, 4, 4), (5, 12, 8200)])
+def test_transpose_with_16_byte_accesses(B, r, c):
+    """g4d_transpose_f32's 64 x 64 tile kernel (round 6: both dimensions multiples of 4 and 16-byte aligned pointers): whole tiles, edge tiles in
+    both directions, tensors smaller than a tile; a view that starts 4 bytes into a buffer takes the scalar kernel -- same result."""
+    g = torch.Generator(device="cuda").manual_seed(r * 1000 + c)
+    x = torch.randn((B, r, c), generator=g, device="cuda")
+    want = x.transpose(1, 2).contiguous()
+    out = torch.full((B, c, r), float("nan"), device="cuda")
+    _lib.call("g4d_transpose_f32", B, r, c, x.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+    assert torch.equal(out, want)
+    buf = torch.empty(B * r * c + 1, device="cuda")
+    xs = buf[1:].view(B, r, c)           # 4 bytes off: not 16-byte aligned
+    xs.copy_(x)
+    out2 = torch.full((B, c, r), float("nan"), device="cuda")
+    _lib.call("g4d_transpose_f32", B, r, c, xs.data_ptr(), out2.data_ptr(), _lib.stream_ptr())
+    assert torch.equal(out2, want)
 
 
 @pytest.mark.parametrize("use_stack,use_chain", [(True, True), (True, False), (False, False)])
