@@ -1,7 +1,7 @@
 """DIAGNOSTIC: what each launch of a 240-cloud call COSTS the executor (its marginal cost with eight calls in flight), next to its duration alone.
 One eager call is recorded as C-ABI calls (as scripts/exp_overlap.py does); the whole list is replayed back to back on NS streams (NS calls in
 flight, the executor's regime, no host work in between) and timed per call; then again with one unit left out of every replay.  Marginal cost
-= (time per call with everything) - (time per call without the unit).  A unit whose marginal cost is far below its duration alone is hidden
+= (time per call with everything, measured right before and right after) - (time per call without the unit).  A unit whose marginal cost is far below its duration alone is hidden
 behind the other calls' launches (dependent rounds on a few waves); one at its full duration is issue-slot-bound like its neighbours.
     python scripts/exp_knockout240.py [B=240] [precision] [NS=8]"""
 import os, sys, gc, ctypes
@@ -115,7 +115,8 @@ for i, (label, calls) in enumerate(units):
     if only and only not in label:
         continue
     a = alone_us(calls)
-    m = full - per_call_us(skip=i)
+    f0 = per_call_us(); k = per_call_us(skip=i); f1 = per_call_us()     # the baseline on both sides of the knock-out: clocks drift over the run
+    m = 0.5 * (f0 + f1) - k
     tot_a += a; tot_m += m
     print(f"  {label[:66]:66s} {a:8.1f} {m:9.1f} {m / a if a > 0 else 0:6.2f}")
 print(f"# sums: alone {tot_a:.0f} us, marginal {tot_m:.0f} us (per call with everything: {full:.0f} us)")
