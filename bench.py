@@ -346,7 +346,7 @@ def launch_table(model, smpl, pose_pool, pool, kco, precision):
     fps = next((r for r in rows_out if r["entry"] == "g4d_fps_gather_grid_f32"), None)
     if fps is not None:
         tr = pmc_traffic("fps_bucket_grid_reg_kernel") or pmc_traffic("fps_bucket_grid_kernel")
-        roof["roofline_fps"] = dict(fps, kernel="fps_bucket_grid_reg_kernel<FM, 8> (register form: 64 VGPRs, 70 KB of LDS; from 32 clouds per launch on)", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
+        roof["roofline_fps"] = dict(fps, kernel="fps_bucket_grid_reg_kernel<FM, 16> (register form: 72 VGPRs, 70 KB of LDS, up to 16 samples per round; from 32 clouds per launch on)", traffic=None if tr is None else tr["bytes"], traffic_unit="bytes/launch",
                                     traffic_source=None if tr is None else tr["source"], share_of_call=fps["us"] / total,
                                     traffic_over_algorithmic_incl_grid_role=None if tr is None else tr["bytes"] / (fps["algorithmic_bytes"] + fps["grid_role_bytes"]),
                                     note="serial-dependency bound: dependent rounds, one workgroup per cloud; neither HBM nor MFMA limits it (frac is against HBM only "

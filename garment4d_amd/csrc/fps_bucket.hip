@@ -218,8 +218,12 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         if ((lane & (P - 1)) == i) { blx = a0; bly = a1; blz = a2; bhx = a3; bhy = a4; bhz = a5; }   // lane l holds the box of bucket l % P
     }
     if (t == 0) { spick[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
+    if (KMAX > 1 && t == 0) {   // multi-pick rounds: the first round's only sample (point 0) in the samples' exchange area
+        float *res0 = reinterpret_cast<float *>(smem_raw + 1024 + 256);
+        res0[0] = x0; res0[1] = y0; res0[2] = z0; res0[3] = INF;
+    }
     // register form: the boxes wait in LDS (the sort keys are dead: everybody read its keys before the barrier above) and are re-read at the
-    // head of every round -- six registers that are NOT live while the top-two trees run (the kernel has to fit 64 VGPRs so that a
+    // head of every round -- six registers that are NOT live while the top-two trees run (the kernel is held to 72 VGPRs -- 64 until round 6 -- so that a
     // 256-register shared-MLP wave of another stream shares the SIMD with four FPS waves); a bucket's box = 32 bytes, 8 distinct per wave
     float *sbox = reinterpret_cast<float *>(smem_raw + kFpsHdr) + (wave * P + (lane & (P - 1))) * 8;
     if constexpr (!SOA) {
@@ -229,7 +233,10 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
             *reinterpret_cast<f32x4b *>(sbox) = (f32x4b){blx, bly, blz, bhx};
             *reinterpret_cast<f32x2b *>(sbox + 4) = (f32x2b){bhy, bhz};
         }
-        if (lane < 2) slots[(wave * 2 + lane) * 4] = 0ull;   // = rec[..]: "no candidate" until the wave's first sweep publishes one
+        if (lane < 2) {   // = rec[..]: "no candidate" until the wave's first sweep publishes one (third-best value: none)
+            slots[(wave * 2 + lane) * 4] = 0ull;
+            reinterpret_cast<float *>(smem_raw)[(wave * 2 + lane) * 8 + 5] = -2.f;
+        }
     }
     __syncthreads();
 
@@ -253,12 +260,14 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         //     one 16-byte LDS store per wave, one barrier;
         //   * every wave then walks the merged order of the 2 W keys redundantly (same data, same code -> same result, no second
         //     barrier): lane l holds key l with its point's coordinates (LDS SoA cloud); arg-max by DPP, accept, mark the candidates
-        //     the accepted point would change as dirty; the walk stops at a dirty or zero-valued key, after KE picks, or once a wave's
-        //     SECOND key has gone (its third is unknown, so nothing below that key is known to be next);
+        //     the accepted point would change as dirty; the walk stops at a dirty or zero-valued key, after KE picks, or at a key
+        //     that one of a wave's UNPUBLISHED keys could outrank (both of that wave's keys are above it and its value does not exceed the wave's
+        //     third-best value, published along; until round 6: after any wave's second key -- half of all stops on a uniform cloud);
         //   * next round: box tests of all accepted samples at once (lane l: bucket l % P against sample l / P), sweeps of the active
         //     (sample, bucket) pairs (min is order-independent), pruning bound = the value of the LAST accepted key (every remaining
         //     min-distance is <= it).
-        constexpr int KE0 = KMAX * P <= 64 ? KMAX : 64 / P;   // samples per round (compile-time bound)
+        constexpr int SPP = 64 / P;                           // samples one box-test pass covers (lane l: bucket l % P against sample p0 + l / P)
+        constexpr int KE0 = KMAX;                             // samples per round (compile-time bound; round 6: up to two passes of SPP)
         const int KE = min(KE0, max(1, kcap));               // run-time cap (tuning hook G4D_FPS_KCAP)
         constexpr int NK = 2 * W;                            // keys per round (<= 32)
         static_assert(NK * 32 <= 1024 && 1024 + 256 + KE0 * 16 <= kFpsHdr, "fps multi-pick: the exchange areas must fit the LDS header");
@@ -266,9 +275,8 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem_raw);    // [2 W] candidate records of 32 bytes: key, x, y, z (the bbox partials are dead)
         unsigned *nstop = reinterpret_cast<unsigned *>(smem_raw + 1024);                // [2] the round's length: LDS atomic min over the candidates' stop positions (two slots, alternating)
         float *res = reinterpret_cast<float *>(smem_raw + 1024 + 256);                  // [KE0] the round's samples in rank order: x, y, z, value
-        const int ls = lane / P;                             // which sample of the round this lane tests its box against
-        float xs = x0, ys = y0, zs = z0;                     // lane layout: sample lane / P; round 1: the one sample is point 0
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int ls = lane / P;                             // which sample of a pass this lane tests its box against
+        typedef float f32x4 __attribute__((ext_vector_type(4)));   // (the round's samples live in LDS, `res`; round 1: the one sample is point 0, written before the barrier above)
         int ns = 1, j = 1, rpar = 0;
         if (t == 0) { nstop[0] = 0xffu; nstop[1] = 0xffu; }   // (ordered before the first use by the barriers of round 1)
         float gval = INF;
@@ -276,6 +284,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         // (register form: the record in LDS IS the cache -- an unswept wave simply leaves its two records alone)
         unsigned long long rkey = 0ull;
         float rx = x0, ry = y0, rz = z0;
+        float rv3 = -2.f;   // an upper bound of the wave's THIRD-best value (round 6): what its unpublished keys cannot exceed
 #ifdef G4D_FPS_DEBUG
         long long dbg_rounds = 0, dbg_stop[4] = {0, 0, 0, 0}, dbg_ph[4] = {0, 0, 0, 0}, dbg_actw = 0, dbg_a[4] = {0, 0, 0, 0}, dbg_pairs = 0, dbg_c1 = 0;   // stop: dirty | zero | cap | second key
 #endif
@@ -291,14 +300,20 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 const f32x2b b1_ = *reinterpret_cast<const volatile f32x2b *>(sbox + 4);
                 blx = b0.x; bly = b0.y; blz = b0.z; bhx = b0.w; bhy = b1_.x; bhz = b1_.y;
             }
-            const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
-            const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
-            const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
-            const float dbox = dist2<FM>(gx, gy, gz);
-            const unsigned long long active = __builtin_amdgcn_ballot_w64(ls < ns && dbox < gval);
-            if (active != 0ull) {   // wave-uniform
+            bool swept = false;
+            for (int p0 = 0; p0 < ns; p0 += SPP) {   // wave-uniform: one pass per SPP samples of the round
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(&res[min(p0 + ls, KE0 - 1) * 4]);   // (lanes of samples >= ns read stale slots: masked below)
+                const float xs = sv.x, ys = sv.y, zs = sv.z;
+                const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
+                const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
+                const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
+                const float dbox = dist2<FM>(gx, gy, gz);
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(p0 + ls < ns && dbox < gval);
+                if (active == 0ull) continue;   // wave-uniform
+                swept = true;
                 // 2. sweeps
-                for (int i = 0; i < ns; ++i) {
+                const int cnt = min(SPP, ns - p0);
+                for (int i = 0; i < cnt; ++i) {
                     const unsigned mi = (unsigned)(active >> (i * P)) & (P >= 32 ? 0xffffffffu : ((1u << (P & 31)) - 1u));
                     if (mi == 0u) continue;
                     const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), i * P));
@@ -313,7 +328,12 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                     }
                 }
 #ifdef G4D_FPS_DEBUG
-                { const long long now_ = clock64(); dbg_a[0] += now_ - dbg_c0; dbg_c1 = now_; dbg_pairs += __builtin_popcountll(active); }
+                dbg_pairs += __builtin_popcountll(active);
+#endif
+            }
+            if (swept) {   // wave-uniform
+#ifdef G4D_FPS_DEBUG
+                { const long long now_ = clock64(); dbg_a[0] += now_ - dbg_c0; dbg_c1 = now_; }
 #endif
                 // 3. the lane's best and second-best slot (value, then smallest rank), then the wave's
                 float tv[P];
@@ -374,8 +394,12 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                     c2r = (unsigned)__builtin_amdgcn_readlane((int)q2, h2);
                 } else {
                     c2r = wave_min_u32(v2 == c2v ? q2 : 0xffffffffu);
-                    h2 = SOA ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(v2 == c2v && q2 == c2r) | (1ull << 63));
+                    h2 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(v2 == c2v && q2 == c2r) | (1ull << 63));
                 }
+                // the wave's third-best VALUE, or rather an upper bound of it: the best value of every lane once the two published points are gone
+                // (a lane that owns both published points offers its second value instead of its unknown third: larger, hence safe)
+                const float v3w = wave_max_f32((lane == h1 || lane == h2) ? b2 : b1);
+                if constexpr (SOA) rv3 = v3w;   // (register form: the record in LDS is the cache, no register lives across the round)
                 {
                     const float cvv = lane == 0 ? c1v : c2v;
                     const unsigned crr = lane == 0 ? c1r : c2r;
@@ -396,7 +420,8 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                         if (lane < 2) {   // publish here: the record doubles as the wave's cache
                             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                             *reinterpret_cast<u64x2 *>(&rec[(wave * 2 + lane) * 4]) = (u64x2){rkey, ((unsigned long long)__float_as_uint(ry) << 32) | __float_as_uint(rx)};
-                            reinterpret_cast<float *>(rec)[(wave * 2 + lane) * 8 + 4] = rz;
+                            typedef float f32x2b __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<f32x2b *>(reinterpret_cast<float *>(rec) + (wave * 2 + lane) * 8 + 4) = (f32x2b){rz, v3w};
                         }
                     }
                 }
@@ -405,13 +430,14 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
 #endif
             }
 #ifdef G4D_FPS_DEBUG
-            { const long long now_ = clock64(); dbg_ph[0] += now_ - dbg_c0; dbg_c0 = now_; dbg_actw += active != 0ull; }
+            { const long long now_ = clock64(); dbg_ph[0] += now_ - dbg_c0; dbg_c0 = now_; dbg_actw += swept; }
 #endif
             // 4. publish the two candidates as records {key, x, y, z}; barrier A
             if (SOA && lane < 2) {
                 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2b __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<u64x2 *>(&rec[(wave * 2 + lane) * 4]) = (u64x2){rkey, ((unsigned long long)__float_as_uint(ry) << 32) | __float_as_uint(rx)};
-                reinterpret_cast<float *>(rec)[(wave * 2 + lane) * 8 + 4] = rz;
+                *reinterpret_cast<f32x2b *>(reinterpret_cast<float *>(rec) + (wave * 2 + lane) * 8 + 4) = (f32x2b){rz, rv3};
             }
             __syncthreads();
 #ifdef G4D_FPS_DEBUG
@@ -420,7 +446,7 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
             // 5. every wave ranks ITS two candidates against all 2 W and tests them for independence, in one pass: lane (c = l / 32, jj = l % 32)
             //    holds the pair (own candidate c, candidate jj).  rank = number of larger keys; bad = some larger key's point would lower this
             //    candidate's min-distance (d < value: the comparison the sweep's min makes).  The sequential walk (take keys in descending
-            //    order; stop at a candidate that an earlier pick affects or whose value is 0; stop after a wave's second key) only ever tests a
+            //    order; stop at a candidate that an earlier pick affects, whose value is 0, or that a hidden key could outrank) only ever tests a
             //    candidate against ALL larger keys, so the flags of all candidates can be computed independently, here by 16 waves at once.
             {
                 const int c = lane >> 5, jj = lane & 31;
@@ -436,11 +462,20 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
                 const unsigned long long gtm = __builtin_amdgcn_ballot_w64(gt), afm = __builtin_amdgcn_ballot_w64(aff);
                 const unsigned gth = c ? (unsigned)(gtm >> 32) : (unsigned)gtm, afh = c ? (unsigned)(afm >> 32) : (unsigned)afm;
                 const int rank = __builtin_popcount(gth);
-                // the walk stops AT this candidate (bad: affected by a larger key, empty, or -- unless it is the round's first -- value 0)
-                // or right AFTER it (a wave's second key: the wave's third is unknown; value 0)
+                // Unpublished keys (round 6; until then the walk simply stopped after a wave's SECOND key -- half of all stops on a uniform cloud):
+                // a wave publishes two keys, everything else it owns is at most its third-best value v3 (sent along with its records).  If BOTH
+                // keys of wave w rank above this candidate, one of w's hidden keys could rank above it too -- unless the candidate's value is
+                // strictly larger than v3(w).  Values only: a tie with v3 counts as "could" (safe).  A NaN fails `>`: stops, as everywhere.
+                const float v3j = recf[(jj >> 1) * 16 + 5];
+                const unsigned both = gth & (gth >> 1) & 0x55555555u;      // bit 2 w: keys 2 w and 2 w + 1 are both above this candidate
+                const bool hid = ((both >> (jj & ~1)) & 1u) != 0u && !(mv > v3j);
+                const unsigned long long hdm = __builtin_amdgcn_ballot_w64(hid);
+                const unsigned hdh = c ? (unsigned)(hdm >> 32) : (unsigned)hdm;
+                // the walk stops AT this candidate (bad: affected by a larger key, possibly outranked by a hidden key, empty, or -- unless it is the
+                // round's first -- value 0) or right AFTER it (value 0)
                 const bool zero = !(mv > 0.f);
-                const bool bad = km == 0ull || afh != 0u || (zero && rank > 0);
-                const bool after = c == 1 || zero;
+                const bool bad = km == 0ull || afh != 0u || hdh != 0u || (zero && rank > 0);
+                const bool after = zero;
                 if (jj == 0) {
                     // where the walk stops because of this candidate: AT it (bad) or right AFTER it; the round's length is the smallest
                     atomicMin(&nstop[rpar], bad ? (unsigned)rank : (after ? (unsigned)rank + 1u : 0xffu));
@@ -456,12 +491,9 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
             __syncthreads();
             // 6. the round's length = the first stop; its samples in the lane layout of the next box test; pruning bound = the last sample's value
             {
-                const int li = min(ls, KE0 - 1);
-                const f32x4 sv = *reinterpret_cast<const f32x4 *>(&res[li * 4]);   // (lanes of samples >= n read stale slots: masked by ls < ns)
                 int n = __builtin_amdgcn_readfirstlane((int)nstop[rpar]);
                 n = max(1, min(min(n, KE), m - j));
-                xs = sv.x; ys = sv.y; zs = sv.z;
-                gval = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.w), (n - 1) * P));
+                gval = res[(n - 1) * 4 + 3];   // (wave-uniform address: a broadcast read; the samples themselves are read by the next round's passes)
                 ns = n;
             }
             rpar ^= 1;
@@ -476,18 +508,23 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
             if constexpr (!SOA) {
                 blx = sbox[0]; bly = sbox[1]; blz = sbox[2]; bhx = sbox[3]; bhy = sbox[4]; bhz = sbox[5];
             }
-            const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
-            const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
-            const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
-            const unsigned long long active = __builtin_amdgcn_ballot_w64(ls < ns - 1 && dist2<FM>(gx, gy, gz) < INF);
-            for (int i = 0; i < ns - 1; ++i) {
-                const unsigned mi = (unsigned)(active >> (i * P)) & (P >= 32 ? 0xffffffffu : ((1u << (P & 31)) - 1u));
-                const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), i * P));
-                const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys), i * P));
-                const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), i * P));
+            for (int p0 = 0; p0 < ns - 1; p0 += SPP) {
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(&res[min(p0 + ls, KE0 - 1) * 4]);
+                const float xs = sv.x, ys = sv.y, zs = sv.z;
+                const float gx = fmaxf(fmaxf(blx - xs, xs - bhx), 0.f);
+                const float gy = fmaxf(fmaxf(bly - ys, ys - bhy), 0.f);
+                const float gz = fmaxf(fmaxf(blz - zs, zs - bhz), 0.f);
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(p0 + ls < ns - 1 && dist2<FM>(gx, gy, gz) < INF);
+                const int cnt = min(SPP, ns - 1 - p0);
+                for (int i = 0; i < cnt; ++i) {
+                    const unsigned mi = (unsigned)(active >> (i * P)) & (P >= 32 ? 0xffffffffu : ((1u << (P & 31)) - 1u));
+                    const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), i * P));
+                    const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys), i * P));
+                    const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs), i * P));
 #pragma unroll
-                for (int q = 0; q < P; ++q)
-                    if ((mi >> q) & 1u) md(q) = fpsb_min(dist2<FM>(px(q) - ax, py(q) - ay, pz(q) - az), md(q));
+                    for (int q = 0; q < P; ++q)
+                        if ((mi >> q) & 1u) md(q) = fpsb_min(dist2<FM>(px(q) - ax, py(q) - ay, pz(q) - az), md(q));
+                }
             }
         }
 #ifdef G4D_FPS_DEBUG
@@ -615,21 +652,27 @@ __global__ void __launch_bounds__(64 * W) fps_bucket_kernel(int n, int m, int bs
     fps_bucket_body<W, P, FM, KMAX, true>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
 }
 
-// the register form (multi-pick, no LDS cloud copy), held to 64 VGPRs: four of its waves + one 256-register wave fill a SIMD's 512
+// the register form (multi-pick, no LDS cloud copy), held to 72 VGPRs (round 6; 64 before: with up to 16 samples per round and the third-best-value
+// rule the 64-register build spilled six dwords and ran 3 % slower; measured with both builds on one box: 624-633 vs 604-607 us per 240-cloud launch,
+// 68.4-68.6k vs 68.5k frames/s fp32, 110.0-110.6k vs 111.0-111.3k bf16): four of its waves leave 224 registers of a SIMD's 512 to another call's wave
+// (the widest fp32 shared-MLP kernel takes 212)
 template <int W, int P, int FM, int KMAX>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(7, 8)))
 fps_bucket_reg_kernel(int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all, float *__restrict__ temp_all,
                       int *__restrict__ idx_all, float *__restrict__ nx_all) {
     fps_bucket_body<W, P, FM, KMAX, false>(n, m, bs, log2bs, deal, pick_off, xyz_all, temp_all, idx_all, nx_all, blockIdx.x);
 }
 
-// samples per round of the bucketed kernels: 8 (multi-pick, default) or 1 (G4D_FPS_MULTI=1: one arg-max per round, the round-2 loop)
+// samples per round of the bucketed kernels: up to kFpsPicks (multi-pick, default) or 1 (G4D_FPS_MULTI=1: one arg-max per round, the round-2 loop).
+// Round 6: 8 -> 16 (two box-test passes per round when more than 64 / P samples went out) together with the third-best-value rule of the merge:
+// on a uniform 8192 -> 1024 cloud 236 -> 166 rounds (numpy emulation: stops after a wave's second key 123 -> hidden-key stops 53, cap 23 -> 7).
+constexpr int kFpsPicks = 16;
 static int fps_multi() {
     static const int k = getenv("G4D_FPS_MULTI") ? atoi(getenv("G4D_FPS_MULTI")) : 8;
     return k > 1 ? 8 : 1;
 }
 // Which multi-pick form a launch of b clouds takes.  The LDS-copy form (rounds 3-4: 74 VGPRs, 104 KB) has the shorter round (0.61 us per pick
-// against 0.67 at b = 8): it serves the small launches, where the sampling chain is the latency of the step.  The register form (64 VGPRs,
+// against 0.67 at b = 8): it serves the small launches, where the sampling chain is the latency of the step.  The register form (72 VGPRs,
 // 70 KB) serves the coalesced calls (b >= 32 clouds): there every CU hosts a sampling workgroup and what counts is which launches of the OTHER
 // calls in flight fit beside it -- measured at 240 clouds per call, four calls in flight, both arms on one box: 51.9k -> 53.6k frames/s
 // fp32, 94.4k -> 96.8k bf16 (profiles/r05_overlap_pairs_240clouds.txt: next to fp_init 0.98 -> 0.80 of the sum, next to the tiled GEMMs
@@ -639,7 +682,7 @@ static bool fps_soa(int b) {
     return k < 0 ? b < 32 : k != 0;
 }
 static int fps_kcap() {   // tuning hook: at most this many samples per round
-    static const int k = getenv("G4D_FPS_KCAP") ? atoi(getenv("G4D_FPS_KCAP")) : 8;
+    static const int k = getenv("G4D_FPS_KCAP") ? atoi(getenv("G4D_FPS_KCAP")) : kFpsPicks;
     return k < 1 ? 1 : (k > 64 ? 64 : k);
 }
 
@@ -655,7 +698,7 @@ __global__ void __launch_bounds__(1024) fps_bucket_grid_kernel(int b, int n, int
 }
 
 template <int FM, int KMAX>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8)))
 fps_bucket_grid_reg_kernel(int b, int n, int m, int bs, int log2bs, int deal, int pick_off, const float *__restrict__ xyz_all, int *__restrict__ idx_all,
                            float *__restrict__ nx_all, int cmax, float cell_req, unsigned char *__restrict__ ws_all, size_t ws_stride) {
     if ((int)blockIdx.x < b) fps_bucket_body<16, 8, FM, KMAX, false>(n, m, bs, log2bs, deal, pick_off, xyz_all, nullptr, idx_all, nx_all, blockIdx.x);
@@ -666,13 +709,13 @@ template <int W, int P, int FM>
 static int launch_bucket_fm(int b, int n, int m, int bs, int log2bs, const float *xyz, float *temp, int *idx, float *nx, hipStream_t s) {
     const size_t npad = (size_t)64 * W * P;
     const bool multi = fps_multi() > 1;
-    const bool soa = !multi || fps_soa(b) || W != 16;   // (the register form is held to 64 VGPRs: 16 waves x 4 or 8 points per lane only)
+    const bool soa = !multi || fps_soa(b) || W != 16;   // (the register form is held to 72 VGPRs: 16 waves x 4 or 8 points per lane only)
     const size_t body = (!soa || npad * 8 > (size_t)n * 12) ? npad * 8 : (size_t)n * 12;
     const size_t pick_off = (kFpsHdr + body + 15) & ~(size_t)15;
     const size_t lds = pick_off + (size_t)m * 4;
     if (lds > 160 * 1024 - 1024) return -1;   // the pick list lives in LDS: m beyond ~15.8k at n = 8192 goes to the next route (fps.hip)
-    auto kern = multi ? fps_bucket_kernel<W, P, FM, 8> : fps_bucket_kernel<W, P, FM, 1>;
-    if constexpr (W == 16) { if (!soa) kern = fps_bucket_reg_kernel<W, P, FM, 8>; }
+    auto kern = multi ? fps_bucket_kernel<W, P, FM, kFpsPicks> : fps_bucket_kernel<W, P, FM, 1>;
+    if constexpr (W == 16) { if (!soa) kern = fps_bucket_reg_kernel<W, P, FM, kFpsPicks>; }
     static unsigned long long attr_done[3] = {0, 0, 0};  // one bit per device
     if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024 - 1024, attr_done[multi ? (soa ? 1 : 2) : 0], "g4d_fps_f32(bucketed)")) return rc;
     // measured at N = 8192, M = 1024, B = 8 (scripts/time_fps.py): deal 1 / 2 / 4 / 8 -> 0.812 / 0.783 / 0.757 / 0.748 us per round
@@ -705,13 +748,13 @@ int fps_bucket_grid_launch(int b, int n, int m, int bs, int log2bs, const float 
     const int mode = distance_contraction();
     const int slot = (mode == 0 ? 0 : (mode == 1 ? 1 : 2)) + (multi ? (soa ? 3 : 6) : 0);
     const void *k = nullptr;
-    G4D_WITH_FM(mode, k = multi ? (soa ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 8>) : reinterpret_cast<const void *>(fps_bucket_grid_reg_kernel<FM, 8>))
+    G4D_WITH_FM(mode, k = multi ? (soa ? reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, kFpsPicks>) : reinterpret_cast<const void *>(fps_bucket_grid_reg_kernel<FM, kFpsPicks>))
                                 : reinterpret_cast<const void *>(fps_bucket_grid_kernel<FM, 1>))
     if (const int rc = ensure_dynamic_lds(k, 160 * 1024 - 1024, attr[slot], "g4d_fps_gather_grid_f32")) return rc;
 #define G4D_GRID_LAUNCH(KM, KERN)                                                                                                                                    \
     G4D_WITH_FM(mode, hipLaunchKernelGGL((KERN<FM, KM>), dim3(2 * b), dim3(1024), lds, s, b, n, m, bs, log2bs, P | (fps_kcap() << 8), (int)pick_off, xyz, idx, nx, \
                                          cmax, rmax * kCellSlack, reinterpret_cast<unsigned char *>(grid_ws), grid_cloud_bytes(n)))
-    if (multi && soa) { G4D_GRID_LAUNCH(8, fps_bucket_grid_kernel) } else if (multi) { G4D_GRID_LAUNCH(8, fps_bucket_grid_reg_kernel) } else { G4D_GRID_LAUNCH(1, fps_bucket_grid_kernel) }
+    if (multi && soa) { G4D_GRID_LAUNCH(kFpsPicks, fps_bucket_grid_kernel) } else if (multi) { G4D_GRID_LAUNCH(kFpsPicks, fps_bucket_grid_reg_kernel) } else { G4D_GRID_LAUNCH(1, fps_bucket_grid_kernel) }
 #undef G4D_GRID_LAUNCH
     return check_launch("g4d_fps_gather_grid_f32");
 }
