@@ -20,5 +20,5 @@ if len(sys.argv) > 1:
     print(f"deal {os.environ.get('G4D_FPS_DEAL', '-')} kcap {os.environ.get('G4D_FPS_KCAP', '-')}: {t:7.1f} us  = {t / 1023:.3f} us/pick   checksum {int(idx.long().sum())}")
 else:
     for d in ("1", "2", "4", "8"):
-        for k in ("8", "4", "2"):
+        for k in ("16",):
             subprocess.run([sys.executable, __file__, "run"], env=dict(os.environ, G4D_FPS_DEAL=d, G4D_FPS_KCAP=k))
