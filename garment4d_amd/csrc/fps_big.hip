@@ -10,7 +10,9 @@
 //     one of its buckets was swept, the lane candidate is the best of the P / 8 group candidates;
 //   * workgroup exchange as in fps_bucket.hip (one LDS atomic max per wave on a rotating slot, one barrier); the winner's coordinates
 //     are one broadcast load from global memory.
-// What bounds a round: the dependent chain box test -> gather of the swept buckets (one L2 round trip per active group of 8 slots) ->
+// Round 6: multi-pick rounds (fps_big_kernel<., ., MULTI = true>, the default; G4D_FPS_BIG_MULTI=0 restores one pick per round): 32 x 32768 -> 8192 in
+// 6.6 ms instead of 12.6 (0.80 us per pick).
+// What bounds a single-pick round: the dependent chain box test -> gather of the swept buckets (one L2 round trip per active group of 8 slots) ->
 // group / lane / wave arg-max -> barrier -> winner decode -> winner's coordinates (another L2 round trip).  Measured: see DESIGN.md.
 // The generic kernel this replaces for these sizes (fps.hip: 1024 threads striding over global min-distances, the reference's own
 // shape) runs ~3 us per round at N = 8192 and ~10 us at N = 32768.
@@ -68,7 +70,9 @@ struct __attribute__((packed, aligned(4))) F3g { float x, y, z; };
 __device__ __forceinline__ F3g fpsg_ld3(const float *base, int k) { return *reinterpret_cast<const F3g *>(base + (size_t)k * 3); }
 
 // W = 16 waves, P slots per lane (16 | 32): N <= 1024 P.  LDS: header + 4 * 1024 P sort keys (the pick list reuses that region).
-template <int P, int FM>
+// MULTI (round 6): multi-pick rounds as in fps_bucket.hip -- every wave publishes its two best keys and its third-best VALUE, one pass of pair tests
+// decides how long a prefix of the merged order goes out this round (up to 16 samples), see the loop below.
+template <int P, int FM, bool MULTI>
 __global__ void __launch_bounds__(1024) fps_big_kernel(int n, int m, int bs, int log2bs, int idxbits, const float *__restrict__ xyz_all,
                                                        float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ nx_all) {
     constexpr int W = 16, T = 1024, NPAD = T * P, G = P / 8;
@@ -160,6 +164,156 @@ __global__ void __launch_bounds__(1024) fps_big_kernel(int n, int m, int bs, int
     if (t == 0) { spick[0] = 0; slots[0] = 0ull; slots[1] = 0ull; slots[2] = 0ull; }
     __syncthreads();
 
+    if constexpr (MULTI) {
+        // ---- multi-pick rounds (the protocol of fps_bucket.hip's multi-pick loop, laid out for coordinates that live in global memory) -----------
+        //   1. the round's samples (<= 16, in LDS) are tested against the wave's P boxes one sample at a time (lane l: bucket l), the swept buckets'
+        //      rows are gathered ONCE per round (one L2 round trip per active half-group of 4 slots) and every sample that reaches them is applied;
+        //   2. a swept wave recomputes its two best keys and an upper bound of its third-best value and publishes {key, v3}; barrier A;
+        //   3. pair tests: lane (c, jj) holds (own candidate c, candidate jj), both points' coordinates fetched from the cloud by the index the key's
+        //      rank encodes (one L2 round trip for all 32 candidates at once); rank = number of larger keys; a candidate stops the walk if a larger
+        //      key's point would lower it, if a hidden key could outrank it (both keys of some wave above it, value not above that wave's third), or
+        //      at value 0; accepted candidates write their coordinates and index at slot `rank`; barrier B;
+        //   4. everybody reads the round's length.
+        constexpr int KE = 16;
+        unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem_raw);   // [2 W] records of 32 bytes: key at +0, third-best value at +20
+        float *recf = reinterpret_cast<float *>(smem_raw);
+        unsigned *nstop = reinterpret_cast<unsigned *>(smem_raw + 1024);               // [2] the round's length (LDS atomic min), alternating
+        float *res = reinterpret_cast<float *>(smem_raw + 1024 + 256);                 // [KE] the round's samples: x, y, z, value
+        static_assert(2 * W * 32 <= 1024 && 1024 + 256 + KE * 16 <= kBigHdr, "fps_big multi-pick: the exchange areas must fit the LDS header");
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        if (lane < 2) { rec[(wave * 2 + lane) * 4] = 0ull; recf[(wave * 2 + lane) * 8 + 5] = -2.f; }
+        if (t == 0) {
+            const F3g p0 = fpsg_ld3(xyz, 0);
+            nstop[0] = 0xffu; nstop[1] = 0xffu;
+            res[0] = p0.x; res[1] = p0.y; res[2] = p0.z; res[3] = INF;
+        }
+        __syncthreads();
+        int ns = 1, j = 1, rpar = 0;
+        float gval = INF;
+        // box tests of `cnt` samples + sweeps of the buckets they reach (pruning bound `bound`); returns the union of the swept buckets
+        auto sweep = [&](int cnt, float bound) -> unsigned {
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(&res[min(lane, KE - 1) * 4]);   // lane i: sample i
+            unsigned am = 0u, U = 0u;
+            for (int i = 0; i < cnt; ++i) {
+                const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.x), i)), ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.y), i)),
+                            az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.z), i));
+                const float gx = fmaxf(fmaxf(blx - ax, ax - bhx), 0.f), gy = fmaxf(fmaxf(bly - ay, ay - bhy), 0.f), gz = fmaxf(fmaxf(blz - az, az - bhz), 0.f);
+                const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(lane < P && dist2<FM>(gx, gy, gz) < bound);
+                am = lane == i ? mask : am;   // lane i keeps sample i's buckets
+                U |= mask;
+            }
+            if (U == 0u) return 0u;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (((U >> (8 * g)) & 0xffu) == 0u) continue;   // wave-uniform
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (((U >> (8 * g + 4 * h)) & 0xfu) == 0u) continue;   // wave-uniform
+                    F3g p[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        unsigned r = G4D_RK(8 * g + 4 * h + s4);
+                        asm volatile("" : "+v"(r));   // (see the single-pick loop: keeps the row addresses from being hoisted and spilled)
+                        p[s4] = fpsg_ld3(xyz, r == 0xffffu ? 0 : fpsg_index16(r));
+                    }
+                    for (int i = 0; i < cnt; ++i) {
+                        const unsigned mi = ((unsigned)__builtin_amdgcn_readlane((int)am, i) >> (8 * g + 4 * h)) & 0xfu;
+                        if (mi == 0u) continue;   // wave-uniform
+                        const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.x), i)), ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.y), i)),
+                                    az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv.z), i));
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            if ((mi >> s4) & 1u) {
+                                const float dx = p[s4].x - ax, dy = p[s4].y - ay, dz = p[s4].z - az;
+                                md[8 * g + 4 * h + s4] = fpsg_min(dist2<FM>(dx, dy, dz), md[8 * g + 4 * h + s4]);
+                            }
+                    }
+                }
+            }
+            return U;
+        };
+        while (j < m) {
+            if (sweep(ns, gval) != 0u) {   // wave-uniform
+                // the lane's best and second-best slot (value, then smallest rank)
+                float b1 = md[0];
+#pragma unroll
+                for (int i = 1; i < P; ++i) b1 = fpsg_max(b1, md[i]);
+                unsigned r1 = 0xffffu;
+#pragma unroll
+                for (int i = 0; i < P; ++i) r1 = min(r1, md[i] == b1 ? G4D_RK(i) : 0xffffu);
+                float b2 = -2.f;
+#pragma unroll
+                for (int i = 0; i < P; ++i) b2 = fpsg_max(b2, G4D_RK(i) == r1 ? -2.f : md[i]);   // ranks of real points are unique: drops exactly the best slot
+                unsigned r2 = 0xffffu;
+#pragma unroll
+                for (int i = 0; i < P; ++i) r2 = min(r2, (md[i] == b2 && G4D_RK(i) != r1) ? G4D_RK(i) : 0xffffu);
+                // the wave's two best keys and an upper bound of its third-best value
+                const float c1v = wave_max_f32(b1);
+                unsigned long long hit = __builtin_amdgcn_ballot_w64(b1 == c1v);
+                unsigned c1r, c2r;
+                int h1, h2;
+                if (__builtin_popcountll(hit) == 1) { h1 = __builtin_ctzll(hit); c1r = (unsigned)__builtin_amdgcn_readlane((int)r1, h1); }
+                else { c1r = wave_min_u32(b1 == c1v ? r1 : 0xffffu); h1 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == c1v && r1 == c1r) | (1ull << 63)); }
+                const float v2 = lane == h1 ? b2 : b1;
+                const unsigned q2 = lane == h1 ? r2 : r1;
+                const float c2v = wave_max_f32(v2);
+                hit = __builtin_amdgcn_ballot_w64(v2 == c2v);
+                if (__builtin_popcountll(hit) == 1) { h2 = __builtin_ctzll(hit); c2r = (unsigned)__builtin_amdgcn_readlane((int)q2, h2); }
+                else { c2r = wave_min_u32(v2 == c2v ? q2 : 0xffffu); h2 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(v2 == c2v && q2 == c2r) | (1ull << 63)); }
+                const float v3w = wave_max_f32((lane == h1 || lane == h2) ? b2 : b1);   // (a lane owning both published points offers its second value: larger, safe)
+                if (lane < 2) {
+                    const float cvv = lane == 0 ? c1v : c2v;
+                    const unsigned c16 = lane == 0 ? c1r : c2r;
+                    const unsigned r32 = ((c16 >> 5) << 16) | (c16 & 31u);   // the 32-bit rank of fpsg_rank
+                    rec[(wave * 2 + lane) * 4] = (cvv < 0.f || c16 == 0xffffu) ? 0ull : (((unsigned long long)__float_as_uint(cvv) << 32) | (unsigned)(~r32));
+                    recf[(wave * 2 + lane) * 8 + 5] = v3w;
+                }
+            }
+            __syncthreads();
+            {
+                const int c = lane >> 5, jj = lane & 31;
+                const unsigned long long kj = rec[jj * 4];
+                const int me = wave * 2 + c;
+                const unsigned long long km = rec[me * 4];
+                const float v3j = recf[(jj >> 1) * 16 + 5];
+                int ij = fpsg_index(~(unsigned)kj, log2bs), im = fpsg_index(~(unsigned)km, log2bs);
+                ij = (kj != 0ull && (unsigned)ij < (unsigned)n) ? ij : 0;   // (an empty slot reads point 0: never used)
+                im = (km != 0ull && (unsigned)im < (unsigned)n) ? im : 0;
+                const F3g pj = fpsg_ld3(xyz, ij), pm = fpsg_ld3(xyz, im);
+                const float mv = __uint_as_float((unsigned)(km >> 32));
+                const bool gt = kj > km;
+                const bool aff = gt && !(dist2<FM>(pm.x - pj.x, pm.y - pj.y, pm.z - pj.z) >= mv);
+                const unsigned long long gtm = __builtin_amdgcn_ballot_w64(gt), afm = __builtin_amdgcn_ballot_w64(aff);
+                const unsigned gth = c ? (unsigned)(gtm >> 32) : (unsigned)gtm, afh = c ? (unsigned)(afm >> 32) : (unsigned)afm;
+                const int rank = __builtin_popcount(gth);
+                const unsigned both = gth & (gth >> 1) & 0x55555555u;      // bit 2 w: both keys of wave w are above this candidate
+                const bool hid = ((both >> (jj & ~1)) & 1u) != 0u && !(mv > v3j);
+                const unsigned long long hdm = __builtin_amdgcn_ballot_w64(hid);
+                const unsigned hdh = c ? (unsigned)(hdm >> 32) : (unsigned)hdm;
+                const bool zero = !(mv > 0.f);
+                const bool bad = km == 0ull || afh != 0u || hdh != 0u || (zero && rank > 0);
+                if (jj == 0) {
+                    atomicMin(&nstop[rpar], bad ? (unsigned)rank : (zero ? (unsigned)rank + 1u : 0xffu));
+                    if (rank < KE) {   // ranks are unique among real keys; empty slots all carry point 0
+                        *reinterpret_cast<f32x4 *>(&res[rank * 4]) = (f32x4){pm.x, pm.y, pm.z, mv};
+                        if (j + rank < m) spick[j + rank] = im;
+                    }
+                }
+                if (t == 0) nstop[rpar ^ 1] = 0xffu;
+            }
+            __syncthreads();
+            {
+                int nn = __builtin_amdgcn_readfirstlane((int)nstop[rpar]);
+                nn = max(1, min(min(nn, KE), m - j));
+                gval = res[(nn - 1) * 4 + 3];
+                ns = nn;
+            }
+            rpar ^= 1;
+            j += ns;
+        }
+        // the reference's scratch holds the min-distances to every sample but the LAST one (sampling_gpu.cu:129-141): the final round's others
+        if (temp && ns > 1) sweep(ns - 1, INF);
+    } else {
     float x1, y1, z1;
     { const F3g p0 = fpsg_ld3(xyz, 0); x1 = p0.x; y1 = p0.y; z1 = p0.z; }
     float gval = INF;          // the last winner's value: no min-distance exceeds it
@@ -249,6 +403,7 @@ __global__ void __launch_bounds__(1024) fps_big_kernel(int n, int m, int bs, int
         x1 = pw.x; y1 = pw.y; z1 = pw.z;
         if (t == 0) spick[j] = old;
     }
+    }   // single-pick rounds
     __syncthreads();
     for (int j = t; j < m; j += T) {
         const int k = spick[j];
@@ -268,12 +423,14 @@ static int launch_big(int b, int n, int m, int bs, int log2bs, const float *xyz,
     const size_t lds = kBigHdr + (size_t)4 * 1024 * P;   // m <= n <= 1024 P: the pick list fits the sort region
     int idxbits = 1;
     while ((1 << idxbits) < n + 1) ++idxbits;            // 2^idxbits > n: the padding key 0xffffffff is never a real key
-    static unsigned long long attr[3] = {0, 0, 0};
+    static unsigned long long attr[6] = {0, 0, 0, 0, 0, 0};
     const int mode = distance_contraction();
     const void *k = nullptr;
-    G4D_WITH_FM(mode, k = reinterpret_cast<const void *>(fps_big_kernel<P, FM>))
-    if (const int rc = ensure_dynamic_lds(k, 160 * 1024 - 1024, attr[mode == 0 ? 0 : (mode == 1 ? 1 : 2)], "g4d_fps_f32(large)")) return rc;
-    G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_big_kernel<P, FM>), dim3(b), dim3(1024), lds, s, n, m, bs, log2bs, idxbits, xyz, temp, idx, nx))
+    static const int multi = getenv("G4D_FPS_BIG_MULTI") ? atoi(getenv("G4D_FPS_BIG_MULTI")) : 1;   // 0: one pick per round (the round-3 loop)
+    G4D_WITH_FM(mode, k = multi ? reinterpret_cast<const void *>(fps_big_kernel<P, FM, true>) : reinterpret_cast<const void *>(fps_big_kernel<P, FM, false>))
+    if (const int rc = ensure_dynamic_lds(k, 160 * 1024 - 1024, attr[(mode == 0 ? 0 : (mode == 1 ? 1 : 2)) + (multi ? 3 : 0)], "g4d_fps_f32(large)")) return rc;
+    if (multi) { G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_big_kernel<P, FM, true>), dim3(b), dim3(1024), lds, s, n, m, bs, log2bs, idxbits, xyz, temp, idx, nx)) }
+    else { G4D_WITH_FM(mode, hipLaunchKernelGGL((fps_big_kernel<P, FM, false>), dim3(b), dim3(1024), lds, s, n, m, bs, log2bs, idxbits, xyz, temp, idx, nx)) }
     return check_launch("g4d_fps_f32(large)");
 }
 
