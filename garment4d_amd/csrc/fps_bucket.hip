@@ -268,8 +268,9 @@ __device__ __forceinline__ void fps_bucket_body(int n, int m, int bs, int log2bs
         //     min-distance is <= it).
         constexpr int SPP = 64 / P;                           // samples one box-test pass covers (lane l: bucket l % P against sample p0 + l / P)
         constexpr int KE0 = KMAX;                             // samples per round (compile-time bound; round 6: up to two passes of SPP)
-        const int KE = min(KE0, max(1, kcap));               // run-time cap (tuning hook G4D_FPS_KCAP)
         constexpr int NK = 2 * W;                            // keys per round (<= 32)
+        const int KE = min(min(KE0, NK), max(1, kcap));      // run-time cap (tuning hook G4D_FPS_KCAP); never more than the keys a round has -- with
+                                                             // W = 4 all 8 candidates can be clean, and nobody would have written samples 8 .. 15
         static_assert(NK * 32 <= 1024 && 1024 + 256 + KE0 * 16 <= kFpsHdr, "fps multi-pick: the exchange areas must fit the LDS header");
         static_assert(NK <= 64 && KE0 >= 1, "fps multi-pick: key / sample counts must fit a wave");
         unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem_raw);    // [2 W] candidate records of 32 bytes: key, x, y, z (the bbox partials are dead)
